@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""SMAP inference hot path benchmark (BASELINE.json metric: frames/sec at 3x512x832).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over one batch of B=8 synthetic frames per GPU
+(BASELINE config 3): SMAP backbone forward (HIP engine) -> /255,/127 scaling -> depth-aware
+association -> 3D lifting -> device-to-host copy of the poses -> result records; with N>1
+every rank processes its own batch (weak scaling, frames shard with no data-path collective)
+and the step ends with the RCCL all_gather of the per-frame JSON records (config 4).
+Inputs are resident in HBM before the timed region.  Weights are the default random init
+(torch.manual_seed(0)); with them the pelvis heat-map has no peaks, so grouping of the
+network's own output is trivial -- to keep representative association work inside the timed
+region, every step ALSO associates + lifts a resident batch of synthetic 8-person scenes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+ALG_GFLOP_PER_FRAME = 300.628      # SURVEY.md 8d / BASELINE.md 3: inference-live conv FLOPs (2*MAC)
+PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+H, W = 512, 832
+
+
+def records_from(pred_2d, pred_3d, root_z, counts, tag):
+    out = []
+    for i, P in enumerate(counts):
+        if P == 0:
+            continue                   # test.py:131-132
+        out.append({"pred_2d": pred_2d[i, :P].tolist(), "pred_3d": pred_3d[i, :P].tolist(),
+                    "root_d": root_z[i, :P].tolist(), "image_path": f"{tag}/{i}", "gt_3d": [], "gt_2d": []})
+    return out
+
+
+def cpu_baseline(sd, scenes, budget_s=20.0):
+    """Reference CPU path restated (oracle/): torch-CPU backbone + C association + lifting,
+    on a bounded sample of the same workload."""
+    from oracle.backbone_ref import smap_forward
+    from oracle import oracle_lib as O
+    torch.set_num_threads(os.cpu_count())
+    x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(1234))
+    sdf = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        smap_forward(sdf, x)                     # warm-up
+        t0, n = time.time(), 0
+        while n < 2 or (time.time() - t0 < budget_s * 0.7 and n < 10):
+            smap_forward(sdf, x)
+            n += 1
+        t_bb = (time.time() - t0) / n
+    cam = np.array([1.0, 832, 512, 832, 512, 832, 832, 416, 256], np.float64)
+    det = np.zeros((14, 128, 208), np.float32)
+    t0, m = time.time(), 0
+    for hms, rd in scenes[:8]:
+        bodys, _, _ = O.connect(hms, rd)
+        O.lift(bodys, det, rd, cam)
+        m += 1
+    t_as = (time.time() - t0) / max(m, 1)
+    return {"value": 1.0 / (t_bb + t_as), "unit": "frames/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} x backbone fwd of 1x3x{H}x{W} (torch CPU fp32, {torch.get_num_threads()} threads) "
+                      f"+ {m} x association+lift of a synthetic 8-person frame (C oracle, 1 thread)",
+            "backbone_ms": t_bb * 1e3, "assoc_ms": t_as * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    import dapalib
+    from helpers import make_cfg, synth_scene
+    from model.smap import SMAP
+    from smap_amd.dist import gather_json
+
+    B = args.batch
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((128, 208))).eval()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(dev)
+    eng = net.engine(B, H, W, dev)
+    imgs = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    scenes = [synth_scene(8, seed=1000 * rank + i)[:2] for i in range(B)]
+    s_hms = torch.from_numpy(np.stack([s[0] for s in scenes])).to(dev)
+    s_rd = torch.from_numpy(np.stack([s[1] for s in scenes])).to(dev)
+    cams = np.tile(np.array([1.0, 832, 512, 832, 512, 832, 832, 416, 256], np.float64), (B, 1))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    bb_ms = []
+
+    def step(timed):
+        if timed:
+            ev[0].record()
+        hms, det_d, root_d = eng.run(imgs)
+        if timed:
+            ev[1].record()
+        dapalib.scale_hms_(hms)                                   # test.py:111-112
+        res = []
+        for tag, (h, rd, dd) in (("net", (hms, root_d, det_d)), ("synth", (s_hms, s_rd, det_d))):
+            bodys, counts = dapalib.connect_batch(h, rd)
+            p2, p3, rz = dapalib.lift_batch(bodys, counts, dd, rd, cams)
+            res.append((tag, p2, p3, rz, counts))
+        recs = []
+        for tag, p2, p3, rz, counts in res:                       # device -> host of the poses
+            recs += records_from(p2.cpu().numpy(), p3.cpu().numpy(), rz.cpu().numpy(), counts.cpu().numpy(), tag)
+        allr = gather_json(recs, dev)
+        if timed:
+            torch.cuda.synchronize()
+            bb_ms.append(ev[0].elapsed_time(ev[1]))
+        return allr
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        frames = B * world * args.steps
+        fps = frames / dt
+        bb = float(np.mean(bb_ms)) * 1e-3
+        achieved = ALG_GFLOP_PER_FRAME * B / bb / 1e3            # TFLOP/s over the whole backbone schedule
+        out = {
+            "metric": "frames/sec at 3x512x832 (SMAP backbone + depth-aware association + 3D lifting)",
+            "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 (fp32 accumulate; association fp32/fp64)", "data": "synthetic",
+            "config": {"workload": f"batch={B} x 3x512x832 per GPU, full SMAP + depth-aware PAF association "
+                                   f"+ lifting (BASELINE configs[2]; configs[3] when n_gpus=8)",
+                       "frames_per_step": B * world, "persons_in_last_step": sum(len(r) for r in last)},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F16_TFLOPS, "traffic": None,
+                         "kernel": "conv_igemm_kernel (all backbone launches, HIP-event bracket)",
+                         "backbone_ms_per_batch": bb * 1e3,
+                         "algorithmic_gflop_per_frame": ALG_GFLOP_PER_FRAME},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, scenes)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

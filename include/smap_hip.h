@@ -1,0 +1,138 @@
+/*
+ * smap_hip.h -- C ABI of libsmap_hip.so, the MI355X (gfx950) implementation of
+ * the SMAP inference hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * Every entry point is stream-ordered on the hipStream_t passed as `stream`
+ * (void* so that this header needs no HIP include), never allocates, never
+ * synchronises, borrows all buffers from the caller and returns
+ *      0            on success,
+ *      SMAP_E_ARG   (-1) on an argument error,
+ *      -(1000+e)    when a HIP call failed with hipError_t e.
+ * All pointers are DEVICE pointers unless the parameter says "host".
+ *
+ * The reference interface each entry replaces is cited as file:line relative
+ * to the reference checkout (zju3dv/SMAP).
+ */
+#ifndef SMAP_HIP_H
+#define SMAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMAP_E_ARG (-1)
+
+#define SMAP_NJ 15        /* association.cpp:18 nJoints  */
+#define SMAP_NL 14        /* association.cpp:19 nLimbs   */
+#define SMAP_MAXP 127     /* association.cpp:20 maxPeaks */
+#define SMAP_HMS_C 43     /* association.cpp:21 heatmapDim[0] = 15 keypoints + 28 PAF */
+
+/* Library / build identification (also used by the tests to prove the HIP
+ * library, not a fallback, is what is loaded). */
+const char* smap_version(void);
+
+/* ---- association: replaces extensions/association.cpp::extract/connect ---- */
+
+/* test.py:111-112  hmsIn[:15] /= 255 ; hmsIn[15:] /= 127  (in place, fp32 IEEE divide)
+ * hms: [B,43,H,W] fp32. */
+int smap_scale_hms(float* hms, int B, int H, int W, void* stream);
+
+/* nmsBase.cu:10-175 (nmsRegisterKernel + exclusive_scan + writeResultKernel) fused.
+ * hms  : [B,C,H,W] fp32, C >= 15 (only channels 0..14 are read)
+ * peaks: [B,15,128,3] fp32 out; slot 0 = (count,0,0), slots > count zero-filled.
+ * Requires H*W <= 32768. */
+int smap_nms(const float* hms, int B, int C, int H, int W, float threshold,
+             float* peaks, void* stream);
+
+/* bodyPartConnectorBase.cu:11-63,104-189 (process + pafScoreKernel).
+ * hms: [B,43,H,W]; peaks as above; scores: [B,14,127,127] fp32 out (-1 where no pair). */
+int smap_paf_score(const float* hms, const float* peaks, int B, int H, int W,
+                   float* scores, void* stream);
+
+/* association.cpp:123-233 (findConnectedJoints), batched: one frame per workgroup.
+ * rdepth: [B,H,W] fp32 root-depth maps; bodys: [B,127,15,4] fp32 out (x,y,0,score in
+ * heat-map pixels; rows >= counts[b] are zero); counts: [B] int32 out. */
+int smap_group(const float* peaks, const float* scores, const float* rdepth, int B,
+               int H, int W, int root_idx, int dist_flag, float* bodys, int32_t* counts,
+               void* stream);
+
+/* test.py:116-134 + test_util.py:45-99 + post_3d.py:4-27 (x4, nearest x4 upsample,
+ * generate_relZ, chain_bones, gen_3d_pose, back_projection), batched.
+ * det_d : [B,14,H,W] fp32, root_d: [B,H,W] fp32 (heat-map resolution)
+ * cams  : [B,9] f64 = scale,img_w,img_h,net_w,net_h,f_x,f_y,cx,cy
+ * pred_2d: [B,127,15,4] fp32 out; pred_3d: [B,127,15,4] f64 out; root_z: [B,127] f64 out. */
+int smap_lift(const float* bodys, const int32_t* counts, const float* det_d,
+              const float* root_d, const double* cams, int B, int H, int W,
+              float* pred_2d, double* pred_3d, double* root_z, void* stream);
+
+/* test_util.py:102-131 + refinenet.py:5-37 (lift_and_refine_3d_pose + RefineNet MLP).
+ * wt: 5 device pointers (host array) to BN-folded TRANSPOSED weights [in][out] fp32,
+ * bs: 5 device pointers (host array) to folded biases [out]; dims 75,160,256,256,128,45.
+ * refined: [B,127,15,4] f64 out. */
+int smap_refine(const float* pred_2d, const double* pred_3d, const int32_t* counts, int B,
+                const float* const* wt, const float* const* bs, double* refined, void* stream);
+
+/* refinenet.py:34-37 RefineNet.forward alone: x [N,75] fp32 -> y [N,45] fp32 (same weight format). */
+int smap_refine_mlp(const float* x, int N, const float* const* wt, const float* const* bs, float* y,
+                    void* stream);
+
+/* ---- backbone: replaces model/smap.py SMAP.forward (eval) ------------------ */
+
+/* One op of the static inference schedule.  Offsets are BYTE offsets into the
+ * caller's activation arena / weight blob; -1 = absent. */
+enum smap_op_kind {
+    SMAP_OP_CONV = 0,       /* conv_bn_relu (smap.py:13-45) with folded BN, implicit GEMM on MFMA */
+    SMAP_OP_STEM = 1,       /* ResNet_top conv 7x7 s2 (smap.py:83-84) from fp32 NCHW input      */
+    SMAP_OP_MAXPOOL = 2,    /* ResNet_top maxpool 3x3 s2 p1 (smap.py:86)                         */
+    SMAP_OP_UPADD = 3,      /* out = relu(a + bilinear_align_corners(t)) (smap.py:213-217)       */
+    SMAP_OP_HEADSUM = 4,    /* fp32 NCHW out = sum of bilinear-upsampled heads (smap.py:221-229,417-419) */
+};
+
+typedef struct smap_op {
+    int32_t kind;
+    int32_t B, H, W, Cin;           /* input geometry (CONV/MAXPOOL/UPADD: NHWC fp16; STEM: NCHW fp32) */
+    int32_t in_stride_c, in_c_off;  /* CONV: channel stride / first channel of the input pixel   */
+    int32_t Ho, Wo, Cout;           /* output geometry                                           */
+    int32_t ksize, stride, pad;
+    int32_t relu;                   /* apply ReLU after bias (+residual)                         */
+    int32_t cout_pad;               /* rows of the padded weight matrix (multiple of the N tile) */
+    int32_t out_stride_c;           /* channel stride of the output pixel (>= Cout)              */
+    int32_t out_c_off;              /* channel offset inside the output pixel                    */
+    int32_t out_fp32;               /* CONV: 1 = fp32 NHWC output (heads), 0 = fp16              */
+    int32_t tile;                   /* CONV tile selector: 0=128x128 1=128x64 2=64x64 3=128x32 4=64x128 */
+    int32_t n_aux;                  /* HEADSUM: number of source tensors (1..3)                  */
+    int64_t in_off, out_off;        /* arena byte offsets                                        */
+    int64_t w_off, bias_off;        /* weight-blob byte offsets (CONV: fp16 [cout_pad][K] + fp32 [cout_pad];
+                                       STEM: fp32 [147][64] + fp32 [64])                         */
+    int64_t res_off;                /* dense [M][Cout] tensor added before ReLU, or -1           */
+    int64_t add1_off, add2_off;     /* dense tensors added AFTER ReLU (smap.py:142-153), or -1   */
+    int64_t aux_off[3];             /* UPADD: aux[0] = low-res t ; HEADSUM: fp32 NHWC head tensors (arena) */
+    int32_t aux_h[3], aux_w[3];     /* their spatial sizes                                       */
+    int64_t ext_off;                /* HEADSUM: byte offset of the [B,Cout,Ho,Wo] block in the fp32 output buffer */
+} smap_op;
+
+/* sizeof(smap_op) as compiled: lets a foreign-language binding verify its struct mirror. */
+int smap_sizeof_op(void);
+
+typedef struct smap_plan smap_plan;
+
+/* Copies `ops`; validates geometry.  n_ops <= 4096. */
+int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan);
+void smap_plan_destroy(smap_plan* plan);
+/* Runs the whole schedule on `stream`.
+ * input : [B,3,H,W] fp32 NCHW images; arena: activation arena; weights: weight blob;
+ * out   : fp32 output buffer (hms [B,43,h,w] | det_d [B,14,h,w] | root_d [B,1,h,w] at the
+ *         offsets recorded in the HEADSUM ops). */
+int smap_plan_run(const smap_plan* plan, const float* input, void* arena, const void* weights,
+                  float* out, void* stream);
+/* Runs ops [first, first+count) only (tests, per-layer profiling). */
+int smap_plan_run_range(const smap_plan* plan, int first, int count, const float* input,
+                        void* arena, const void* weights, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMAP_HIP_H */

@@ -1,0 +1,68 @@
+"""Torch (CPU or GPU, fp32 math) interpreter of the engine's op list (smap_amd.engine.Graph).
+
+TEST INFRASTRUCTURE ONLY.  Two uses:
+  * quantize=False: executes the schedule with the un-rounded folded weights -> checks the
+    WIRING of the schedule (folding, dead-head removal, commuted up_conv, merged heads,
+    skip adds) against the reference's golden outputs, on CPU, without a GPU;
+  * quantize=True: rounds exactly where the HIP engine rounds (fp16 weights, fp16 activation
+    storage after each op, fp32 heads) -> tight per-tensor check of the HIP kernels.
+"""
+import torch
+import torch.nn.functional as F
+
+from smap_amd.engine import OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM
+
+
+def _q(x, on):
+    return x.to(torch.float16).to(torch.float32) if on else x
+
+
+def run_graph(g, imgs, quantize, keep=False):
+    """g: Graph built with keep_ref=True.  Returns (hms, det_d, root_d[, dict name->NCHW tensor])."""
+    dev = imgs.device
+    blob = g.weight_blob()
+    T = {}
+    outs = {}
+    up = lambda x, size: F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+    for op in g.ops:
+        p = op.p
+        if op.kind == OP_STEM:
+            w, b = p["w_ref"].float().to(dev), p["b_ref"].float().to(dev)
+            y = F.relu(F.conv2d(imgs.float(), w, b, stride=2, padding=3))
+            T[op.out.name] = _q(y, quantize)
+        elif op.kind == OP_MAXPOOL:
+            T[op.out.name] = F.max_pool2d(T[op.inp.name], 3, 2, 1)
+        elif op.kind == OP_CONV:
+            cin, cout, k = p["Cin"], p["Cout"], p["ksize"]
+            x = T[op.inp.name][:, p["in_c_off"]:p["in_c_off"] + cin]
+            if quantize:
+                K = k * k * cin
+                wk = blob[p["w_off"]:p["w_off"] + p["cout_pad"] * K * 2].view(torch.float16).view(p["cout_pad"], K)
+                w = wk[:cout].float().view(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()
+                b = blob[p["bias_off"]:p["bias_off"] + p["cout_pad"] * 4].view(torch.float32)[:cout].clone()
+            else:
+                w, b = p["w_ref"].float(), p["b_ref"].float()
+            y = F.conv2d(x, w.to(dev), b.to(dev), stride=p["stride"], padding=p["pad"])
+            if op.res is not None:
+                y = y + T[op.res.name]
+            if p["relu"]:
+                y = F.relu(y)
+            if op.add1 is not None:
+                y = y + T[op.add1.name]
+            if op.add2 is not None:
+                y = y + T[op.add2.name]
+            T[op.out.name] = y if p["out_fp32"] else _q(y, quantize)
+        elif op.kind == OP_UPADD:
+            a, t = T[op.inp.name], T[op.aux[0].name]
+            y = a + up(t, a.shape[-2:])
+            T[op.out.name] = _q(F.relu(y) if p["relu"] else y, quantize)
+        elif op.kind == OP_HEADSUM:
+            size = (g.out_h, g.out_w)
+            y = None
+            for t in op.aux:
+                u = up(T[t.name][:, :p["Cout"]], size)
+                y = u if y is None else y + u
+            outs[p["ext_off"]] = y
+    lay = g.out_layout
+    r = (outs[lay["hms"][0]], outs[lay["det_d"][0]], outs[lay["root_d"][0]])
+    return r + (T,) if keep else r

@@ -1,0 +1,624 @@
+// assoc.hip -- depth-aware part association + 3D lifting for SMAP on gfx950.
+//
+// Hand-written HIP for CDNA4 (wave64).  Compiled with -ffp-contract=off: every
+// float op below rounds exactly once, in the order written, so results are
+// bit-identical to the scalar CPU statement of the same algorithm.
+//
+// Reference semantics (zju3dv/SMAP):
+//   nms_kernel        extensions/gpu/nmsBase.cu:10-175
+//   paf_score_kernel  extensions/gpu/bodyPartConnectorBase.cu:11-63,104-189
+//   group_kernel      extensions/association.cpp:123-233
+//   lift_kernel       exps/stage3_root2/test.py:116-134, test_util.py:45-99, lib/utils/post_3d.py
+//   refine_kernel     exps/stage3_root2/test_util.py:102-131, model/refinenet.py
+//
+// Data layout (all fp32 unless noted, all resident in HBM, batched over frames):
+//   hms    [B,43,H,W]   0..14 keypoint heat-maps, 15+2l / 16+2l PAF x / y of limb l
+//   peaks  [B,15,128,3] slot 0 = (count,0,0); slot r+1 = (x+.5, y+.5, score) of the r-th
+//                        raster-order peak; slots > count are zero
+//   scores [B,14,127,127]
+//   bodys  [B,127,15,4] (x, y, 0, score) heat-map pixels, persons sorted near -> far
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "smap_hip.h"
+
+namespace {
+
+constexpr int NJ = SMAP_NJ, NL = SMAP_NL, MAXP = SMAP_MAXP, PSTRIDE = MAXP + 1;
+
+__constant__ int c_pairs[2 * NL] = {0, 1, 0, 2, 0, 9, 9, 10, 10, 11, 0, 3, 3, 4,
+                                    4, 5, 2, 12, 12, 13, 13, 14, 2, 6, 6, 7, 7, 8};
+__constant__ float c_bone_length[NL] = {
+    26.42178982f, 48.36980909f, 14.88291009f, 31.28002332f, 23.915707f,
+    14.97674918f, 31.28002549f, 23.91570732f, 12.4644364f,  48.26604433f,
+    39.03553194f, 12.4644364f,  48.19076948f, 39.03553252f};
+
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -(1000 + (int)e); }
+
+// ------------------------------------------------------------------ scale --
+__global__ void scale_hms_kernel(float* __restrict__ hms, int HW4, int total4)
+{
+    // one float4 per thread; channel = (i / HW4) % 43 decides the divisor
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+        const int c = (i / HW4) % SMAP_HMS_C;
+        const float d = c < NJ ? 255.f : 127.f;
+        float4 v = reinterpret_cast<float4*>(hms)[i];
+        v.x = v.x / d; v.y = v.y / d; v.z = v.z / d; v.w = v.w / d;
+        reinterpret_cast<float4*>(hms)[i] = v;
+    }
+}
+
+__global__ void scale_hms_kernel_scalar(float* __restrict__ hms, int HW, int total)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = (i / HW) % SMAP_HMS_C;
+        hms[i] = hms[i] / (c < NJ ? 255.f : 127.f);
+    }
+}
+
+// -------------------------------------------------------------------- NMS --
+// One workgroup (NT threads = NT/64 waves) per (frame, keypoint channel).
+// Pass 1: strict 3x3 local-max mask, one wave-ballot per 64 consecutive pixels
+//         (coalesced: thread t of chunk i owns pixel i*NT+t), ballots kept in LDS.
+// Pass 2: wave 0 turns the per-(chunk,wave) popcounts into exclusive raster-order
+//         offsets -- this is the reference's global exclusive scan, restricted to
+//         the channel (scan[p] - scan[channel start]).
+// Pass 3: every peak finds its rank = offset + popcount(lower lanes) and, if
+//         rank < 127, writes the 7x7 score-weighted centroid.
+constexpr int NMS_NT = 1024;
+constexpr int NMS_NW = NMS_NT / 64;
+constexpr int NMS_MAXCHUNK = 32;
+
+__device__ __forceinline__ bool nms_is_peak(const float* __restrict__ s, int p, int H, int W, float thr)
+{
+    const int x = p % W, y = p / W;
+    if (!(0 < x && x < W - 1 && 0 < y && y < H - 1)) return false;
+    const float v = s[p];
+    if (!(v > thr)) return false;
+    return v > s[p - W - 1] && v > s[p - W] && v > s[p - W + 1] && v > s[p - 1] && v > s[p + 1] &&
+           v > s[p + W - 1] && v > s[p + W] && v > s[p + W + 1];
+}
+
+__global__ __launch_bounds__(NMS_NT) void nms_kernel(const float* __restrict__ hms, int C, int H, int W,
+                                                      float thr, float* __restrict__ peaks)
+{
+    __shared__ unsigned long long s_ballot[NMS_MAXCHUNK * NMS_NW];
+    __shared__ int s_off[NMS_MAXCHUNK * NMS_NW + 1];
+    const int c = blockIdx.x % NJ, b = blockIdx.x / NJ;
+    const int HW = H * W;
+    const float* s = hms + ((size_t)b * C + c) * HW;
+    float* out = peaks + ((size_t)b * NJ + c) * PSTRIDE * 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunk = (HW + NMS_NT - 1) / NMS_NT;
+
+    for (int i = 0; i < nchunk; ++i) {
+        const int p = i * NMS_NT + tid;
+        const bool f = p < HW && nms_is_peak(s, p, H, W, thr);
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) s_ballot[i * NMS_NW + wave] = m;
+    }
+    __syncthreads();
+    const int nq = nchunk * NMS_NW;
+    if (wave == 0) {
+        const int per = (nq + 63) / 64;
+        int local = 0;
+        for (int k = 0; k < per; ++k) {
+            const int q = lane * per + k;
+            if (q < nq) local += __popcll(s_ballot[q]);
+        }
+        int incl = local;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        int run = incl - local;
+        for (int k = 0; k < per; ++k) {
+            const int q = lane * per + k;
+            if (q < nq) {
+                s_off[q] = run;
+                run += __popcll(s_ballot[q]);
+            }
+        }
+        if (lane == 63) s_off[nq] = incl;   // total peaks of the channel
+    }
+    __syncthreads();
+    const int total = s_off[nq];
+    const int count = total < MAXP ? total : MAXP;
+    if (tid < PSTRIDE) {
+        if (tid == 0) { out[0] = (float)count; out[1] = 0.f; out[2] = 0.f; }
+        else if (tid > count) { out[3 * tid] = 0.f; out[3 * tid + 1] = 0.f; out[3 * tid + 2] = 0.f; }
+    }
+    for (int i = 0; i < nchunk; ++i) {
+        const unsigned long long m = s_ballot[i * NMS_NW + wave];
+        if (!((m >> lane) & 1ull)) continue;
+        const int rank = s_off[i * NMS_NW + wave] + __popcll(m & ((1ull << lane) - 1ull));
+        if (rank >= MAXP) continue;
+        const int p = i * NMS_NT + tid;
+        const int px = p % W, py = p / W;
+        float xAcc = 0.f, yAcc = 0.f, sAcc = 0.f;
+        for (int dy = -3; dy <= 3; ++dy) {
+            const int y = py + dy;
+            if (0 <= y && y < H) {
+                for (int dx = -3; dx <= 3; ++dx) {
+                    const int x = px + dx;
+                    if (0 <= x && x < W) {
+                        const float sc = s[y * W + x];
+                        if (sc > 0) {
+                            xAcc += (float)x * sc;
+                            yAcc += (float)y * sc;
+                            sAcc += sc;
+                        }
+                    }
+                }
+            }
+        }
+        const int oi = (rank + 1) * 3;
+        out[oi] = xAcc / sAcc + 0.5f;
+        out[oi + 1] = yAcc / sAcc + 0.5f;
+        out[oi + 2] = s[p];
+    }
+}
+
+// -------------------------------------------------------------- PAF score --
+__device__ __forceinline__ int int_round(float a) { return (int)(a + 0.5f); }
+
+__device__ float paf_process(const float* __restrict__ A, const float* __restrict__ Bp,
+                             const float* __restrict__ mapX, const float* __restrict__ mapY,
+                             int W, int H)
+{
+    const float interThreshold = 0.05f, interMinAbove = 0.95f, defaultNms = 0.1f;
+    const float dx = Bp[0] - A[0];
+    const float dy = Bp[1] - A[1];
+    const float dmax = fmaxf(fabsf(dx), fabsf(dy));
+    int n = int_round(sqrtf(5 * dmax));
+    n = n < 25 ? n : 25;
+    n = n > 5 ? n : 5;
+    const float norm = sqrtf(dx * dx + dy * dy);
+    if ((double)norm > 1e-6) {
+        const float sX = A[0], sY = A[1];
+        const float ux = dx / norm, uy = dy / norm;
+        float sum = 0.f;
+        int count = 0;
+        const float lx = dx / (float)n, ly = dy / (float)n;
+        for (int lm = 0; lm < n; ++lm) {
+            int mX = int_round(sX + (float)lm * lx);
+            int mY = int_round(sY + (float)lm * ly);
+            mX = mX < W - 1 ? mX : W - 1;
+            mY = mY < H - 1 ? mY : H - 1;
+            const int idx = mY * W + mX;
+            const float score = ux * mapX[idx] + uy * mapY[idx];
+            if (score > interThreshold) {
+                sum += score;
+                count++;
+            }
+        }
+        if ((float)count / (float)n > interMinAbove) return sum / (float)count;
+        const float l2 = sqrtf(dx * dx + dy * dy);
+        const float th = sqrtf((float)(W * H)) / 150;
+        if (l2 < th) return (float)((double)defaultNms + 1e-6);
+    }
+    return -1.f;
+}
+
+// grid (127 peakA rows, 14 limbs, B frames), 128 threads: lane = peakB.  Rows with
+// no peak A only stream out the -1 fill (coalesced 508 B row).
+__global__ __launch_bounds__(128) void paf_score_kernel(const float* __restrict__ hms,
+                                                        const float* __restrict__ peaks, int H, int W,
+                                                        float* __restrict__ scores)
+{
+    const int pb = threadIdx.x, pa = blockIdx.x, l = blockIdx.y, b = blockIdx.z;
+    if (pb >= MAXP) return;
+    const int HW = H * W;
+    const float* pk = peaks + (size_t)b * NJ * PSTRIDE * 3;
+    const int ja = c_pairs[2 * l], jb = c_pairs[2 * l + 1];
+    const float nA = pk[3 * ja * PSTRIDE], nB = pk[3 * jb * PSTRIDE];
+    float v = -1.f;
+    if ((float)pa < nA && (float)pb < nB) {
+        const float* h = hms + (size_t)b * SMAP_HMS_C * HW;
+        v = paf_process(pk + 3 * (ja * PSTRIDE + pa + 1), pk + 3 * (jb * PSTRIDE + pb + 1),
+                        h + (size_t)(NJ + 2 * l) * HW, h + (size_t)(NJ + 2 * l + 1) * HW, W, H);
+    }
+    scores[(((size_t)b * NL + l) * MAXP + pa) * MAXP + pb] = v;
+}
+
+// ------------------------------------------------------------------ group --
+// One wave64 per frame.  Limbs and persons are inherently sequential (depth-ordered
+// greedy); the <=127 destination candidates of a (limb, person) step are spread two
+// per lane and reduced with 6 xor-shuffles: max score, lowest index on ties == the
+// reference's "first strict maximum" scan order.
+struct GroupLds {
+    float body[MAXP][NJ][4];
+    int remap[NJ][PSTRIDE];
+    float depth[PSTRIDE];
+    float sdepth[PSTRIDE];
+    int sidx[PSTRIDE];
+};
+
+__global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ peaks_all,
+                                                   const float* __restrict__ scores_all,
+                                                   const float* __restrict__ rdepth_all, int H, int W,
+                                                   int root_idx, int dist_flag,
+                                                   float* __restrict__ bodys_all, int* __restrict__ counts)
+{
+    __shared__ GroupLds L;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* peaks = peaks_all + (size_t)b * NJ * PSTRIDE * 3;
+    const float* scores = scores_all + (size_t)b * NL * MAXP * MAXP;
+    const float* rdepth = rdepth_all + (size_t)b * H * W;
+    float* bodys = bodys_all + (size_t)b * MAXP * NJ * 4;
+    const float dsScale = 4;
+
+    const float* rp = peaks + 3 * root_idx * PSTRIDE;
+    const int P = (int)rp[0];
+    if (lane == 0) counts[b] = P;
+    float* lb = &L.body[0][0][0];
+    for (int i = lane; i < MAXP * NJ * 4; i += 64) lb[i] = 0.f;
+    if (P == 0) {
+        for (int i = lane; i < MAXP * NJ * 4; i += 64) bodys[i] = 0.f;
+        return;
+    }
+    for (int i = lane; i < P; i += 64)
+        L.depth[i] = rdepth[(int)rp[3 * (i + 1) + 1] * W + (int)rp[3 * (i + 1)]];
+    __syncthreads();
+    // stable ascending rank sort (ordinal prior: near persons first)
+    for (int i = lane; i < P; i += 64) {
+        const float di = L.depth[i];
+        int r = 0;
+        for (int j = 0; j < P; ++j) {
+            const float dj = L.depth[j];
+            r += (dj < di) || (dj == di && j < i);
+        }
+        L.sidx[r] = i;
+        L.sdepth[r] = di;
+    }
+    __syncthreads();
+    for (int i = lane; i < NJ * PSTRIDE; i += 64) {
+        const int j = i / PSTRIDE, k = i % PSTRIDE;
+        if (k < P) L.remap[j][k] = (j == root_idx) ? L.sidx[k] : k;
+    }
+    for (int i = lane; i < P; i += 64) {
+        const int s = L.sidx[i];
+        L.body[i][root_idx][0] = rp[3 * (s + 1)];
+        L.body[i][root_idx][1] = rp[3 * (s + 1) + 1];
+        L.body[i][root_idx][3] = rp[3 * (s + 1) + 2];
+    }
+    __syncthreads();
+
+    for (int j = 0; j < NL; ++j) {
+        const int i = (j == 0) ? 1 : (j == 1) ? 0 : j;
+        int src, dst;
+        bool flip = false;
+        if (root_idx == 2 && i == 1) { src = c_pairs[2 * i + 1]; dst = c_pairs[2 * i]; flip = true; }
+        else { src = c_pairs[2 * i]; dst = c_pairs[2 * i + 1]; }
+        const float* dp = peaks + 3 * dst * PSTRIDE;
+        const int nDst = (int)dp[0];
+        if (nDst == 0) continue;
+        const float* S = scores + (size_t)i * MAXP * MAXP;
+        // this lane's two candidates
+        const int c0 = lane, c1 = lane + 64;
+        const bool v0 = c0 < nDst, v1 = c1 < nDst;
+        const float d0x = v0 ? dp[3 * (c0 + 1)] : 0.f, d0y = v0 ? dp[3 * (c0 + 1) + 1] : 0.f;
+        const float d1x = v1 ? dp[3 * (c1 + 1)] : 0.f, d1y = v1 ? dp[3 * (c1 + 1) + 1] : 0.f;
+        bool used0 = false, used1 = false;
+        for (int k1 = 0; k1 < P; ++k1) {
+            const float sscore = L.body[k1][src][3];
+            if ((double)sscore < 1e-5) continue;        // wave-uniform
+            const float sx = L.body[k1][src][0], sy = L.body[k1][src][1];
+            const float bone_dist = (float)(1.2 * (double)c_bone_length[i] / (double)L.sdepth[k1]);
+            const int rs = L.remap[src][k1];
+            float best = 0.0f;
+            int bidx = 0x7fffffff;
+            if (v0 && !used0) {
+                float score = flip ? S[c0 * MAXP + rs] : S[rs * MAXP + c0];
+                if (dist_flag && score > 0) {
+                    const float ddx = sx - d0x, ddy = sy - d0y;
+                    const float limb = (float)sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
+                    const float pen = bone_dist / limb / dsScale - 1;
+                    score += pen < 0.0f ? pen : 0.0f;
+                }
+                if (score > best) { best = score; bidx = c0; }
+            }
+            if (v1 && !used1) {
+                float score = flip ? S[c1 * MAXP + rs] : S[rs * MAXP + c1];
+                if (dist_flag && score > 0) {
+                    const float ddx = sx - d1x, ddy = sy - d1y;
+                    const float limb = (float)sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
+                    const float pen = bone_dist / limb / dsScale - 1;
+                    score += pen < 0.0f ? pen : 0.0f;
+                }
+                if (score > best) { best = score; bidx = c1; }   // c1 > c0: strict > keeps the lower index
+            }
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float os = __shfl_xor(best, d);
+                const int oi = __shfl_xor(bidx, d);
+                if (os > best || (os == best && oi < bidx)) { best = os; bidx = oi; }
+            }
+            if (best > 0) {                              // wave-uniform after the butterfly
+                if (lane == 0) {
+                    L.body[k1][dst][0] = dp[3 * (bidx + 1)];
+                    L.body[k1][dst][1] = dp[3 * (bidx + 1) + 1];
+                    L.body[k1][dst][3] = dp[3 * (bidx + 1) + 2];
+                    L.remap[dst][k1] = bidx;
+                }
+                if (bidx == c0) used0 = true;
+                if (bidx == c1) used1 = true;
+            }
+        }
+        __syncthreads();   // lane-0 LDS writes visible before the next limb reads them
+    }
+    for (int i = lane; i < MAXP * NJ * 4; i += 64) bodys[i] = lb[i];
+}
+
+// ------------------------------------------------------------------- lift --
+// One thread per person (<=127 per frame), one workgroup per frame.
+__device__ __forceinline__ double np_lerp(double a, double b, double t)
+{
+    const double d = (double)((float)b - (float)a);
+    return t >= 0.5 ? b - d * (1 - t) : a + d * t;
+}
+
+__global__ __launch_bounds__(128) void lift_kernel(const float* __restrict__ bodys_all,
+                                                   const int* __restrict__ counts,
+                                                   const float* __restrict__ det_d_all,
+                                                   const float* __restrict__ root_d_all,
+                                                   const double* __restrict__ cams, int H, int W,
+                                                   float* __restrict__ pred_2d_all,
+                                                   double* __restrict__ pred_3d_all,
+                                                   double* __restrict__ root_z_all)
+{
+    constexpr int STRIDE = 4, NPTS = 10, root_n = 2;
+    const int b = blockIdx.x, i = threadIdx.x;
+    const int P = counts[b];
+    float* p2 = pred_2d_all + ((size_t)b * MAXP + i) * NJ * 4;
+    double* o = pred_3d_all + ((size_t)b * MAXP + i) * NJ * 4;
+    if (i >= MAXP) return;
+    if (i >= P) {
+        for (int k = 0; k < NJ * 4; ++k) { p2[k] = 0.f; o[k] = 0.0; }
+        root_z_all[(size_t)b * MAXP + i] = 0.0;
+        return;
+    }
+    const float* src = bodys_all + ((size_t)b * MAXP + i) * NJ * 4;
+    const float* det_d = det_d_all + (size_t)b * NL * H * W;
+    const float* root_d = root_d_all + (size_t)b * H * W;
+    const double* cam = cams + (size_t)b * 9;
+    const double scale = cam[0], img_w = cam[1], img_h = cam[2], net_w = cam[3], net_h = cam[4],
+                 fx = cam[5], fy = cam[6], cx = cam[7], cy = cam[8];
+    float bx[NJ], by[NJ], bz[NJ], bs[NJ];
+    for (int j = 0; j < NJ; ++j) {
+        bx[j] = src[4 * j] * (float)STRIDE;
+        by[j] = src[4 * j + 1] * (float)STRIDE;
+        bz[j] = src[4 * j + 2];
+        bs[j] = src[4 * j + 3];
+    }
+    double depth_v[NL];
+    for (int k = 0; k < NL; ++k) depth_v[k] = 0.0;
+    double rz = 0.0;
+    if (bs[root_n] > 0) {
+        const int ry = (int)by[root_n], rx = (int)bx[root_n];
+        rz = (double)root_d[(ry / STRIDE) * W + rx / STRIDE] * scale * fx;
+        for (int k = 0; k < NL; ++k) {
+            const int js = c_pairs[2 * k], jd = c_pairs[2 * k + 1];
+            if (!(bs[jd] > 0 && bs[js] > 0)) continue;
+            float v[NPTS], sv[NPTS];
+            const double dxx = (double)bx[jd] - (double)bx[js], dyy = (double)by[jd] - (double)by[js];
+            const double stepx = dxx / (NPTS - 1), stepy = dyy / (NPTS - 1);
+            for (int t = 0; t < NPTS; ++t) {
+                double px = (double)t * stepx + (double)bx[js];
+                double py = (double)t * stepy + (double)by[js];
+                if (stepx == 0) px = ((double)t / (NPTS - 1)) * dxx + (double)bx[js];
+                if (stepy == 0) py = ((double)t / (NPTS - 1)) * dyy + (double)by[js];
+                if (t == NPTS - 1) { px = bx[jd]; py = by[jd]; }
+                const long ix = (long)rint(px), iy = (long)rint(py);
+                v[t] = det_d[((size_t)k * H + iy / STRIDE) * W + ix / STRIDE];
+            }
+            for (int t = 0; t < NPTS; ++t) {           // insertion sort
+                const float x = v[t];
+                int u = t;
+                while (u > 0 && sv[u - 1] > x) { sv[u] = sv[u - 1]; --u; }
+                sv[u] = x;
+            }
+            const double vlo = 10.0 / 100.0 * (NPTS - 1), vhi = 90.0 / 100.0 * (NPTS - 1);
+            const int ilo = (int)floor(vlo), ihi = (int)floor(vhi);
+            const double mn = np_lerp(sv[ilo], sv[ilo + 1], vlo - ilo);
+            const double mx = np_lerp(sv[ihi], sv[ihi + 1 < NPTS ? ihi + 1 : ihi], vhi - ihi);
+            for (int t = 0; t < NPTS; ++t) {
+                if ((double)v[t] < mn) v[t] = (float)mn;
+                if ((double)v[t] > mx) v[t] = (float)mx;
+            }
+            float r = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            r += v[8];
+            r += v[9];
+            depth_v[k] = (double)(r / (float)NPTS);
+        }
+        bz[2] = 0.f;
+        bz[0] = (float)((double)bz[2] - depth_v[1]);
+        bz[1] = (float)((double)bz[0] + depth_v[0]);
+        for (int k = 2; k < NL; ++k)
+            bz[c_pairs[2 * k + 1]] = (float)((double)bz[c_pairs[2 * k]] + depth_v[k]);
+    }
+    root_z_all[(size_t)b * MAXP + i] = rz;
+    const bool live = bs[root_n] != 0;
+    for (int j = 0; j < NJ; ++j) {
+        p2[4 * j] = bx[j]; p2[4 * j + 1] = by[j]; p2[4 * j + 2] = bz[j]; p2[4 * j + 3] = bs[j];
+        const float x = (float)((double)bx[j] / scale - (net_w / scale - img_w) / 2);
+        const float y = (float)((double)by[j] / scale - (net_h / scale - img_h) / 2);
+        double X = 0.0, Y = 0.0, Z = 0.0, Sc = bs[j];
+        if (live) {
+            const float z = (float)((double)bz[j] + rz);
+            X = ((double)x - cx) * (double)z / fx;
+            Y = ((double)y - cy) * (double)z / fy;
+            Z = z;
+        }
+        if (Sc == 0) { X = Y = Z = 0.0; }
+        o[4 * j] = X; o[4 * j + 1] = Y; o[4 * j + 2] = Z; o[4 * j + 3] = Sc;
+    }
+}
+
+// ----------------------------------------------------------------- refine --
+// One workgroup per (frame, person); the 5 layers run back to back with the
+// activations in LDS and the folded, transposed weights [in][out] streamed from L2
+// (thread o reads Wt[k][o]: coalesced across the wave).
+struct RefineW { const float* wt[5]; const float* bs[5]; };
+
+__global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ pred_2d_all,
+                                                     const double* __restrict__ pred_3d_all,
+                                                     const int* __restrict__ counts, RefineW w,
+                                                     double* __restrict__ refined_all)
+{
+    const int dims[6] = {75, 160, 256, 256, 128, 45};
+    constexpr int root_n = 2;
+    __shared__ float act[2][256];
+    const int b = blockIdx.y, i = blockIdx.x, t = threadIdx.x;
+    double* out = refined_all + ((size_t)b * MAXP + i) * NJ * 4;
+    if (i >= counts[b]) {
+        if (t < NJ * 4) out[t] = 0.0;
+        return;
+    }
+    const float* p2 = pred_2d_all + ((size_t)b * MAXP + i) * NJ * 4;
+    const double* p3 = pred_3d_all + ((size_t)b * MAXP + i) * NJ * 4;
+    if (t < 75) {
+        const int j = t / 5, d = t % 5;
+        double v = 0.0;
+        if (j == root_n) v = d < 2 ? (double)p2[4 * j + d] : p3[4 * j + d - 2];
+        else if (p3[4 * j + 3] > 0)
+            v = d < 2 ? (double)(float)(p2[4 * j + d] - p2[4 * root_n + d]) : p3[4 * j + d - 2] - p3[4 * root_n + d - 2];
+        act[0][t] = (float)v;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int l = 0; l < 5; ++l) {
+        const int nin = dims[l], nout = dims[l + 1];
+        if (t < nout) {
+            float acc = 0.f;
+            for (int k = 0; k < nin; ++k) acc += w.wt[l][(size_t)k * nout + t] * act[cur][k];
+            acc += w.bs[l][t];
+            act[cur ^ 1][t] = (l < 4 && acc < 0.f) ? 0.f : acc;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (t < NJ * 4) {
+        const int j = t / 4, d = t % 4;
+        double v;
+        if (d == 3) v = (p3[4 * root_n + 3] == 0) ? 0.0 : 1.0;
+        else if (j != root_n) v = (double)(float)((double)act[cur][j * 3 + d] + p3[4 * root_n + d]);
+        else v = (double)(float)p3[4 * j + d];
+        out[t] = v;
+    }
+}
+
+// Plain RefineNet forward (refinenet.py:34-37): x [N,75] -> y [N,45], one workgroup per row.
+__global__ __launch_bounds__(256) void refine_mlp_kernel(const float* __restrict__ x, RefineW w,
+                                                         float* __restrict__ y)
+{
+    const int dims[6] = {75, 160, 256, 256, 128, 45};
+    __shared__ float act[2][256];
+    const int i = blockIdx.x, t = threadIdx.x;
+    if (t < 75) act[0][t] = x[(size_t)i * 75 + t];
+    __syncthreads();
+    int cur = 0;
+    for (int l = 0; l < 5; ++l) {
+        const int nin = dims[l], nout = dims[l + 1];
+        if (t < nout) {
+            float acc = 0.f;
+            for (int k = 0; k < nin; ++k) acc += w.wt[l][(size_t)k * nout + t] * act[cur][k];
+            acc += w.bs[l][t];
+            act[cur ^ 1][t] = (l < 4 && acc < 0.f) ? 0.f : acc;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (t < 45) y[(size_t)i * 45 + t] = act[cur][t];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- C ABI ----
+extern "C" {
+
+int smap_scale_hms(float* hms, int B, int H, int W, void* stream)
+{
+    if (!hms || B <= 0 || H <= 0 || W <= 0) return SMAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)B * SMAP_HMS_C * H * W;
+    if ((H * W) % 4 == 0 && ((uintptr_t)hms & 15) == 0) {
+        const int total4 = (int)(total / 4);
+        const int grid = (total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048;
+        hipLaunchKernelGGL(scale_hms_kernel, dim3(grid), dim3(256), 0, st, hms, H * W / 4, total4);
+    } else {
+        const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(scale_hms_kernel_scalar, dim3(grid), dim3(256), 0, st, hms, H * W, (int)total);
+    }
+    return hip_rc(hipGetLastError());
+}
+
+int smap_nms(const float* hms, int B, int C, int H, int W, float threshold, float* peaks, void* stream)
+{
+    if (!hms || !peaks || B <= 0 || C < NJ || H < 3 || W < 3) return SMAP_E_ARG;
+    if ((long long)H * W > (long long)NMS_MAXCHUNK * NMS_NT) return SMAP_E_ARG;
+    hipLaunchKernelGGL(nms_kernel, dim3(B * NJ), dim3(NMS_NT), 0, (hipStream_t)stream, hms, C, H, W,
+                       threshold, peaks);
+    return hip_rc(hipGetLastError());
+}
+
+int smap_paf_score(const float* hms, const float* peaks, int B, int H, int W, float* scores, void* stream)
+{
+    if (!hms || !peaks || !scores || B <= 0 || H <= 0 || W <= 0) return SMAP_E_ARG;
+    hipLaunchKernelGGL(paf_score_kernel, dim3(MAXP, NL, B), dim3(128), 0, (hipStream_t)stream, hms, peaks,
+                       H, W, scores);
+    return hip_rc(hipGetLastError());
+}
+
+int smap_group(const float* peaks, const float* scores, const float* rdepth, int B, int H, int W,
+               int root_idx, int dist_flag, float* bodys, int32_t* counts, void* stream)
+{
+    if (!peaks || !scores || !rdepth || !bodys || !counts || B <= 0 || root_idx < 0 || root_idx >= NJ)
+        return SMAP_E_ARG;
+    hipLaunchKernelGGL(group_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, peaks, scores, rdepth, H, W,
+                       root_idx, dist_flag, bodys, counts);
+    return hip_rc(hipGetLastError());
+}
+
+int smap_lift(const float* bodys, const int32_t* counts, const float* det_d, const float* root_d,
+              const double* cams, int B, int H, int W, float* pred_2d, double* pred_3d, double* root_z,
+              void* stream)
+{
+    if (!bodys || !counts || !det_d || !root_d || !cams || !pred_2d || !pred_3d || !root_z || B <= 0)
+        return SMAP_E_ARG;
+    hipLaunchKernelGGL(lift_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, bodys, counts, det_d, root_d,
+                       cams, H, W, pred_2d, pred_3d, root_z);
+    return hip_rc(hipGetLastError());
+}
+
+int smap_refine(const float* pred_2d, const double* pred_3d, const int32_t* counts, int B,
+                const float* const* wt, const float* const* bs, double* refined, void* stream)
+{
+    if (!pred_2d || !pred_3d || !counts || !wt || !bs || !refined || B <= 0) return SMAP_E_ARG;
+    RefineW w;
+    for (int l = 0; l < 5; ++l) {
+        if (!wt[l] || !bs[l]) return SMAP_E_ARG;
+        w.wt[l] = wt[l];
+        w.bs[l] = bs[l];
+    }
+    hipLaunchKernelGGL(refine_kernel, dim3(MAXP, B), dim3(256), 0, (hipStream_t)stream, pred_2d, pred_3d,
+                       counts, w, refined);
+    return hip_rc(hipGetLastError());
+}
+
+}  // extern "C"
+
+extern "C" int smap_refine_mlp(const float* x, int N, const float* const* wt, const float* const* bs, float* y,
+                               void* stream)
+{
+    if (!x || !y || !wt || !bs || N < 0) return SMAP_E_ARG;
+    if (N == 0) return 0;
+    RefineW w;
+    for (int l = 0; l < 5; ++l) {
+        if (!wt[l] || !bs[l]) return SMAP_E_ARG;
+        w.wt[l] = wt[l];
+        w.bs[l] = bs[l];
+    }
+    hipLaunchKernelGGL(refine_mlp_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, w, y);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" const char* smap_version(void) { return "smap_hip gfx950 r1 (assoc+backbone)"; }

@@ -1,0 +1,255 @@
+// conv.hip -- conv_bn_relu (model/smap.py:13-45) as an implicit GEMM on the gfx950
+// matrix cores, with folded BN, and bias + residual + ReLU + skip adds fused into
+// the epilogue.  Hand-written for CDNA4: wave64, v_mfma_f32_32x32x16_f16,
+// global_load_lds (LDS-DMA) staging with a source-side XOR swizzle, XCD-aware
+// block order.
+//
+// GEMM view     D[m][n] = sum_k A[m][k] * Wt[n][k]
+//   m = (b, oy, ox) output pixel, M = B*Ho*Wo          (NHWC fp16 activations)
+//   n = output channel, N = cout_pad                   (weights [cout_pad][KH][KW][Cin] fp16)
+//   k = (kh, kw, cin), K = KH*KW*Cin, walked in BK=64 chunks; a chunk never straddles a
+//       (kh,kw) position because Cin % 64 == 0, so the A rows of a chunk are 128
+//       contiguous bytes of one input pixel -- or 16 bytes of zeros from a zero page
+//       when the tap falls into the padding / past M.
+//
+// LDS image of a staged tile: [rows][64 halves] = 128-B rows, written by LDS-DMA
+// (lane-linear: wave w, round i covers rows i*32+w*8 .. +8, lane l -> row l/8, 16-B
+// slot l%8).  Slot s of row r holds K-granule s ^ ((r>>1)&7): the permutation is
+// applied to the per-lane GLOBAL address (the DMA cannot scatter) and again on the
+// ds_read_b128 side, which makes the 16-lane groups of ds_read_b128 conflict free.
+//
+// Epilogue: accumulators (+bias) go to LDS as an fp32 [BM][BN] tile, then every
+// thread owns 8 consecutive channels of one pixel: residual (16-B load) -> ReLU ->
+// post-ReLU skip adds -> one 16-B fp16 store (or two 16-B fp32 stores), i.e. full
+// coalesced NHWC lines.  One rounding to fp16 per output value.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "smap_hip.h"
+#include "plan.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+constexpr int BK = 64;            // halves per K chunk
+constexpr int ROWB = BK * 2;      // bytes per LDS row
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
+{
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+    static_assert(MI >= 1 && NI >= 1, "tile too small for the wave grid");
+    constexpr int STAGE = (BM + BN) * ROWB;
+    static_assert(2 * STAGE >= BM * BN * 4, "epilogue tile must fit in the staging LDS");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- XCD-aware block order: blocks b, b+8, b+16.. run on one XCD; give each XCD a
+    //      contiguous range of logical tiles so that the N-tiles of one M-tile (which
+    //      re-read the same activation rows) share an L2.
+    int logical;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int m_tile = logical / a.n_tiles, n_tile = logical - m_tile * a.n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    // ---- per-thread staging geometry
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int gch = lslot ^ (((wave & 1) << 2) | (lrow >> 1));   // K-granule this lane fetches
+    const _Float16* __restrict__ in = a.in;
+    const _Float16* __restrict__ wt = a.w;
+    const int HoWo = a.Ho * a.Wo;
+
+    long long a_base[BM / 32];
+    int a_iy0[BM / 32], a_ix0[BM / 32];
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+        const int m = m0 + i * 32 + wave * 8 + lrow;
+        if (m < a.M) {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            a_iy0[i] = oy * a.stride - a.pad;
+            a_ix0[i] = ox * a.stride - a.pad;
+            a_base[i] = ((long long)(b * a.H + a_iy0[i]) * a.W + a_ix0[i]) * a.in_stride_c + a.in_c_off + gch * 8;
+        } else {
+            a_iy0[i] = -(1 << 20);
+            a_ix0[i] = -(1 << 20);
+            a_base[i] = 0;
+        }
+    }
+    long long w_base[BN / 32];
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i)
+        w_base[i] = (long long)(n0 + i * 32 + wave * 8 + lrow) * a.K + gch * 8;
+
+    const int cchunks = a.Cin / BK;
+    const int n_iter = a.ksize * a.ksize * cchunks;
+
+    auto stage = [&](int it, int buf) {
+        const int kpos = it / cchunks, c0 = (it - kpos * cchunks) * BK;
+        const int kh = kpos / a.ksize, kw = kpos - kh * a.ksize;
+        const long long koff = (long long)(kh * a.W + kw) * a.in_stride_c + c0;
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) {
+            const bool ok = (unsigned)(a_iy0[i] + kh) < (unsigned)a.H && (unsigned)(a_ix0[i] + kw) < (unsigned)a.W;
+            const _Float16* src = ok ? in + a_base[i] + koff : a.zero;
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sA + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const _Float16* src = wt + w_base[i] + (long long)it * BK;
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sB + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int rswz = (l31 >> 1) & 7;
+    const int a_row0 = wm * (BM / WM) + l31;     // + mi*32
+    const int b_row0 = wn * (BN / WN) + l31;     // + ni*32
+
+    stage(0, 0);
+    for (int it = 0; it < n_iter; ++it) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's LDS-DMA has landed
+        __syncthreads();
+        if (it + 1 < n_iter) stage(it + 1, buf ^ 1);
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + BM * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int slot = ((kk * 2 + lhi) ^ rswz) * 16;
+            half8 af[MI], bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                af[mi] = *reinterpret_cast<const half8*>(sA + (a_row0 + mi * 32) * ROWB + slot);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                bf[ni] = *reinterpret_cast<const half8*>(sB + (b_row0 + ni * 32) * ROWB + slot);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    __syncthreads();   // everyone is done reading the staging buffers
+
+    // ---- epilogue 1: acc + bias -> fp32 [BM][BN] tile in LDS
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = wn * (BN / WN) + ni * 32 + l31;
+        const float bias = a.bias[n0 + col];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (BM / WM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                Cs[row * BN + col] = acc[mi][ni][r] + bias;
+            }
+    }
+    __syncthreads();
+
+    // ---- epilogue 2: 8 consecutive channels of one pixel per thread
+    constexpr int CG = BN / 8;                    // channel groups per row
+    constexpr int PASSES = BM * CG / 256;
+    static_assert(BM * CG % 256 == 0, "tile/thread mismatch");
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int idx = p * 256 + tid;
+        const int row = idx / CG, cg = idx - row * CG;
+        const int m = m0 + row, n = n0 + cg * 8;
+        if (m >= a.M || n >= a.Cout8) continue;
+        float v[8];
+        {
+            const float4 lo = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+            v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        }
+        const long long dense = (long long)m * a.Cout8 + n;      // res/add tensors are dense [M][Cout8]
+        if (a.res) {
+            const half8 r = *reinterpret_cast<const half8*>(a.res + dense);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (a.add1) {
+            const half8 r = *reinterpret_cast<const half8*>(a.add1 + dense);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+        }
+        if (a.add2) {
+            const half8 r = *reinterpret_cast<const half8*>(a.add2 + dense);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+        }
+        const long long o = (long long)m * a.out_stride_c + a.out_c_off + n;
+        if (a.out_fp32) {
+            float* op = reinterpret_cast<float*>(a.out) + o;
+            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
+            *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + o) = h;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+hipError_t launch(const ConvArgs& a, hipStream_t st)
+{
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// tile selector -> (BM, BN).  Keep in sync with smap_amd/plan.py::TILES.
+int smap_conv_tile_dims(int tile, int* bm, int* bn)
+{
+    switch (tile) {
+        case 0: *bm = 128; *bn = 128; return 0;
+        case 1: *bm = 128; *bn = 64; return 0;
+        case 2: *bm = 64; *bn = 64; return 0;
+        case 3: *bm = 128; *bn = 32; return 0;
+        case 4: *bm = 64; *bn = 128; return 0;
+        default: return -1;
+    }
+}
+
+hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
+{
+    switch (tile) {
+        case 0: return launch<128, 128, 2, 2>(a, st);
+        case 1: return launch<128, 64, 2, 2>(a, st);
+        case 2: return launch<64, 64, 2, 2>(a, st);
+        case 3: return launch<128, 32, 4, 1>(a, st);
+        case 4: return launch<64, 128, 2, 2>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}

@@ -1,0 +1,384 @@
+// plan.hip -- static inference schedule executor for SMAP.forward (model/smap.py:403-419)
+// plus the non-GEMM kernels of the backbone:
+//   stem_kernel     ResNet_top conv 7x7 s2 p3 + folded BN + ReLU   (smap.py:83-84, 88-90)
+//   maxpool_kernel  MaxPool2d(3, 2, 1)                              (smap.py:86)
+//   upadd_kernel    relu(a + bilinear_align_corners(t))             (smap.py:213-217)
+//   headsum_kernel  res4 + up(res3) + up(res2) -> fp32 NCHW         (smap.py:221-229, 417-419)
+// The schedule itself (which op, which buffers) is built by the Python host
+// (smap_amd/plan.py) and handed over as a flat array of smap_op; this file only
+// launches it, op after op, on one HIP stream -- capturable into a hipGraph.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <new>
+#include <vector>
+#include "smap_hip.h"
+#include "plan.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -(1000 + (int)e); }
+
+// ------------------------------------------------------------------ stem --
+// fp32 NCHW image -> NHWC fp16 [B,Ho,Wo,64].  One 16x16 output tile per workgroup,
+// one output pixel (all 64 channels, fp32 accumulators) per thread.  The 37x37x3
+// input patch and the folded [147][64] fp32 weights live in LDS; weight reads are
+// wave-wide broadcasts.
+constexpr int ST_T = 16, ST_P = ST_T * 2 + 5;   // output tile edge, input patch edge
+
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ wf,
+                                                   const float* __restrict__ bias, _Float16* __restrict__ out,
+                                                   int H, int W, int Ho, int Wo)
+{
+    __shared__ float s_w[147 * 64];
+    __shared__ float s_p[3 * ST_P * ST_P];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, oy0 = blockIdx.y * ST_T, ox0 = blockIdx.x * ST_T;
+    for (int i = tid; i < 147 * 64; i += 256) s_w[i] = wf[i];
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    for (int i = tid; i < 3 * ST_P * ST_P; i += 256) {
+        const int c = i / (ST_P * ST_P), r = i - c * ST_P * ST_P;
+        const int py = r / ST_P, px = r - py * ST_P;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            v = img[(((size_t)b * 3 + c) * H + iy) * W + ix];
+        s_p[i] = v;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    float acc[64];
+#pragma unroll
+    for (int co = 0; co < 64; ++co) acc[co] = 0.f;
+    for (int c = 0; c < 3; ++c)
+        for (int kh = 0; kh < 7; ++kh) {
+            const float* prow = s_p + (c * ST_P + ty * 2 + kh) * ST_P + tx * 2;
+            const float* wrow = s_w + ((c * 7 + kh) * 7) * 64;
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const float av = prow[kw];
+                const float4* w4 = reinterpret_cast<const float4*>(wrow + kw * 64);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float4 wv = w4[q];
+                    acc[4 * q] += av * wv.x;
+                    acc[4 * q + 1] += av * wv.y;
+                    acc[4 * q + 2] += av * wv.z;
+                    acc[4 * q + 3] += av * wv.w;
+                }
+            }
+        }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < Ho && ox < Wo) {
+        _Float16* op = out + (((size_t)b * Ho + oy) * Wo + ox) * 64;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = acc[g * 8 + e] + bias[g * 8 + e];
+                h[e] = (_Float16)(v > 0.f ? v : 0.f);
+            }
+            *reinterpret_cast<half8*>(op + g * 8) = h;
+        }
+    }
+}
+
+// --------------------------------------------------------------- maxpool --
+// NHWC fp16, 3x3 stride 2 pad 1 (padding never wins: only in-range taps are read).
+__global__ void maxpool_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, int B, int H, int W,
+                               int C, int Ho, int Wo)
+{
+    const int cg_n = C / 8;
+    const long long total = (long long)B * Ho * Wo * cg_n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % cg_n);
+        long long pix = idx / cg_n;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho), b = (int)(pix / Ho);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const half8 v = *reinterpret_cast<const half8*>(in + (((size_t)b * H + iy) * W + ix) * C + cg * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+            }
+        }
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (_Float16)m[e];
+        *reinterpret_cast<half8*>(out + (((size_t)b * Ho + oy) * Wo + ox) * C + cg * 8) = h;
+    }
+}
+
+// ------------------------------------------------- bilinear align-corners --
+// ATen's index/weight rule for align_corners=True (UpSample.h compute_source_index_and_lambda):
+// identity when sizes match; else src = dst*(in-1)/(out-1) in fp32, i0 = (int)src,
+// i1 = i0 + (i0 < in-1), l1 = clamp(src - i0, 0, 1), l0 = 1 - l1.
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_index(int dst, int in_size, int out_size)
+{
+    Lerp r;
+    if (in_size == out_size) { r.i0 = dst; r.i1 = dst; r.l0 = 1.f; r.l1 = 0.f; return r; }
+    const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+    const float src = scale * (float)dst;
+    r.i0 = (int)src;
+    r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+    float l1 = src - (float)r.i0;
+    l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+    r.l1 = l1;
+    r.l0 = 1.f - l1;
+    return r;
+}
+
+// out = relu(a + up(t)); a/out [B,Ho,Wo,C] fp16, t [B,h,w,C] fp16; 8 channels per thread.
+__global__ void upadd_kernel(const _Float16* __restrict__ a, const _Float16* __restrict__ t,
+                             _Float16* __restrict__ out, int B, int Ho, int Wo, int C, int h, int w, int relu)
+{
+    const int cg_n = C / 8;
+    const long long total = (long long)B * Ho * Wo * cg_n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % cg_n);
+        long long pix = idx / cg_n;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho), b = (int)(pix / Ho);
+        const Lerp ly = lerp_index(oy, h, Ho), lx = lerp_index(ox, w, Wo);
+        const _Float16* tb = t + (size_t)b * h * w * C + cg * 8;
+        const half8 v00 = *reinterpret_cast<const half8*>(tb + ((size_t)ly.i0 * w + lx.i0) * C);
+        const half8 v01 = *reinterpret_cast<const half8*>(tb + ((size_t)ly.i0 * w + lx.i1) * C);
+        const half8 v10 = *reinterpret_cast<const half8*>(tb + ((size_t)ly.i1 * w + lx.i0) * C);
+        const half8 v11 = *reinterpret_cast<const half8*>(tb + ((size_t)ly.i1 * w + lx.i1) * C);
+        const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * C + cg * 8;
+        const half8 av = *reinterpret_cast<const half8*>(a + o);
+        half8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float up = ly.l0 * (lx.l0 * (float)v00[e] + lx.l1 * (float)v01[e]) +
+                             ly.l1 * (lx.l0 * (float)v10[e] + lx.l1 * (float)v11[e]);
+            float v = (float)av[e] + up;
+            if (relu) v = v > 0.f ? v : 0.f;
+            r[e] = (_Float16)v;
+        }
+        *reinterpret_cast<half8*>(out + o) = r;
+    }
+}
+
+// fp32 NHWC heads (channel stride Cs) -> fp32 NCHW [B,C,Ho,Wo] = ((s0 + up(s1)) + up(s2)).
+// One 32-pixel row segment per workgroup; LDS transposes pixel-major -> channel-major so
+// that both the NHWC reads and the NCHW writes are coalesced.
+struct HeadSrc { const float* p[3]; int h[3], w[3]; int n; };
+constexpr int HS_PX = 32;
+
+__global__ __launch_bounds__(256) void headsum_kernel(HeadSrc s, float* __restrict__ out, int Ho, int Wo, int C,
+                                                      int Cs)
+{
+    __shared__ float tile[48 * (HS_PX + 1)];
+    const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * HS_PX, tid = threadIdx.x;
+    Lerp ly[3];
+    for (int k = 0; k < s.n; ++k) ly[k] = lerp_index(y, s.h[k], Ho);
+    for (int idx = tid; idx < HS_PX * Cs; idx += 256) {
+        const int px = idx / Cs, c = idx - px * Cs;
+        const int x = x0 + px;
+        if (x >= Wo || c >= C) continue;
+        float v = 0.f;
+        for (int k = 0; k < s.n; ++k) {
+            const Lerp lx = lerp_index(x, s.w[k], Wo);
+            const float* base = s.p[k] + (size_t)b * s.h[k] * s.w[k] * Cs + c;
+            const float v00 = base[((size_t)ly[k].i0 * s.w[k] + lx.i0) * Cs];
+            const float v01 = base[((size_t)ly[k].i0 * s.w[k] + lx.i1) * Cs];
+            const float v10 = base[((size_t)ly[k].i1 * s.w[k] + lx.i0) * Cs];
+            const float v11 = base[((size_t)ly[k].i1 * s.w[k] + lx.i1) * Cs];
+            const float up = ly[k].l0 * (lx.l0 * v00 + lx.l1 * v01) + ly[k].l1 * (lx.l0 * v10 + lx.l1 * v11);
+            v = (k == 0) ? up : v + up;
+        }
+        tile[c * (HS_PX + 1) + px] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < C * HS_PX; idx += 256) {
+        const int c = idx / HS_PX, px = idx - c * HS_PX;
+        const int x = x0 + px;
+        if (x < Wo) out[(((size_t)b * C + c) * Ho + y) * Wo + x] = tile[c * (HS_PX + 1) + px];
+    }
+}
+
+inline int grid_for(long long total, int block)
+{
+    long long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+struct smap_plan {
+    std::vector<smap_op> ops;
+    _Float16* zero = nullptr;   // 256 zero bytes for padded conv taps
+};
+
+static int validate(const smap_op& o)
+{
+    if (o.B <= 0 || o.H <= 0 || o.W <= 0 || o.Ho <= 0 || o.Wo <= 0 || o.Cout <= 0) return SMAP_E_ARG;
+    switch (o.kind) {
+        case SMAP_OP_CONV: {
+            int bm, bn;
+            if (smap_conv_tile_dims(o.tile, &bm, &bn)) return SMAP_E_ARG;
+            if (o.Cin % 64 || o.cout_pad % bn || o.cout_pad < o.Cout) return SMAP_E_ARG;
+            if (o.ksize != 1 && o.ksize != 3) return SMAP_E_ARG;
+            if (o.in_stride_c % 8 || o.in_c_off % 8 || o.out_stride_c % 8 || o.out_c_off % 8) return SMAP_E_ARG;
+            if (o.out_stride_c < ((o.Cout + 7) & ~7)) return SMAP_E_ARG;
+            if ((o.res_off >= 0 || o.add1_off >= 0 || o.add2_off >= 0) && o.Cout % 8) return SMAP_E_ARG;
+            if (o.in_off < 0 || o.out_off < 0 || o.w_off < 0 || o.bias_off < 0) return SMAP_E_ARG;
+            if (o.Ho != (o.H + 2 * o.pad - o.ksize) / o.stride + 1) return SMAP_E_ARG;
+            if (o.Wo != (o.W + 2 * o.pad - o.ksize) / o.stride + 1) return SMAP_E_ARG;
+            return 0;
+        }
+        case SMAP_OP_STEM:
+            if (o.Cin != 3 || o.Cout != 64 || o.Ho != (o.H + 6 - 7) / 2 + 1 || o.Wo != (o.W + 6 - 7) / 2 + 1)
+                return SMAP_E_ARG;
+            return 0;
+        case SMAP_OP_MAXPOOL:
+            if (o.Cin % 8 || o.Cin != o.Cout || o.Ho != (o.H + 2 - 3) / 2 + 1 || o.Wo != (o.W + 2 - 3) / 2 + 1)
+                return SMAP_E_ARG;
+            return 0;
+        case SMAP_OP_UPADD:
+            if (o.Cout % 8 || o.aux_off[0] < 0 || o.aux_h[0] <= 0 || o.aux_w[0] <= 0) return SMAP_E_ARG;
+            return 0;
+        case SMAP_OP_HEADSUM:
+            if (o.n_aux < 1 || o.n_aux > 3 || o.Cout > 48 || o.Cin < o.Cout || o.ext_off < 0) return SMAP_E_ARG;
+            return 0;
+        default:
+            return SMAP_E_ARG;
+    }
+}
+
+extern "C" {
+
+int smap_sizeof_op(void) { return (int)sizeof(smap_op); }
+
+int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan)
+{
+    if (!ops || !plan || n_ops <= 0 || n_ops > 4096) return SMAP_E_ARG;
+    for (int i = 0; i < n_ops; ++i)
+        if (int rc = validate(ops[i])) return rc;
+    smap_plan* p = new (std::nothrow) smap_plan();
+    if (!p) return SMAP_E_ARG;
+    p->ops.assign(ops, ops + n_ops);
+    void* z = nullptr;
+    hipError_t e = hipMalloc(&z, 256);
+    if (e == hipSuccess) e = hipMemset(z, 0, 256);
+    if (e != hipSuccess) { delete p; return hip_rc(e); }
+    p->zero = static_cast<_Float16*>(z);
+    *plan = p;
+    return 0;
+}
+
+void smap_plan_destroy(smap_plan* plan)
+{
+    if (!plan) return;
+    if (plan->zero) (void)hipFree(plan->zero);
+    delete plan;
+}
+
+int smap_plan_run_range(const smap_plan* plan, int first, int count, const float* input, void* arena,
+                        const void* weights, float* out, void* stream)
+{
+    if (!plan || !arena || !weights || first < 0 || count < 0 || first + count > (int)plan->ops.size())
+        return SMAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    char* ar = static_cast<char*>(arena);
+    const char* wb = static_cast<const char*>(weights);
+    auto A = [&](int64_t off) -> _Float16* { return off < 0 ? nullptr : reinterpret_cast<_Float16*>(ar + off); };
+    for (int i = first; i < first + count; ++i) {
+        const smap_op& o = plan->ops[i];
+        hipError_t e = hipSuccess;
+        switch (o.kind) {
+            case SMAP_OP_CONV: {
+                ConvArgs a;
+                a.in = A(o.in_off);
+                a.w = reinterpret_cast<const _Float16*>(wb + o.w_off);
+                a.bias = reinterpret_cast<const float*>(wb + o.bias_off);
+                a.out = ar + o.out_off;
+                a.res = A(o.res_off);
+                a.add1 = A(o.add1_off);
+                a.add2 = A(o.add2_off);
+                a.zero = plan->zero;
+                a.H = o.H; a.W = o.W; a.Cin = o.Cin; a.in_stride_c = o.in_stride_c; a.in_c_off = o.in_c_off;
+                a.Ho = o.Ho; a.Wo = o.Wo; a.Cout8 = (o.Cout + 7) & ~7;
+                a.ksize = o.ksize; a.stride = o.stride; a.pad = o.pad; a.relu = o.relu;
+                a.out_stride_c = o.out_stride_c; a.out_c_off = o.out_c_off; a.out_fp32 = o.out_fp32;
+                a.M = o.B * o.Ho * o.Wo;
+                a.K = o.ksize * o.ksize * o.Cin;
+                int bm, bn;
+                smap_conv_tile_dims(o.tile, &bm, &bn);
+                a.m_tiles = (a.M + bm - 1) / bm;
+                a.n_tiles = o.cout_pad / bn;
+                e = smap_launch_conv(a, o.tile, st);
+                break;
+            }
+            case SMAP_OP_STEM: {
+                if (!input) return SMAP_E_ARG;
+                dim3 grid((o.Wo + ST_T - 1) / ST_T, (o.Ho + ST_T - 1) / ST_T, o.B);
+                hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, st, input,
+                                   reinterpret_cast<const float*>(wb + o.w_off),
+                                   reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, o.Ho,
+                                   o.Wo);
+                e = hipGetLastError();
+                break;
+            }
+            case SMAP_OP_MAXPOOL: {
+                const long long total = (long long)o.B * o.Ho * o.Wo * (o.Cin / 8);
+                hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, A(o.in_off),
+                                   A(o.out_off), o.B, o.H, o.W, o.Cin, o.Ho, o.Wo);
+                e = hipGetLastError();
+                break;
+            }
+            case SMAP_OP_UPADD: {
+                const long long total = (long long)o.B * o.Ho * o.Wo * (o.Cout / 8);
+                hipLaunchKernelGGL(upadd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, A(o.in_off),
+                                   A(o.aux_off[0]), A(o.out_off), o.B, o.Ho, o.Wo, o.Cout, o.aux_h[0], o.aux_w[0],
+                                   o.relu);
+                e = hipGetLastError();
+                break;
+            }
+            case SMAP_OP_HEADSUM: {
+                if (!out) return SMAP_E_ARG;
+                HeadSrc s;
+                s.n = o.n_aux;
+                for (int k = 0; k < 3; ++k) {
+                    s.p[k] = k < o.n_aux ? reinterpret_cast<const float*>(ar + o.aux_off[k]) : nullptr;
+                    s.h[k] = o.aux_h[k];
+                    s.w[k] = o.aux_w[k];
+                }
+                dim3 grid((o.Wo + HS_PX - 1) / HS_PX, o.Ho, o.B);
+                hipLaunchKernelGGL(headsum_kernel, grid, dim3(256), 0, st, s,
+                                   reinterpret_cast<float*>(reinterpret_cast<char*>(out) + o.ext_off), o.Ho, o.Wo,
+                                   o.Cout, o.Cin);
+                e = hipGetLastError();
+                break;
+            }
+            default:
+                return SMAP_E_ARG;
+        }
+        if (e != hipSuccess) return hip_rc(e);
+    }
+    return 0;
+}
+
+int smap_plan_run(const smap_plan* plan, const float* input, void* arena, const void* weights, float* out,
+                  void* stream)
+{
+    if (!plan) return SMAP_E_ARG;
+    return smap_plan_run_range(plan, 0, (int)plan->ops.size(), input, arena, weights, out, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,402 @@
+"""Host side of the SMAP backbone on MI355X: folds the checkpoint, lays the static
+inference schedule out as an array of `smap_op` (include/smap_hip.h) and runs it
+through libsmap_hip.so.  Python only DESCRIBES the schedule; every kernel launch
+happens inside smap_plan_run (csrc/plan.hip).
+
+Reference being replaced: model/smap.py SMAP.forward, inference branch (:403-419).
+
+What the schedule does differently from a layer-by-layer replay (all exact up to
+floating-point rounding):
+  * eval-mode BatchNorm is folded into the conv weights / bias (smap.py:13-45);
+  * heads that the inference branch never returns are not computed (smap.py:417-419 uses
+    only stage-2 res2..4, res_d4, res_rd4): 62 of the 268 convs;
+  * `up_conv(bilinear_up(x))` (smap.py:214-215) is evaluated as `bilinear_up(up_conv(x))`:
+    a 1x1 conv + per-channel affine commutes with the (convex, per-channel) bilinear
+    resampling, which moves the 256->256 GEMM to the 4x smaller grid;
+  * the three 1x1 head convs of stage-2/up4 share their input and run as one N=768 GEMM;
+  * residual add, ReLU and the inter-stage skip adds (smap.py:142-153) run in the
+    epilogue of the producing conv.
+Activations are NHWC fp16, accumulation fp32, head outputs fp32.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import torch
+
+from . import lib as _L
+
+OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM = range(5)
+TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128)}
+LAYERS = (3, 4, 6, 3)            # smap.py:299  resnet-50
+PLANES = (64, 128, 256, 512)
+ALIGN = 256
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------- folding
+def fold_conv_bn(sd, prefix, eps=1e-5):
+    """conv_bn_relu (smap.py:13-45) in eval mode -> (w [Cout,Cin,kh,kw] f64, b [Cout] f64)."""
+    w = sd[prefix + ".conv.weight"].double()
+    b = sd[prefix + ".conv.bias"].double()
+    g = sd[prefix + ".bn.weight"].double()
+    beta = sd[prefix + ".bn.bias"].double()
+    mu = sd[prefix + ".bn.running_mean"].double()
+    var = sd[prefix + ".bn.running_var"].double()
+    s = g / torch.sqrt(var + eps)
+    return w * s[:, None, None, None], (b - mu) * s + beta
+
+
+# ----------------------------------------------------------------------------- graph IR
+@dataclass
+class Tensor:
+    name: str
+    B: int
+    H: int
+    W: int
+    C: int                 # channel stride of a pixel
+    esize: int = 2         # bytes per element (2 = fp16, 4 = fp32)
+    first: int = -1
+    last: int = -1
+    off: int = -1
+
+    @property
+    def nbytes(self):
+        return self.B * self.H * self.W * self.C * self.esize
+
+
+@dataclass
+class Op:
+    kind: int
+    out: Tensor = None
+    inp: Tensor = None
+    res: Tensor = None
+    add1: Tensor = None
+    add2: Tensor = None
+    aux: list = field(default_factory=list)
+    p: dict = field(default_factory=dict)
+
+
+def pick_tile(M, cout):
+    """Largest tile that still gives >= 2 waves of workgroups on 256 CUs."""
+    if cout <= 32:
+        return 3
+    cands = [1, 2] if cout <= 64 else [0, 1, 2]
+    best, best_blocks = None, -1
+    for t in cands:
+        bm, bn = TILES[t]
+        blocks = -(-M // bm) * (-(-cout // bn))
+        if blocks >= 512:
+            return t
+        if blocks > best_blocks:
+            best, best_blocks = t, blocks
+    return best
+
+
+class Graph:
+    def __init__(self, sd, B, H, W, stage_num=3, chl=256, kpt_paf=43, paf=14, keep_ref=False):
+        self.keep_ref = keep_ref
+        assert H % 32 == 0 and W % 32 == 0, "input must be a multiple of 32 (5 stride-2 levels)"
+        self.sd, self.B, self.H, self.W = sd, B, H, W
+        self.ops, self.tensors = [], []
+        self.wchunks, self.woff = [], 0
+        self.stage_num, self.chl, self.kpt_paf, self.paf = stage_num, chl, kpt_paf, paf
+        self.flops = 0
+        self._build()
+
+    # -- helpers
+    def tensor(self, name, H, W, C, esize=2):
+        t = Tensor(name, self.B, H, W, C, esize)
+        self.tensors.append(t)
+        return t
+
+    def _add_w(self, t):
+        t = t.contiguous()
+        raw = t.view(torch.uint8).reshape(-1) if t.dtype != torch.uint8 else t.reshape(-1)
+        off = self.woff
+        self.wchunks.append((off, raw))
+        self.woff = _rup(off + raw.numel(), ALIGN)
+        return off
+
+    def conv(self, name, prefixes, x, ksize=1, stride=1, relu=True, res=None, add1=None, add2=None,
+             in_c_off=0, cin=None, out_fp32=False):
+        """One conv launch; `prefixes` (list) are concatenated along Cout (shared input)."""
+        ws, bs = zip(*[fold_conv_bn(self.sd, p) for p in prefixes])
+        w, b = torch.cat(ws, 0), torch.cat(bs, 0)
+        cout, cin_w = w.shape[0], w.shape[1]
+        cin = cin or x.C
+        assert cin_w == cin and w.shape[2] == ksize, (name, w.shape, cin, ksize)
+        pad = ksize // 2
+        Ho = (x.H + 2 * pad - ksize) // stride + 1
+        Wo = (x.W + 2 * pad - ksize) // stride + 1
+        M = self.B * Ho * Wo
+        tile = pick_tile(M, cout)
+        bn = TILES[tile][1]
+        cout_pad = _rup(cout, bn)
+        K = ksize * ksize * cin
+        wk = torch.zeros((cout_pad, K), dtype=torch.float16)
+        wk[:cout] = w.permute(0, 2, 3, 1).reshape(cout, K).to(torch.float16)
+        bk = torch.zeros((cout_pad,), dtype=torch.float32)
+        bk[:cout] = b.to(torch.float32)
+        out = self.tensor(name, Ho, Wo, _rup(cout, 8), 4 if out_fp32 else 2)
+        self.flops += 2 * M * cout * K
+        self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, p=dict(
+            Cin=cin, in_c_off=in_c_off, Cout=cout, ksize=ksize, stride=stride, pad=pad, relu=int(relu),
+            cout_pad=cout_pad, tile=tile, out_fp32=int(out_fp32), w_off=self._add_w(wk), bias_off=self._add_w(bk),
+            w_ref=w if self.keep_ref else None, b_ref=b if self.keep_ref else None)))
+        return out
+
+    # -- the network (smap.py:313-353 structure, :403-419 data flow)
+    def _build(self):
+        B, H, W, sd = self.B, self.H, self.W, self.sd
+        # ResNet_top (smap.py:80-92)
+        w, b = fold_conv_bn(sd, "top.conv")
+        wk = w.permute(1, 2, 3, 0).reshape(147, 64).to(torch.float32)
+        H2, W2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        t = self.tensor("top.conv", H2, W2, 64)
+        self.flops += 2 * B * H2 * W2 * 64 * 147
+        self.ops.append(Op(OP_STEM, out=t, p=dict(w_off=self._add_w(wk), bias_off=self._add_w(b.to(torch.float32)),
+                                                  w_ref=w, b_ref=b)))
+        H4, W4 = (H2 + 2 - 3) // 2 + 1, (W2 + 2 - 3) // 2 + 1
+        x = self.tensor("top.pool", H4, W4, 64)
+        self.ops.append(Op(OP_MAXPOOL, out=x, inp=t))
+        self.out_h, self.out_w = H4, W4
+        skip1 = skip2 = None
+        for s in range(self.stage_num):
+            last = s == self.stage_num - 1
+            x, skip1, skip2 = self._stage(s, x, skip1, skip2, gen_skip=not last, heads=last)
+
+    def _bottleneck(self, pre, x, planes, stride, has_ds, add1=None, add2=None):
+        # Bottleneck (smap.py:48-77): stride on the 3x3, shortcut 1x1 stride-s when shape changes
+        idn = self.conv(pre + ".downsample", [pre + ".downsample"], x, 1, stride, relu=False) if has_ds else x
+        y = self.conv(pre + ".c1", [pre + ".conv_bn_relu1"], x, 1, 1, relu=True)
+        y = self.conv(pre + ".c2", [pre + ".conv_bn_relu2"], y, 3, stride, relu=True)
+        return self.conv(pre + ".c3", [pre + ".conv_bn_relu3"], y, 1, 1, relu=True, res=idn, add1=add1, add2=add2)
+
+    def _stage(self, s, x, skip1, skip2, gen_skip, heads):
+        pre = f"stage{s}."
+        feats = []
+        inpl = 64
+        for li, (planes, nblk) in enumerate(zip(PLANES, LAYERS)):
+            stride = 1 if li == 0 else 2
+            for j in range(nblk):
+                lastb = j == nblk - 1
+                a1 = skip1[li] if (skip1 is not None and lastb) else None   # smap.py:142-153
+                a2 = skip2[li] if (skip2 is not None and lastb) else None
+                has_ds = j == 0 and (stride != 1 or inpl != planes * 4)
+                x = self._bottleneck(f"{pre}downsample.layer{li + 1}.{j}", x, planes, stride if j == 0 else 1,
+                                     has_ds, a1, a2)
+                inpl = planes * 4
+            feats.append(x)
+        x1, x2, x3, x4 = feats
+        # Upsample_module (smap.py:244-286): up1 on x4 ... up4 on x1
+        out, s1, s2, cross = None, [None] * 4, [None] * 4, None
+        head_t = {}
+        for ind, xin in enumerate((x4, x3, x2, x1)):
+            u = f"{pre}upsample.up{ind + 1}"
+            if ind == 0:
+                out = self.conv(u + ".out", [u + ".u_skip"], xin, relu=True)
+            else:
+                a = self.conv(u + ".u_skip", [u + ".u_skip"], xin, relu=False)
+                tl = self.conv(u + ".up_conv@low", [u + ".up_conv"], out, relu=False)   # commuted with the upsample
+                o = self.tensor(u + ".out", a.H, a.W, a.C)
+                self.ops.append(Op(OP_UPADD, out=o, inp=a, aux=[tl], p=dict(relu=1)))
+                out = o
+            if gen_skip:
+                lvl = 3 - ind                      # skip lists are fine -> coarse (smap.py:283-284)
+                s1[lvl] = self.conv(u + ".skip1", [u + ".skip1"], xin, relu=True)
+                s2[lvl] = self.conv(u + ".skip2", [u + ".skip2"], out, relu=True)
+                if ind == 3:
+                    cross = self.conv(u + ".cross_conv", [u + ".cross_conv"], out, relu=True)
+            if heads:
+                if ind == 3:
+                    m = self.conv(u + ".heads1x1", [u + ".res_conv1", u + ".res_d_conv1", u + ".res_rd_conv1"],
+                                  out, relu=True)
+                    c = self.chl
+                    head_t["res4"] = self.conv(u + ".res", [u + ".res_conv2"], m, 3, relu=False, in_c_off=0,
+                                               cin=c, out_fp32=True)
+                    head_t["res_d"] = self.conv(u + ".res_d", [u + ".res_d_conv2"], m, 3, relu=False, in_c_off=c,
+                                                cin=c, out_fp32=True)
+                    head_t["res_rd"] = self.conv(u + ".res_rd", [u + ".res_rd_conv2"], m, 3, relu=False,
+                                                 in_c_off=2 * c, cin=c, out_fp32=True)
+                elif ind >= 1:
+                    m = self.conv(u + ".res1", [u + ".res_conv1"], out, relu=True)
+                    head_t[f"res{ind + 1}"] = self.conv(u + ".res", [u + ".res_conv2"], m, 3, relu=False,
+                                                        out_fp32=True)
+        if heads:
+            B, h, w = self.B, self.out_h, self.out_w
+            n_hms, n_d = self.kpt_paf, self.paf
+            self.out_layout = dict(hms=(0, n_hms), det_d=(B * n_hms * h * w * 4, n_d),
+                                   root_d=(B * (n_hms + n_d) * h * w * 4, 1))
+            self.out_bytes = B * (n_hms + n_d + 1) * h * w * 4
+            # outputs_2d = res4 + res3 + res2 (smap.py:417)
+            self.ops.append(Op(OP_HEADSUM, aux=[head_t["res4"], head_t["res3"], head_t["res2"]],
+                               p=dict(Cout=n_hms, ext_off=self.out_layout["hms"][0])))
+            self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_d"]], p=dict(Cout=n_d, ext_off=self.out_layout["det_d"][0])))
+            self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_rd"]], p=dict(Cout=1, ext_off=self.out_layout["root_d"][0])))
+        return cross, (s1 if gen_skip else None), (s2 if gen_skip else None)
+
+    # -- arena: liveness-based first-fit allocation
+    def allocate(self, reuse=True):
+        for i, op in enumerate(self.ops):
+            for t in [op.inp, op.res, op.add1, op.add2] + list(op.aux):
+                if t is not None:
+                    t.last = i
+            if op.out is not None:
+                op.out.first = i
+                op.out.last = max(op.out.last, i)
+        free, top = [], 0            # free: list of (off, size)
+        by_first = {}
+        for t in self.tensors:
+            by_first.setdefault(t.first, []).append(t)
+        expiring = {}
+        for t in self.tensors:
+            expiring.setdefault(t.last, []).append(t)
+        for i in range(len(self.ops)):
+            for t in by_first.get(i, []):
+                need = _rup(t.nbytes, ALIGN)
+                pick = None
+                if reuse:
+                    for k, (o, sz) in enumerate(free):
+                        if sz >= need and (pick is None or sz < free[pick][1]):
+                            pick = k
+                if pick is not None:
+                    o, sz = free.pop(pick)
+                    t.off = o
+                    if sz > need:
+                        free.append((o + need, sz - need))
+                else:
+                    t.off = top
+                    top += need
+            for t in expiring.get(i, []):
+                if reuse and t.off >= 0:
+                    free.append((t.off, _rup(t.nbytes, ALIGN)))
+                    free.sort()
+                    merged = []
+                    for o, sz in free:
+                        if merged and merged[-1][0] + merged[-1][1] == o:
+                            merged[-1] = (merged[-1][0], merged[-1][1] + sz)
+                        else:
+                            merged.append((o, sz))
+                    free = merged
+        self.arena_bytes = max(top, ALIGN)
+        return self.arena_bytes
+
+    def emit(self):
+        arr = (_L.SmapOp * len(self.ops))()
+        for i, op in enumerate(self.ops):
+            o = arr[i]
+            C.memset(C.byref(o), 0, C.sizeof(o))
+            o.kind = op.kind
+            o.B = self.B
+            o.res_off = o.add1_off = o.add2_off = -1
+            for k in range(3):
+                o.aux_off[k] = -1
+            o.in_off = o.out_off = o.w_off = o.bias_off = o.ext_off = -1
+            p = op.p
+            if op.kind == OP_CONV:
+                x, y = op.inp, op.out
+                o.H, o.W, o.Cin, o.in_stride_c, o.in_c_off = x.H, x.W, p["Cin"], x.C, p["in_c_off"]
+                o.Ho, o.Wo, o.Cout = y.H, y.W, p["Cout"]
+                o.ksize, o.stride, o.pad, o.relu = p["ksize"], p["stride"], p["pad"], p["relu"]
+                o.cout_pad, o.out_stride_c, o.out_c_off = p["cout_pad"], y.C, 0
+                o.out_fp32, o.tile = p["out_fp32"], p["tile"]
+                o.in_off, o.out_off, o.w_off, o.bias_off = x.off, y.off, p["w_off"], p["bias_off"]
+                for nm in ("res", "add1", "add2"):
+                    t = getattr(op, nm)
+                    if t is not None:
+                        assert (t.H, t.W, t.C) == (y.H, y.W, y.C) and t.esize == 2, (y.name, nm)
+                        setattr(o, nm + "_off", t.off)
+            elif op.kind == OP_STEM:
+                y = op.out
+                o.H, o.W, o.Cin, o.Ho, o.Wo, o.Cout = self.H, self.W, 3, y.H, y.W, 64
+                o.ksize, o.stride, o.pad, o.relu = 7, 2, 3, 1
+                o.out_off, o.w_off, o.bias_off = y.off, p["w_off"], p["bias_off"]
+            elif op.kind == OP_MAXPOOL:
+                x, y = op.inp, op.out
+                o.H, o.W, o.Cin, o.Ho, o.Wo, o.Cout = x.H, x.W, x.C, y.H, y.W, y.C
+                o.ksize, o.stride, o.pad = 3, 2, 1
+                o.in_off, o.out_off = x.off, y.off
+            elif op.kind == OP_UPADD:
+                x, y, t = op.inp, op.out, op.aux[0]
+                o.H, o.W, o.Cin, o.Ho, o.Wo, o.Cout = x.H, x.W, x.C, y.H, y.W, y.C
+                o.relu = p["relu"]
+                o.in_off, o.out_off = x.off, y.off
+                o.aux_off[0], o.aux_h[0], o.aux_w[0] = t.off, t.H, t.W
+            elif op.kind == OP_HEADSUM:
+                s0 = op.aux[0]
+                assert all(t.C == s0.C and t.esize == 4 for t in op.aux)
+                o.H, o.W, o.Cin, o.Ho, o.Wo, o.Cout = s0.H, s0.W, s0.C, self.out_h, self.out_w, p["Cout"]
+                o.n_aux = len(op.aux)
+                for k, t in enumerate(op.aux):
+                    o.aux_off[k], o.aux_h[k], o.aux_w[k] = t.off, t.H, t.W
+                o.ext_off = p["ext_off"]
+        return arr
+
+    def weight_blob(self):
+        blob = torch.zeros((max(self.woff, ALIGN),), dtype=torch.uint8)
+        for off, raw in self.wchunks:
+            blob[off:off + raw.numel()] = raw
+        return blob
+
+
+# ----------------------------------------------------------------------------- engine
+class BackboneEngine:
+    """Device-resident schedule for one (B, H, W): weights, arena, output buffer, plan."""
+
+    def __init__(self, state_dict, B, H, W, device, stage_num=3, chl=256, kpt_paf=43, paf=14, reuse=True):
+        self.lib = _L.load()          # fails loudly when libsmap_hip.so is missing
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BackboneEngine needs a ROCm GPU device (no CPU path in smap_amd)")
+        sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+        g = Graph(sd, B, H, W, stage_num, chl, kpt_paf, paf)
+        g.allocate(reuse=reuse)
+        self.graph, self.B, self.H, self.W = g, B, H, W
+        self.h, self.w = g.out_h, g.out_w
+        self.ops = g.emit()
+        self.n_ops = len(g.ops)
+        self.weights = g.weight_blob().to(self.device)
+        self.arena = torch.zeros((g.arena_bytes,), dtype=torch.uint8, device=self.device)
+        self.out = torch.zeros((g.out_bytes // 4,), dtype=torch.float32, device=self.device)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _L.check(self.lib.smap_plan_create(self.ops, self.n_ops, C.byref(handle)), "smap_plan_create")
+        self.handle = handle
+        n = B * self.h * self.w
+        self.hms = self.out[:n * kpt_paf].view(B, kpt_paf, self.h, self.w)
+        self.det_d = self.out[n * kpt_paf:n * (kpt_paf + paf)].view(B, paf, self.h, self.w)
+        self.root_d = self.out[n * (kpt_paf + paf):].view(B, 1, self.h, self.w)
+        self.flops_per_batch = g.flops
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.smap_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def run(self, imgs, first=0, count=None):
+        """imgs: [B,3,H,W] fp32 contiguous on the device.  Returns (hms, det_d, root_d) views
+        of the engine's output buffer (overwritten by the next run)."""
+        if tuple(imgs.shape) != (self.B, 3, self.H, self.W) or imgs.dtype != torch.float32 or not imgs.is_cuda:
+            raise ValueError(f"imgs must be a float32 GPU tensor [{self.B},3,{self.H},{self.W}], got "
+                             f"{tuple(imgs.shape)} {imgs.dtype} {imgs.device}")
+        imgs = imgs.contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        count = self.n_ops - first if count is None else count
+        with torch.cuda.device(self.device):
+            _L.check(self.lib.smap_plan_run_range(self.handle, first, count, C.c_void_p(imgs.data_ptr()),
+                                                  C.c_void_p(self.arena.data_ptr()), C.c_void_p(self.weights.data_ptr()),
+                                                  C.c_void_p(self.out.data_ptr()), st), "smap_plan_run")
+        return self.hms, self.det_d, self.root_d
+
+    def read_tensor(self, name):
+        """Debug/test helper: NHWC activation `name` from the arena (valid with reuse=False)."""
+        t = next(t for t in self.graph.tensors if t.name == name)
+        dt = torch.float16 if t.esize == 2 else torch.float32
+        raw = self.arena[t.off:t.off + t.nbytes].view(dt)
+        return raw.view(t.B, t.H, t.W, t.C)

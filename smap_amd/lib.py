@@ -1,0 +1,86 @@
+"""ctypes loader for libsmap_hip.so -- the ONLY compute backend of this package.
+
+There is deliberately no fallback: if the HIP library is missing or a symbol of
+include/smap_hip.h is absent, importing / calling fails loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libsmap_hip.so")
+
+# every symbol include/smap_hip.h declares
+SYMBOLS = [
+    "smap_version", "smap_scale_hms", "smap_nms", "smap_paf_score", "smap_group", "smap_lift",
+    "smap_refine", "smap_refine_mlp", "smap_sizeof_op", "smap_plan_create", "smap_plan_destroy", "smap_plan_run", "smap_plan_run_range",
+]
+
+
+class SmapOp(C.Structure):
+    """Mirror of `struct smap_op` (include/smap_hip.h)."""
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("in_stride_c", C.c_int32), ("in_c_off", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("relu", C.c_int32), ("cout_pad", C.c_int32), ("out_stride_c", C.c_int32),
+        ("out_c_off", C.c_int32), ("out_fp32", C.c_int32), ("tile", C.c_int32), ("n_aux", C.c_int32),
+        ("in_off", C.c_int64), ("out_off", C.c_int64),
+        ("w_off", C.c_int64), ("bias_off", C.c_int64),
+        ("res_off", C.c_int64), ("add1_off", C.c_int64), ("add2_off", C.c_int64),
+        ("aux_off", C.c_int64 * 3), ("aux_h", C.c_int32 * 3), ("aux_w", C.c_int32 * 3),
+        ("ext_off", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+class SmapError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} is missing: build it with `python -m smap_amd.build` "
+            "(hipcc --offload-arch=gfx950). smap_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(SO_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"{SO_PATH} lacks symbols {missing}; rebuild with `python -m smap_amd.build --force`")
+    vp, ip, fp = C.c_void_p, C.c_int, C.c_float
+    lib.smap_version.restype = C.c_char_p
+    lib.smap_scale_hms.argtypes = [vp, ip, ip, ip, vp]
+    lib.smap_nms.argtypes = [vp, ip, ip, ip, ip, fp, vp, vp]
+    lib.smap_paf_score.argtypes = [vp, vp, ip, ip, ip, vp, vp]
+    lib.smap_group.argtypes = [vp, vp, vp, ip, ip, ip, ip, ip, vp, vp, vp]
+    lib.smap_lift.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp, vp, vp, vp]
+    lib.smap_refine.argtypes = [vp, vp, vp, ip, C.POINTER(vp), C.POINTER(vp), vp, vp]
+    lib.smap_refine_mlp.argtypes = [vp, ip, C.POINTER(vp), C.POINTER(vp), vp, vp]
+    lib.smap_plan_create.argtypes = [C.POINTER(SmapOp), ip, C.POINTER(vp)]
+    lib.smap_plan_destroy.argtypes = [vp]
+    lib.smap_plan_destroy.restype = None
+    lib.smap_plan_run.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.smap_plan_run_range.argtypes = [vp, ip, ip, vp, vp, vp, vp, vp]
+    for s in SYMBOLS:
+        if s not in ("smap_version", "smap_plan_destroy"):  # everything else returns int
+            getattr(lib, s).restype = ip
+    if lib.smap_sizeof_op() != C.sizeof(SmapOp):
+        raise ImportError(f"smap_op layout mismatch: C {lib.smap_sizeof_op()} vs ctypes {C.sizeof(SmapOp)}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        detail = "argument error" if rc == -1 else f"hipError_t {-rc - 1000}" if rc <= -1000 else f"code {rc}"
+        raise SmapError(f"{what} failed: {detail}")
+
+
+def version():
+    return load().smap_version().decode()

@@ -1,0 +1,202 @@
+"""CPU suite: pins the oracle (oracle/) against the golden vectors produced by importing the
+reference's Python (tests/golden/gen_golden.py), and against known answers that follow from
+the reference's kernel semantics (strict >, global scan rank, int(a+.5), caps)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_cfg, synth_scene, noise_scene, PAIRS
+from fixture_maps import expand
+from recipe import recipe_state_dict
+from oracle import oracle_lib as O
+
+
+# ------------------------------------------------------------------ lift / refine (golden)
+def _refine_folded():
+    from smap_amd.model.refinenet import RefineNet
+    net = RefineNet().eval()
+    net.load_state_dict(recipe_state_dict(net.state_dict()))
+    wt, bs = net.folded("cpu")
+    return [w.t().contiguous().numpy() for w in wt], [b.numpy() for b in bs], net
+
+
+def test_lift_matches_reference_golden(golden_dir):
+    z = np.load(f"{golden_dir}/lift.npz")
+    for c in range(int(z["n_cases"])):
+        p = f"c{c}_"
+        det, root = expand(z[p + "det_c"], 0.05), expand(z[p + "root_c"], 0.002)[0]
+        p2, p3, rz = O.lift(z[p + "bodys"], det, root, z[p + "cam"])
+        # bit-exact against the reference's numpy post-process
+        assert np.array_equal(p2, z[p + "pred_2d"])
+        assert np.array_equal(p3, z[p + "pred_3d"])
+        assert np.array_equal(rz, z[p + "root_z"])
+
+
+def test_refine_matches_reference_golden(golden_dir):
+    z = np.load(f"{golden_dir}/lift.npz")
+    W, B, _ = _refine_folded()
+    for c in range(int(z["n_cases"])):
+        p = f"c{c}_"
+        out = O.refine(z[p + "pred_2d"], z[p + "pred_3d"], W, B)
+        # 3D joints within 1e-3 m == 0.1 cm (north_star); observed ~1 fp32 ulp
+        assert np.abs(out - z[p + "refined"]).max() < 1e-2
+
+
+def test_refinenet_module_keys(golden_dir):
+    z = np.load(f"{golden_dir}/refine.npz")
+    _, _, net = _refine_folded()
+    assert len(net.state_dict()) == int(z["n_keys"]) == 30
+
+
+# ------------------------------------------------------------------ backbone (golden)
+@pytest.fixture(scope="module")
+def small_model():
+    from smap_amd.model.smap import SMAP
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((16, 24))).eval()
+    sd = recipe_state_dict(net.state_dict())
+    net.load_state_dict(sd)
+    return net, sd
+
+
+def test_module_keys_and_default_init_match_reference(golden_dir):
+    from smap_amd.model.smap import SMAP
+    d = np.load(f"{golden_dir}/default_init.npz")
+    torch.manual_seed(0)
+    sd = SMAP(make_cfg((128, 208))).state_dict()
+    assert list(sd.keys()) == [str(k) for k in d["all_keys"]]          # 1876 keys, same order
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in d["all_shapes"]]
+    for k, s, a in zip(d["keys"], d["sums"], d["abssums"]):            # same RNG consumption order
+        assert float(sd[str(k)].double().sum()) == pytest.approx(float(s), abs=1e-9)
+        assert float(sd[str(k)].double().abs().sum()) == pytest.approx(float(a), abs=1e-9)
+    assert sum(p.numel() for p in SMAP(make_cfg()).parameters()) == 91318696
+
+
+def test_backbone_ref_matches_reference_golden(golden_dir, small_model):
+    from oracle.backbone_ref import smap_forward
+    z = np.load(f"{golden_dir}/backbone_small.npz")
+    _, sd = small_model
+    with torch.no_grad():
+        h, d, r = smap_forward(sd, torch.from_numpy(z["x"]))
+    for a, k in ((h, "hms"), (d, "det_d"), (r, "root_d")):
+        assert np.abs(a.numpy() - z[k]).max() <= 1e-5 * np.abs(z[k]).max()
+
+
+def test_schedule_wiring_matches_reference_golden(golden_dir, small_model):
+    """The engine's op list, interpreted in fp32 on CPU, reproduces the reference outputs:
+    folding, dead-head removal, commuted up_conv, merged heads, epilogue skip adds."""
+    from smap_amd.engine import Graph
+    from oracle.graph_interp import run_graph
+    z = np.load(f"{golden_dir}/backbone_small.npz")
+    _, sd = small_model
+    g = Graph(sd, 2, 64, 96, keep_ref=True)
+    g.allocate()
+    assert len(g.ops) == 217
+    with torch.no_grad():
+        outs = run_graph(g, torch.from_numpy(z["x"]), quantize=False)
+        outs_q = run_graph(g, torch.from_numpy(z["x"]), quantize=True)
+    for a, q, k in zip(outs, outs_q, ("hms", "det_d", "root_d")):
+        ref = z[k]
+        assert np.abs(a.numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+        assert np.abs(q.numpy() - ref).max() <= 5e-3 * np.abs(ref).max()   # fp16 storage budget
+
+
+def test_arena_allocation_has_no_live_overlap(small_model):
+    from smap_amd.engine import Graph
+    _, sd = small_model
+    g = Graph(sd, 1, 64, 96)
+    g.allocate(reuse=True)
+    ts = [t for t in g.tensors if t.off >= 0]
+    assert len(ts) == len(g.tensors)
+    for i, a in enumerate(ts):
+        for b in ts[i + 1:]:
+            live = not (a.last < b.first or b.last < a.first)
+            mem = not (a.off + a.nbytes <= b.off or b.off + b.nbytes <= a.off)
+            assert not (live and mem), (a.name, b.name)
+    g2 = Graph(sd, 1, 64, 96)
+    assert g2.allocate(reuse=False) >= g.arena_bytes
+
+
+# ------------------------------------------------------------------ association known answers
+def _blank(H=128, W=208):
+    return np.zeros((43, H, W), np.float32)
+
+
+def test_nms_single_symmetric_blob():
+    hms = _blank()
+    yy, xx = np.mgrid[0:128, 0:208]
+    hms[3] = np.exp(-((xx - 50) ** 2 + (yy - 40) ** 2) / (2 * 1.5 ** 2)).astype(np.float32)
+    pk = O.nms(hms)
+    assert pk[3, 0, 0] == 1 and all(pk[c, 0, 0] == 0 for c in range(15) if c != 3)
+    # symmetric blob: centroid == centre, +0.5 offset (nmsBase.cu:127-128)
+    assert abs(pk[3, 1, 0] - 50.5) < 1e-4 and abs(pk[3, 1, 1] - 40.5) < 1e-4
+    assert pk[3, 1, 2] == np.float32(1.0)
+
+
+def test_nms_plateau_and_border_and_threshold():
+    hms = _blank()
+    hms[0, 10, 10] = hms[0, 10, 11] = 0.9          # two equal neighbours: strict > -> no peak
+    hms[1, 0, 5] = 0.9                              # border row never registers
+    hms[2, 20, 20] = 0.2                            # == threshold: not > 0.2
+    hms[4, 20, 20] = np.float32(0.2) + np.float32(1e-6)
+    pk = O.nms(hms)
+    assert pk[0, 0, 0] == 0 and pk[1, 0, 0] == 0 and pk[2, 0, 0] == 0 and pk[4, 0, 0] == 1
+
+
+def test_nms_raster_order_and_cap():
+    hms = _blank()
+    pts = [(y, x) for y in range(4, 124, 8) for x in range(4, 204, 8)][:300]   # >= 8 px apart: 7x7 windows isolated
+    for i, (y, x) in enumerate(pts):
+        hms[7, y, x] = 0.3 + 0.001 * (i % 50)
+    pk = O.nms(hms)
+    assert pk[7, 0, 0] == 127                       # truncated to maxPeaks (nmsBase.cu:131-133)
+    for r in range(127):                            # r-th peak in raster (y-major) order
+        y, x = pts[r]
+        assert pk[7, r + 1, 2] == hms[7, y, x]
+        assert abs(pk[7, r + 1, 0] - (x + 0.5)) < 1e-5 and abs(pk[7, r + 1, 1] - (y + 0.5)) < 1e-5
+
+
+def test_paf_score_straight_limb_and_fallbacks():
+    hms = _blank()
+    hms[0, 30, 40] = 1.0      # neck
+    hms[1, 30, 80] = 1.0      # head, 40 px to the right
+    hms[15, 28:33, 38:84] = 1.0      # limb 0 PAF-x ribbon, unit vector (1,0)
+    hms[2, 60, 100] = 1.0     # pelvis far away, no PAF evidence on limb 1
+    pk = O.nms(hms)
+    sc = O.paf_score(hms, pk)
+    assert sc.shape == (14, 127, 127)
+    assert sc[0, 0, 0] == pytest.approx(1.0, abs=1e-6)          # every sample agrees with the limb
+    assert sc[0, 0, 1] == -1 and sc[0, 1, 0] == -1              # no such peak pair
+    # limb 1 (neck->pelvis): no PAF evidence and far apart -> -1
+    assert sc[1, 0, 0] == -1
+
+
+def test_paf_score_close_points_get_default():
+    hms = _blank()
+    hms[0, 30, 40] = 1.0
+    hms[0, 30, 41] = 0.5      # makes the neck centroid sub-pixel, still one peak
+    hms[1, 31, 40] = 1.0      # head 1 px away, PAF empty -> distance fallback (bodyPartConnectorBase.cu:56-59)
+    sc = O.paf_score(hms, O.nms(hms))
+    assert sc[0, 0, 0] == np.float32(np.float32(0.1) + 1e-6)
+
+
+def test_group_depth_order_and_empty():
+    hms, rdepth, joints, depths = synth_scene(3, seed=5, noise=0.0, drop=0.0)
+    bodys, pk, sc = O.connect(hms, rdepth)
+    assert bodys.shape == (3, 15, 4)
+    assert np.all(bodys[:, :, 2] == 0)                             # column 2 untouched (association.cpp:151)
+    order = np.argsort(depths, kind="stable")
+    for i, p in enumerate(order):                                  # near -> far, all joints found
+        assert np.abs(bodys[i, :, :2] - (joints[p] + 0.5)).max() < 1.5
+        assert np.all(bodys[i, :, 3] > 0.2)
+    empty, _, _ = O.connect(_blank(), np.ones((128, 208), np.float32))
+    assert empty.shape == (0, 15, 4)
+
+
+def test_group_each_candidate_used_once():
+    hms, rdepth = noise_scene(3)
+    bodys, pk, sc = O.connect(hms, rdepth)
+    assert bodys.shape[0] == 127
+    for j in range(15):
+        got = bodys[bodys[:, j, 3] > 0][:, j, :2]
+        assert len(np.unique(got, axis=0)) == len(got)
