@@ -6,6 +6,11 @@ include/smap_hip.h is absent, importing / calling fails loudly.
 import ctypes as C
 import os
 
+# torch first: it ships its own libamdhip64.so (SONAME libamdhip64.so.7).  libsmap_hip.so must bind
+# to THAT runtime instance (streams / device pointers are handed over from PyTorch); loading our
+# library before torch would pull a second HIP runtime from /opt/rocm into the process.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "libsmap_hip.so")
 
