@@ -1,0 +1,70 @@
+"""Image-folder dataset for `run_inference` (reference: dataset/custom_dataset.py:11-68).
+
+Same outputs: (normalised BGR CHW float tensor letter-boxed to 832x512 with 128-grey padding,
+image name, `scale` dict with scale/img_width/img_height/net_width/net_height).
+cv2 and torchvision are not part of this image: decoding uses PIL (converted to BGR like
+cv2.imread) and the resize uses torch bilinear with half-pixel centres and no anti-aliasing,
+the sampling rule of cv2.INTER_LINEAR.  uint8 rounding can differ from OpenCV's fixed-point
+path by 1 LSB -- pre-processing is outside the measured hot path.
+`.npy` files holding an HxWx3 uint8 BGR array are accepted as well.
+"""
+import glob
+import os.path as osp
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.utils.data import Dataset
+
+
+class CustomDataset(Dataset):
+    def __init__(self, cfg, dataset_path):
+        self.dataset_path = dataset_path
+        self.image_list = []
+        for ext in ("jpg", "png", "jpeg", "npy"):
+            self.image_list.extend(sorted(glob.glob(osp.join(dataset_path, f"**/*.{ext}"), recursive=True)))
+        self.list_size = len(self.image_list)
+        self.net_input_shape = (832, 512)       # (width, height)
+        self.mean = torch.tensor(cfg.INPUT.MEANS, dtype=torch.float32).view(3, 1, 1)
+        self.std = torch.tensor(cfg.INPUT.STDS, dtype=torch.float32).view(3, 1, 1)
+
+    def __len__(self):
+        return self.list_size
+
+    @staticmethod
+    def _read_bgr(path):
+        if path.endswith(".npy"):
+            return np.load(path)
+        from PIL import Image
+        return np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1].copy()
+
+    def __getitem__(self, index):
+        image_path = self.image_list[index].rstrip()
+        image_name = image_path.replace(self.dataset_path, "").lstrip("/")
+        img = self._read_bgr(image_path)
+        self.image_shape = (img.shape[1], img.shape[0])
+        net_img, scale = self.aug_croppad(img)
+        t = torch.from_numpy(net_img).permute(2, 0, 1).float().div(255.0)      # ToTensor
+        return (t - self.mean) / self.std, image_name, scale                    # Normalize
+
+    def aug_croppad(self, img):
+        crop_x, crop_y = self.net_input_shape
+        w0, h0 = self.image_shape
+        s = min(crop_x / w0, crop_y / h0)
+        scale = dict(scale=s, img_width=w0, img_height=h0, net_width=crop_x, net_height=crop_y)
+        nw, nh = int(round(w0 * s)), int(round(h0 * s))          # cv2.resize(fx, fy): dsize = round(src * f)
+        t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+        r = F.interpolate(t, size=(nh, nw), mode="bilinear", align_corners=False, antialias=False)
+        r = r.round().clamp(0, 255).to(torch.uint8)[0].permute(1, 2, 0).numpy()
+        out = np.full((crop_y, crop_x, 3), 128, np.uint8)
+        if nw < crop_x:
+            l = (crop_x - nw) // 2
+            out[:nh, l:l + nw] = r[:crop_y]
+            if nh < crop_y:                       # both short (rounding): centre vertically too
+                out[:] = 128
+                u = (crop_y - nh) // 2
+                out[u:u + nh, l:l + nw] = r
+        else:
+            u = (crop_y - nh) // 2
+            out[u:u + nh, :crop_x] = r[:, :crop_x]
+        return out, scale

@@ -1,0 +1,148 @@
+"""SMAP inference entry point on MI355X (reference: exps/stage3_root2/test.py).
+
+Same command line (test.py:156-177) and the same result JSON
+(`<exp>_<mode>_<data_mode>_<suffix>.json` with `model_pattern` and `3d_pairs`, test.py:32-38,147-151):
+
+    export PROJECT_HOME=/path/to/repo ; export PYTHONPATH=$PYTHONPATH:$PROJECT_HOME
+    python test.py -p SMAP_model.pth -t run_inference -d test [-rp RefineNet.pth] \
+           --batch_size 16 --do_flip 1 --dataset_path /path/to/images
+
+Per batch everything stays on the GPU: HIP backbone -> optional flip-TTA merge -> /255,/127 ->
+batched association -> batched lifting (-> RefineNet); only the poses come back.  Launched under
+`torch.distributed.run` the image list is split in contiguous per-rank blocks
+(lib/utils/dataloader.py:80-85) and the records are gathered with one RCCL all_gather.
+Only `run_inference` is implemented; `generate_result` / `generate_train` need the training
+datasets."""
+import argparse
+import json
+import logging
+import os
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader, Subset
+
+from model.smap import SMAP
+from model.refinenet import RefineNet
+from dataset.custom_dataset import CustomDataset
+from smap_amd.dist import gather_json, shard_range
+from exps.stage3_root2.config import cfg
+from exps.stage3_root2.test_util import default_cams, merge_flip, poses_from_outputs, save_result
+
+
+def get_logger(name, log_dir, filename):
+    os.makedirs(log_dir, exist_ok=True)
+    logger = logging.getLogger(name)
+    if not logger.handlers:
+        logger.setLevel(logging.INFO)
+        fmt = logging.Formatter("%(asctime)s %(levelname)s %(message)s")
+        for h in (logging.StreamHandler(), logging.FileHandler(os.path.join(log_dir, filename))):
+            h.setFormatter(fmt)
+            logger.addHandler(h)
+    return logger
+
+
+def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, device, output_dir=""):
+    os.makedirs(output_dir, exist_ok=True)
+    model.eval()
+    refine_w = None
+    if refine_model is not None:
+        refine_model.eval()
+        refine_w = refine_model.folded(device)
+    result = dict()
+    result["model_pattern"] = cfg.DATASET.NAME
+    result["3d_pairs"] = []
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    it = data_loader
+    if rank == 0:
+        try:
+            from tqdm import tqdm
+            it = tqdm(data_loader)
+        except ImportError:
+            pass
+    for batch in it:
+        imgs, img_path, scales = batch
+        imgs = imgs.to(device)
+        with torch.no_grad():
+            outputs_2d, outputs_3d, outputs_rd = model(imgs)
+            if cfg.DO_FLIP:
+                outputs_2d_flip, _, _ = model(torch.flip(imgs, [-1]))
+                merge_flip(outputs_2d, outputs_2d_flip, cfg)
+            cams = default_cams(scales, len(imgs))
+            p2, p3, rz, counts = poses_from_outputs(outputs_2d, outputs_3d, outputs_rd, cams, cfg, refine_w)
+        for i in range(len(imgs)):
+            P = int(counts[i])
+            if P == 0:
+                continue                                                        # test.py:131-132
+            save_result(p2[i, :P], p3[i, :P], None, rz[i, :P], img_path[i], result)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        parts = gather_json(result["3d_pairs"], device)
+        result["3d_pairs"] = [r for part in parts for r in part]                # rank order == frame order
+    if rank == 0:
+        dir_name = os.path.split(os.path.split(os.path.realpath(__file__))[0])[1]
+        name = os.path.join(output_dir, "{}_{}_{}_{}.json".format(dir_name, cfg.TEST_MODE, cfg.DATA_MODE,
+                                                                  cfg.JSON_SUFFIX_NAME))
+        with open(name, "w") as f:
+            json.dump(result, f)
+        logger.info("Pairs writed to {}".format(name))
+    return result
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--test_mode", "-t", type=str, default="run_inference",
+                        choices=["generate_train", "generate_result", "run_inference"])
+    parser.add_argument("--data_mode", "-d", type=str, default="test", choices=["test", "generation"])
+    parser.add_argument("--SMAP_path", "-p", type=str, default="log/SMAP.pth", help="Path to SMAP model")
+    parser.add_argument("--RefineNet_path", "-rp", type=str, default="",
+                        help="Path to RefineNet model, empty means without RefineNet")
+    parser.add_argument("--batch_size", type=int, default=1, help="Batch_size of test")
+    parser.add_argument("--do_flip", type=float, default=0, help="Set to 1 if do flip when test")
+    parser.add_argument("--dataset_path", type=str, default="", help='Image dir path of "run_inference" test mode')
+    parser.add_argument("--json_name", type=str, default="", help="Add a suffix to the result json.")
+    args = parser.parse_args()
+    if args.test_mode != "run_inference":
+        raise NotImplementedError("only -t run_inference is implemented (the other modes need the training datasets)")
+    cfg.TEST_MODE = args.test_mode
+    cfg.DATA_MODE = args.data_mode
+    cfg.REFINE = len(args.RefineNet_path) > 0
+    cfg.DO_FLIP = args.do_flip
+    cfg.JSON_SUFFIX_NAME = args.json_name
+    cfg.TEST.IMG_PER_GPU = args.batch_size
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl")
+    torch.cuda.set_device(local)
+    os.makedirs(cfg.TEST_DIR, exist_ok=True)
+    logger = get_logger(cfg.DATASET.NAME, cfg.TEST_DIR, "test_log_{}.txt".format(args.test_mode))
+
+    model = SMAP(cfg, run_efficient=cfg.RUN_EFFICIENT)
+    device = torch.device(cfg.MODEL.DEVICE, local)
+    model.to(device)
+
+    dataset = CustomDataset(cfg, args.dataset_path)
+    if world > 1:
+        st, ed = shard_range(len(dataset), world, dist.get_rank())
+        dataset = Subset(dataset, range(st, ed))
+    data_loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=False)
+
+    refine_model = RefineNet().to(device) if cfg.REFINE else None
+    if os.path.exists(args.SMAP_path):
+        state_dict = torch.load(args.SMAP_path, map_location=lambda storage, loc: storage)
+        model.load_state_dict(state_dict["model"])
+        if refine_model is not None:
+            if os.path.exists(args.RefineNet_path):
+                refine_model.load_state_dict(torch.load(args.RefineNet_path, map_location="cpu"))
+            else:
+                logger.info("No such RefineNet checkpoint of {}".format(args.RefineNet_path))
+                return
+        generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, device,
+                                output_dir=os.path.join(cfg.OUTPUT_DIR, "result"))
+    else:
+        logger.info("No such checkpoint of SMAP {}".format(args.SMAP_path))
+
+
+if __name__ == "__main__":
+    main()
