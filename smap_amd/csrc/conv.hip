@@ -37,15 +37,19 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 constexpr int BK = 64;            // halves per K chunk
 constexpr int ROWB = BK * 2;      // bytes per LDS row
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 {
     static_assert(WM * WN == 4, "4 waves");
+    static_assert(STAGES >= 2 && STAGES <= 4, "2..4 LDS stages");
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     static_assert(MI >= 1 && NI >= 1, "tile too small for the wave grid");
     constexpr int STAGE = (BM + BN) * ROWB;
-    static_assert(2 * STAGE >= BM * BN * 4, "epilogue tile must fit in the staging LDS");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int LPT = BM / 32 + BN / 32;             // LDS-DMA loads per thread per K tile
+    static_assert((STAGES - 2) * LPT <= 63, "vmcnt is 6 bits");
+    static_assert(STAGES * STAGE >= BM * BN * 4, "epilogue tile must fit in the staging LDS");
+    static_assert(STAGES * STAGE <= 160 * 1024, "LDS is 160 KiB per CU");
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -68,21 +72,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     const _Float16* __restrict__ wt = a.w;
     const int HoWo = a.Ho * a.Wo;
 
+    // per staged A row: element offset of tap (0,0) and a 9-bit mask of the taps that are in range
     long long a_base[BM / 32];
-    int a_iy0[BM / 32], a_ix0[BM / 32];
+    unsigned a_mask[BM / 32];
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) {
         const int m = m0 + i * 32 + wave * 8 + lrow;
+        a_base[i] = 0;
+        a_mask[i] = 0;
         if (m < a.M) {
             const int b = m / HoWo, rem = m - b * HoWo;
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            a_iy0[i] = oy * a.stride - a.pad;
-            a_ix0[i] = ox * a.stride - a.pad;
-            a_base[i] = ((long long)(b * a.H + a_iy0[i]) * a.W + a_ix0[i]) * a.in_stride_c + a.in_c_off + gch * 8;
-        } else {
-            a_iy0[i] = -(1 << 20);
-            a_ix0[i] = -(1 << 20);
-            a_base[i] = 0;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            a_base[i] = ((long long)(b * a.H + iy0) * a.W + ix0) * a.in_stride_c + a.in_c_off + gch * 8;
+            for (int kh = 0; kh < a.ksize; ++kh)
+                for (int kw = 0; kw < a.ksize; ++kw)
+                    if ((unsigned)(iy0 + kh) < (unsigned)a.H && (unsigned)(ix0 + kw) < (unsigned)a.W)
+                        a_mask[i] |= 1u << (kh * a.ksize + kw);
         }
     }
     long long w_base[BN / 32];
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         char* sB = sA + BM * ROWB;
 #pragma unroll
         for (int i = 0; i < BM / 32; ++i) {
-            const bool ok = (unsigned)(a_iy0[i] + kh) < (unsigned)a.H && (unsigned)(a_ix0[i] + kw) < (unsigned)a.W;
+            const bool ok = (a_mask[i] >> kpos) & 1u;
             const _Float16* src = ok ? in + a_base[i] + koff : a.zero;
             __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sA + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
         }
@@ -126,12 +132,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     const int a_row0 = wm * (BM / WM) + l31;     // + mi*32
     const int b_row0 = wn * (BN / WN) + l31;     // + ni*32
 
-    stage(0, 0);
+    // ---- STAGES-deep LDS-DMA pipeline.  Iteration `it` needs K tile `it`; tiles it+1 .. it+STAGES-2
+    //      stay in flight across the barrier (counted vmcnt + raw s_barrier: a __syncthreads() here
+    //      would drain the DMA queue).  RAW: every wave waits for its own slice of tile `it`, then the
+    //      barrier publishes all slices.  WAR: the buffer refilled after the barrier held tile it-1,
+    //      whose ds_reads were consumed by MFMAs that precede the barrier in program order.
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < n_iter) stage(st, st);
+    int buf = 0, nbuf = STAGES - 1;
     for (int it = 0; it < n_iter; ++it) {
-        const int buf = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's LDS-DMA has landed
-        __syncthreads();
-        if (it + 1 < n_iter) stage(it + 1, buf ^ 1);
+        if (it + STAGES - 1 <= n_iter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + STAGES - 1 < n_iter) stage(it + STAGES - 1, nbuf);
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + BM * ROWB;
 #pragma unroll
@@ -150,6 +165,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
         }
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
     }
     __syncthreads();   // everyone is done reading the staging buffers
 
@@ -220,24 +237,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES>
 hipError_t launch(const ConvArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
 }  // namespace
 
-// tile selector -> (BM, BN).  Keep in sync with smap_amd/plan.py::TILES.
+// tile selector -> (BM, BN).  Keep in sync with smap_amd/engine.py::TILES.
+//   0..4 : 2-stage (double-buffered) variants; 5..9 : the same tiles with deeper LDS-DMA pipelines
 int smap_conv_tile_dims(int tile, int* bm, int* bn)
 {
     switch (tile) {
-        case 0: *bm = 128; *bn = 128; return 0;
-        case 1: *bm = 128; *bn = 64; return 0;
-        case 2: *bm = 64; *bn = 64; return 0;
-        case 3: *bm = 128; *bn = 32; return 0;
-        case 4: *bm = 64; *bn = 128; return 0;
+        case 0: case 5: *bm = 128; *bn = 128; return 0;
+        case 1: case 6: *bm = 128; *bn = 64; return 0;
+        case 2: case 7: *bm = 64; *bn = 64; return 0;
+        case 3: case 8: *bm = 128; *bn = 32; return 0;
+        case 4: case 9: *bm = 64; *bn = 128; return 0;
         default: return -1;
     }
 }
@@ -245,11 +263,16 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
 {
     switch (tile) {
-        case 0: return launch<128, 128, 2, 2>(a, st);
-        case 1: return launch<128, 64, 2, 2>(a, st);
-        case 2: return launch<64, 64, 2, 2>(a, st);
-        case 3: return launch<128, 32, 4, 1>(a, st);
-        case 4: return launch<64, 128, 2, 2>(a, st);
+        case 0: return launch<128, 128, 2, 2, 2>(a, st);
+        case 1: return launch<128, 64, 2, 2, 2>(a, st);
+        case 2: return launch<64, 64, 2, 2, 2>(a, st);
+        case 3: return launch<128, 32, 4, 1, 2>(a, st);
+        case 4: return launch<64, 128, 2, 2, 2>(a, st);
+        case 5: return launch<128, 128, 2, 2, 4>(a, st);    // 128 KiB LDS, 1 block/CU, 3 tiles in flight
+        case 6: return launch<128, 64, 2, 2, 3>(a, st);     //  72 KiB, 2 blocks/CU
+        case 7: return launch<64, 64, 2, 2, 4>(a, st);      //  64 KiB, 2 blocks/CU
+        case 8: return launch<128, 32, 4, 1, 3>(a, st);     //  60 KiB, 2 blocks/CU
+        case 9: return launch<64, 128, 2, 2, 3>(a, st);     //  72 KiB, 2 blocks/CU
         default: return hipErrorInvalidValue;
     }
 }

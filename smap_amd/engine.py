@@ -26,7 +26,22 @@ import torch
 from . import lib as _L
 
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM = range(5)
-TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128)}
+import os
+
+# tile id -> (BM, BN); ids 5..9 are the same tiles with deeper LDS-DMA pipelines (csrc/conv.hip)
+TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
+         5: (128, 128), 6: (128, 64), 7: (64, 64), 8: (128, 32), 9: (64, 128)}
+
+
+def _tile_remap():
+    """SMAP_TILE_REMAP="0:5,1:6" swaps tile variants without touching the schedule (A/B runs)."""
+    out = {}
+    for kv in os.environ.get("SMAP_TILE_REMAP", "").split(","):
+        if ":" in kv:
+            a, b = kv.split(":")
+            assert TILES[int(a)] == TILES[int(b)], "remap must keep the tile shape"
+            out[int(a)] = int(b)
+    return out
 LAYERS = (3, 4, 6, 3)            # smap.py:299  resnet-50
 PLANES = (64, 128, 256, 512)
 ALIGN = 256
@@ -95,6 +110,9 @@ def pick_tile(M, cout):
     return best
 
 
+DEFAULT_REMAP = {}
+
+
 class Graph:
     def __init__(self, sd, B, H, W, stage_num=3, chl=256, kpt_paf=43, paf=14, keep_ref=False):
         self.keep_ref = keep_ref
@@ -133,6 +151,7 @@ class Graph:
         Wo = (x.W + 2 * pad - ksize) // stride + 1
         M = self.B * Ho * Wo
         tile = pick_tile(M, cout)
+        tile = {**DEFAULT_REMAP, **_tile_remap()}.get(tile, tile)
         bn = TILES[tile][1]
         cout_pad = _rup(cout, bn)
         K = ksize * ksize * cin

@@ -99,6 +99,15 @@ CASES = [
     (1, 16, 24, 256, 14, 3, 1, 3, False, False, False),
     (1, 16, 24, 256, 1, 3, 1, 3, False, False, False),
     (3, 10, 14, 192, 320, 3, 1, 0, True, True, True),      # odd sizes, Cout not a tile multiple
+    # deeper LDS-DMA pipelines (tile ids 5..9), incl. K shorter than the pipeline depth
+    (2, 16, 24, 64, 256, 1, 1, 5, False, False, False),
+    (2, 16, 24, 128, 128, 1, 1, 5, True, True, False),
+    (3, 10, 14, 192, 320, 3, 1, 5, True, True, True),
+    (2, 16, 24, 256, 64, 3, 1, 6, True, False, False),
+    (1, 16, 26, 64, 64, 3, 2, 7, True, False, False),
+    (2, 8, 12, 512, 256, 1, 1, 7, True, True, False),
+    (1, 16, 24, 256, 14, 3, 1, 8, False, False, False),
+    (1, 32, 52, 256, 512, 1, 2, 9, False, False, False),
 ]
 
 
