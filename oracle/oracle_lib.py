@@ -38,6 +38,7 @@ def lib():
         _lib.smap_oracle_group.restype = ip
         _lib.smap_oracle_lift.argtypes = [fp, ip, fp, fp, ip, ip, dp, fp, dp, dp]
         _lib.smap_oracle_refine.argtypes = [fp, dp, ip, C.POINTER(fp), C.POINTER(fp), dp]
+        _lib.smap_oracle_sort_depth.argtypes = [fp, ip, C.POINTER(C.c_int), fp]
         _lib.smap_oracle_connect.argtypes = [fp, fp, ip, ip, ip, ip, fp, fp, fp]
         _lib.smap_oracle_connect.restype = ip
     return _lib
@@ -118,3 +119,13 @@ def refine(pred_2d, pred_3d, weights, biases):
     if P:
         lib().smap_oracle_refine(_f(pred_2d), _d(pred_3d), P, wp, bp, _d(out))
     return out
+
+
+def sort_depth(d):
+    """Person order for root depths d (n <= 127): (indices, sorted values), torch.sort(0, False) order."""
+    d = _c32(d)
+    n = d.shape[0]
+    idx = np.zeros((max(n, 1),), np.int32)
+    out = np.zeros((max(n, 1),), np.float32)
+    lib().smap_oracle_sort_depth(_f(d), n, idx.ctypes.data_as(C.POINTER(C.c_int)), _f(out))
+    return idx[:n], out[:n]

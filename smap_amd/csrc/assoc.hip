@@ -225,13 +225,118 @@ __global__ __launch_bounds__(128) void paf_score_kernel(const float* __restrict_
 // greedy); the <=127 destination candidates of a (limb, person) step are spread two
 // per lane and reduced with 6 xor-shuffles: max score, lowest index on ties == the
 // reference's "first strict maximum" scan order.
+struct KV { float v; int i; };
 struct GroupLds {
     float body[MAXP][NJ][4];
     int remap[NJ][PSTRIDE];
-    float depth[PSTRIDE];
+    KV kv[PSTRIDE];            // (root depth, peak index), sorted in place
     float sdepth[PSTRIDE];
     int sidx[PSTRIDE];
 };
+
+// Person order = torch's CPU Tensor::sort(0, false) (association.cpp:144): std::sort over
+// (value, index) pairs with NaN last -- NOT stable, so equal depths come out in libstdc++
+// introsort order.  Same algorithm as bits/stl_algo.h (median-of-3 to first, unguarded
+// partition, threshold 16, heap-sort fallback, final insertion sort), run by one lane on LDS;
+// the recursion on the right part is an explicit stack (sub-ranges are disjoint, so the
+// processing order does not change the result).
+__device__ __forceinline__ bool kv_lt(const KV a, const KV b) { return (!(a.v != a.v) && (b.v != b.v)) || (a.v < b.v); }
+__device__ __forceinline__ void kv_swap(KV* a, KV* b) { const KV t = *a; *a = *b; *b = t; }
+
+__device__ void kv_adjust_heap(KV* f, int hole, int len, const KV val)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (kv_lt(f[child], f[child - 1])) child--;
+        f[hole] = f[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        f[hole] = f[child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && kv_lt(f[parent], val)) { f[hole] = f[parent]; hole = parent; parent = (hole - 1) / 2; }
+    f[hole] = val;
+}
+
+__device__ void kv_heap_sort(KV* f, int len)
+{
+    if (len >= 2)
+        for (int parent = (len - 2) / 2;; --parent) {
+            kv_adjust_heap(f, parent, len, f[parent]);
+            if (parent == 0) break;
+        }
+    while (len > 1) {
+        --len;
+        const KV val = f[len];
+        f[len] = f[0];
+        kv_adjust_heap(f, 0, len, val);
+    }
+}
+
+__device__ __forceinline__ void kv_unguarded_linear_insert(KV* a, int last)
+{
+    const KV val = a[last];
+    int next = last - 1;
+    while (kv_lt(val, a[next])) { a[last] = a[next]; last = next; --next; }
+    a[last] = val;
+}
+
+__device__ void kv_insertion_sort(KV* a, int first, int last)
+{
+    for (int i = first + 1; i < last; ++i) {
+        if (kv_lt(a[i], a[first])) {
+            const KV val = a[i];
+            for (int k = i; k > first; --k) a[k] = a[k - 1];
+            a[first] = val;
+        } else kv_unguarded_linear_insert(a, i);
+    }
+}
+
+__device__ void kv_std_sort(KV* a, int n)
+{
+    if (n <= 0) return;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) ++lg;
+    int stk_f[32], stk_l[32], stk_d[32], sp = 0;
+    stk_f[0] = 0; stk_l[0] = n; stk_d[0] = 2 * lg; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stk_f[sp], last = stk_l[sp], depth = stk_d[sp];
+        while (last - first > 16) {
+            if (depth == 0) { kv_heap_sort(a + first, last - first); break; }
+            --depth;
+            const int mid = first + (last - first) / 2;
+            KV *pa = a + first + 1, *pb = a + mid, *pc = a + last - 1, *pf = a + first;
+            if (kv_lt(*pa, *pb)) {
+                if (kv_lt(*pb, *pc)) kv_swap(pf, pb);
+                else if (kv_lt(*pa, *pc)) kv_swap(pf, pc);
+                else kv_swap(pf, pa);
+            } else if (kv_lt(*pa, *pc)) kv_swap(pf, pa);
+            else if (kv_lt(*pb, *pc)) kv_swap(pf, pc);
+            else kv_swap(pf, pb);
+            int lo = first + 1, hi = last;
+            for (;;) {
+                while (kv_lt(a[lo], a[first])) ++lo;
+                --hi;
+                while (kv_lt(a[first], a[hi])) --hi;
+                if (!(lo < hi)) break;
+                kv_swap(a + lo, a + hi);
+                ++lo;
+            }
+            if (sp < 32) { stk_f[sp] = lo; stk_l[sp] = last; stk_d[sp] = depth; ++sp; }   // right part later
+            last = lo;
+        }
+    }
+    if (n > 16) {
+        kv_insertion_sort(a, 0, 16);
+        for (int i = 16; i < n; ++i) kv_unguarded_linear_insert(a, i);
+    } else kv_insertion_sort(a, 0, n);
+}
 
 __global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ peaks_all,
                                                    const float* __restrict__ scores_all,
@@ -256,19 +361,16 @@ __global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ pea
         for (int i = lane; i < MAXP * NJ * 4; i += 64) bodys[i] = 0.f;
         return;
     }
-    for (int i = lane; i < P; i += 64)
-        L.depth[i] = rdepth[(int)rp[3 * (i + 1) + 1] * W + (int)rp[3 * (i + 1)]];
-    __syncthreads();
-    // stable ascending rank sort (ordinal prior: near persons first)
     for (int i = lane; i < P; i += 64) {
-        const float di = L.depth[i];
-        int r = 0;
-        for (int j = 0; j < P; ++j) {
-            const float dj = L.depth[j];
-            r += (dj < di) || (dj == di && j < i);
-        }
-        L.sidx[r] = i;
-        L.sdepth[r] = di;
+        L.kv[i].v = rdepth[(int)rp[3 * (i + 1) + 1] * W + (int)rp[3 * (i + 1)]];
+        L.kv[i].i = i;
+    }
+    __syncthreads();
+    if (lane == 0) kv_std_sort(L.kv, P);           // ordinal prior: near persons first
+    __syncthreads();
+    for (int i = lane; i < P; i += 64) {
+        L.sidx[i] = L.kv[i].i;
+        L.sdepth[i] = L.kv[i].v;
     }
     __syncthreads();
     for (int i = lane; i < NJ * PSTRIDE; i += 64) {

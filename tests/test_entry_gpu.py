@@ -64,7 +64,7 @@ def test_run_inference_cli_end_to_end(tmp_path):
     for st in range(0, len(ds), 2):
         items = [ds[i] for i in range(st, min(st + 2, len(ds)))]
         imgs = torch.stack([it[0] for it in items]).to(dev)
-        scales = {k: torch.tensor([it[2][k] for it in items]) for k in items[0][2]}
+        scales = {k: torch.tensor([it[2][k] for it in items], dtype=torch.float64) for k in items[0][2]}   # default_collate: python float -> f64
         h, d, rd = net(imgs)
         hf, _, _ = net(torch.flip(imgs, [-1]))
         merge_flip(h, hf, cfg)

@@ -200,3 +200,42 @@ def test_group_each_candidate_used_once():
     for j in range(15):
         got = bodys[bodys[:, j, 3] > 0][:, j, :2]
         assert len(np.unique(got, axis=0)) == len(got)
+
+
+def test_depth_sort_matches_torch_sort():
+    """association.cpp:144 sorts root depths with Tensor::sort(0, false): torch's CPU kernel is
+    std::sort over (value, index) pairs, NOT stable.  The oracle restates libstdc++'s introsort;
+    pin it against torch itself on tie-heavy, ordered, NaN and adversarial inputs."""
+    rng = np.random.default_rng(0)
+
+    def check(d):
+        d = np.asarray(d, np.float32)
+        v, i = torch.from_numpy(d.copy()).sort(0, False)
+        oi, ov = O.sort_depth(d)
+        assert np.array_equal(i.numpy(), oi), (len(d), d[:8])
+        assert np.array_equal(v.numpy().view(np.uint32), ov.view(np.uint32))
+
+    for n in range(0, 128):
+        for _ in range(12):
+            k = rng.integers(1, max(2, n))
+            vals = rng.uniform(0.1, 2, k).astype(np.float32)
+            check(vals[rng.integers(0, k, n)] if n else np.zeros(0, np.float32))
+        check(np.arange(n))
+        check(np.arange(n)[::-1].copy())
+        check(np.ones(n))
+        check(np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]))
+        x = rng.uniform(0, 1, n).astype(np.float32)
+        if n > 3:
+            x[rng.integers(0, n, 2)] = np.nan
+        check(x)
+
+
+def test_group_tie_order_follows_torch_sort():
+    hms, rdepth, _, _ = synth_scene(20, seed=320)      # overlapping depth discs -> equal root depths
+    pk = O.nms(hms)
+    P = int(pk[2, 0, 0])
+    d = np.array([rdepth[int(pk[2, i + 1, 1]), int(pk[2, i + 1, 0])] for i in range(P)], np.float32)
+    assert len(np.unique(d)) < P                       # the scene really has ties
+    _, idx = torch.from_numpy(d).sort(0, False)
+    bodys, _, _ = O.connect(hms, rdepth)
+    assert np.array_equal(bodys[:, 2, :2], pk[2, 1 + idx.numpy(), :2])

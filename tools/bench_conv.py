@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Single-layer micro-benchmark of the MFMA conv kernel (through the C ABI, 1-op plans).
+
+    python tools/bench_conv.py [--iters 50] [--only L2,L4] [--tile-override L2:0]
+Prints us / TFLOP/s / algorithmic GB/s per preset (B=8 shapes of the SMAP backbone).
+Wrap in `rocprofv3 --pmc ...` for counters (use --iters 3)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from smap_amd import lib as L  # noqa: E402
+from smap_amd.engine import TILES  # noqa: E402
+
+PRESETS = {          # B, H, W, Cin, Cout, k, stride, tile, residual
+    "L1": (8, 128, 208, 64, 256, 1, 1, 0, 1),     # layer1 c3: HBM-bound, K=64
+    "L2": (8, 32, 52, 256, 256, 3, 1, 2, 0),      # layer3 3x3
+    "L3": (8, 128, 208, 256, 256, 1, 1, 0, 0),    # up4 lateral 1x1
+    "L4": (8, 32, 52, 256, 1024, 1, 1, 0, 1),     # layer3 c3
+    "L5": (8, 128, 208, 64, 64, 3, 1, 1, 0),      # layer1 3x3
+    "L6": (8, 16, 26, 512, 512, 3, 1, 2, 0),      # layer4 3x3
+    "L7": (8, 64, 104, 128, 512, 1, 1, 0, 1),     # layer2 c3
+    "L8": (8, 64, 104, 128, 128, 3, 1, 1, 0),     # layer2 3x3
+}
+
+
+def build(B, H, W, Cin, Cout, k, s, tile, res, dev):
+    lib = L.load()
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    bn = TILES[tile][1]
+    cout_pad = (Cout + bn - 1) // bn * bn
+    K = k * k * Cin
+    al = lambda n: (n + 255) // 256 * 256
+    x_b, o_b = al(B * H * W * Cin * 2), al(B * Ho * Wo * Cout * 2)
+    arena = (torch.randn((x_b + 2 * o_b) // 2 + 128, device=dev) * 0.5).half()
+    w_b = al(cout_pad * K * 2)
+    blob = torch.zeros(w_b + al(cout_pad * 4), dtype=torch.uint8, device=dev)
+    blob[:cout_pad * K * 2] = (torch.randn(cout_pad * K, device=dev) * K ** -0.5).half().view(torch.uint8)
+    op = L.SmapOp()
+    op.kind, op.B, op.H, op.W, op.Cin, op.in_stride_c, op.in_c_off = 0, B, H, W, Cin, Cin, 0
+    op.Ho, op.Wo, op.Cout, op.ksize, op.stride, op.pad, op.relu = Ho, Wo, Cout, k, s, pad, 1
+    op.cout_pad, op.out_stride_c, op.out_c_off, op.out_fp32, op.tile = cout_pad, Cout, 0, 0, tile
+    op.in_off, op.out_off, op.w_off, op.bias_off = 0, x_b + o_b, 0, w_b
+    op.res_off = x_b if res else -1
+    op.add1_off = op.add2_off = op.ext_off = -1
+    for i in range(3):
+        op.aux_off[i] = -1
+    h = C.c_void_p()
+    L.check(lib.smap_plan_create(C.byref(op), 1, C.byref(h)), "create")
+    flops = 2.0 * B * Ho * Wo * Cout * K
+    byts = B * H * W * Cin * 2 + B * Ho * Wo * Cout * 2 * (2 if res else 1) + cout_pad * K * 2
+    return lib, h, arena, blob, flops, byts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--tile-override", default="", help="e.g. L2:0,L6:5")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    ov = dict(kv.split(":") for kv in args.tile_override.split(",") if ":" in kv)
+    names = [n for n in PRESETS if not args.only or n in args.only.split(",")]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n in names:
+        p = list(PRESETS[n])
+        if n in ov:
+            p[7] = int(ov[n])
+        lib, h, arena, blob, flops, byts = build(*p, dev)
+        run = lambda: L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()),
+                                                None, st), "run")
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        print(f"{n} {tuple(p)} tile={TILES[p[7]]}#{p[7]}: {us:8.1f} us  {flops / us / 1e6:7.1f} TF/s  {byts / us / 1e3:7.0f} GB/s",
+              flush=True)
+        lib.smap_plan_destroy(h)
+
+
+if __name__ == "__main__":
+    main()
