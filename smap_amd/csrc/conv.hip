@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     static_assert(STAGES * STAGE <= 160 * 1024, "LDS is 160 KiB per CU");
     __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
 
     // ---- XCD-aware block order: blocks b, b+8, b+16.. run on one XCD; give each XCD a
     //      contiguous range of logical tiles so that the N-tiles of one M-tile (which
@@ -65,56 +66,71 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     const int m_tile = logical / a.n_tiles, n_tile = logical - m_tile * a.n_tiles;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
 
-    // ---- per-thread staging geometry
+    // ---- per-thread staging geometry.  Every global address of the K loop is
+    //      (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset in one VGPR): the A base is
+    //      the ARENA (whose first 256 bytes are zeros = the padding "zero page"), the B base the
+    //      weight matrix.  Per K tile only the uniform part moves, so the loop body carries no
+    //      per-lane address arithmetic; the per-lane offsets change once per (kh,kw) tap.
     const int lrow = lane >> 3, lslot = lane & 7;
     const int gch = lslot ^ (((wave & 1) << 2) | (lrow >> 1));   // K-granule this lane fetches
-    const _Float16* __restrict__ in = a.in;
-    const _Float16* __restrict__ wt = a.w;
+    const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
+    const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
     const int HoWo = a.Ho * a.Wo;
 
-    // per staged A row: element offset of tap (0,0) and a 9-bit mask of the taps that are in range
-    long long a_base[BM / 32];
-    unsigned a_mask[BM / 32];
+    unsigned a_off[BM / 32];     // byte offset (from the arena base) of tap (0,0), channel granule gch
+    unsigned a_mask[BM / 32];    // bit kh*ksize+kw set <=> that tap is inside the image (and m < M)
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) {
         const int m = m0 + i * 32 + wave * 8 + lrow;
-        a_base[i] = 0;
+        a_off[i] = 0;
         a_mask[i] = 0;
         if (m < a.M) {
             const int b = m / HoWo, rem = m - b * HoWo;
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
             const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            a_base[i] = ((long long)(b * a.H + iy0) * a.W + ix0) * a.in_stride_c + a.in_c_off + gch * 8;
-            for (int kh = 0; kh < a.ksize; ++kh)
+            const long long e = ((long long)(b * a.H + iy0) * a.W + ix0) * a.in_stride_c + a.in_c_off + gch * 8;
+            a_off[i] = (unsigned)(a.in_off + e * 2);           // wraps for taps above/left of the image; only
+            for (int kh = 0; kh < a.ksize; ++kh)               // used (mod 2^32) when the tap itself is valid
                 for (int kw = 0; kw < a.ksize; ++kw)
                     if ((unsigned)(iy0 + kh) < (unsigned)a.H && (unsigned)(ix0 + kw) < (unsigned)a.W)
                         a_mask[i] |= 1u << (kh * a.ksize + kw);
         }
     }
-    long long w_base[BN / 32];
+    unsigned b_off[BN / 32];
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i)
-        w_base[i] = (long long)(n0 + i * 32 + wave * 8 + lrow) * a.K + gch * 8;
+        b_off[i] = (unsigned)(((n0 + i * 32 + wave * 8 + lrow) * a.K + gch * 8) * 2);
 
     const int cchunks = a.Cin / BK;
     const int n_iter = a.ksize * a.ksize * cchunks;
 
-    auto stage = [&](int it, int buf) {
-        const int kpos = it / cchunks, c0 = (it - kpos * cchunks) * BK;
-        const int kh = kpos / a.ksize, kw = kpos - kh * a.ksize;
-        const long long koff = (long long)(kh * a.W + kw) * a.in_stride_c + c0;
+    // staging cursor (all wave-uniform -> SGPRs): tap (s_kh, s_kw), channel chunk s_cc
+    int s_kh = 0, s_kw = 0, s_cc = 0;
+    unsigned s_boff = 0;                                       // bytes into a weight row: it * 128
+    unsigned a_cur[BM / 32];                                   // per-lane offsets of the current tap (0 = zero page)
+    auto set_tap = [&]() {
+        const unsigned tap_off = (unsigned)((s_kh * a.W + s_kw) * a.in_stride_c * 2);
+        const unsigned bit = 1u << (s_kh * a.ksize + s_kw);
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) a_cur[i] = (a_mask[i] & bit) ? a_off[i] + tap_off : 0u;
+    };
+    set_tap();
+    auto stage = [&](int buf) {
         char* sA = smem + buf * STAGE;
         char* sB = sA + BM * ROWB;
+        const char* gA = arena + (unsigned)(s_cc * (BK * 2));
+        const char* gB = wt + s_boff;
 #pragma unroll
-        for (int i = 0; i < BM / 32; ++i) {
-            const bool ok = (a_mask[i] >> kpos) & 1u;
-            const _Float16* src = ok ? in + a_base[i] + koff : a.zero;
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sA + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
-        }
+        for (int i = 0; i < BM / 32; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) {
-            const _Float16* src = wt + w_base[i] + (long long)it * BK;
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sB + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+        for (int i = 0; i < BN / 32; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+        s_boff += BK * 2;
+        if (++s_cc == cchunks) {
+            s_cc = 0;
+            if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; }
+            set_tap();                 // past the last tap the mask bit is 0 -> offsets 0, never issued anyway
         }
     };
 
@@ -139,14 +155,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     //      whose ds_reads were consumed by MFMAs that precede the barrier in program order.
 #pragma unroll
     for (int st = 0; st < STAGES - 1; ++st)
-        if (st < n_iter) stage(st, st);
+        if (st < n_iter) stage(st);
     int buf = 0, nbuf = STAGES - 1;
     for (int it = 0; it < n_iter; ++it) {
         if (it + STAGES - 1 <= n_iter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + STAGES - 1 < n_iter) stage(it + STAGES - 1, nbuf);
+        if (it + STAGES - 1 < n_iter) stage(nbuf);
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + BM * ROWB;
 #pragma unroll

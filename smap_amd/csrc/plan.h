@@ -4,14 +4,14 @@
 #include <stdint.h>
 
 struct ConvArgs {
-    const _Float16* in;      // NHWC fp16, channel stride in_stride_c, first channel in_c_off
+    const void* arena;       // activation arena base; its first 256 bytes are zeros (padding taps read them)
+    long long in_off;        // byte offset of the NHWC fp16 input (channel stride in_stride_c, first channel in_c_off)
     const _Float16* w;       // [cout_pad][K] fp16
     const float* bias;       // [cout_pad] fp32
     void* out;               // fp16 or fp32 NHWC, channel stride out_stride_c, offset out_c_off
     const _Float16* res;     // dense [M][Cout8] added before ReLU, or null
     const _Float16* add1;    // dense [M][Cout8] added after ReLU, or null
     const _Float16* add2;
-    const _Float16* zero;    // >= 16 bytes of zeros, 16-B aligned
     int H, W, Cin, in_stride_c, in_c_off;
     int Ho, Wo, Cout8;       // Cout rounded up to 8 (channels actually written)
     int ksize, stride, pad, relu;

@@ -222,8 +222,11 @@ inline int grid_for(long long total, int block)
 
 struct smap_plan {
     std::vector<smap_op> ops;
-    _Float16* zero = nullptr;   // 256 zero bytes for padded conv taps
 };
+
+// The first SMAP_ZERO_PAGE bytes of the arena are the conv kernels' "zero page": padding taps and
+// rows past M fetch their 16 bytes there.  smap_plan_run clears it on the stream before the first op.
+constexpr int64_t SMAP_ZERO_PAGE = 256;
 
 static int validate(const smap_op& o)
 {
@@ -237,7 +240,10 @@ static int validate(const smap_op& o)
             if (o.in_stride_c % 8 || o.in_c_off % 8 || o.out_stride_c % 8 || o.out_c_off % 8) return SMAP_E_ARG;
             if (o.out_stride_c < ((o.Cout + 7) & ~7)) return SMAP_E_ARG;
             if ((o.res_off >= 0 || o.add1_off >= 0 || o.add2_off >= 0) && o.Cout % 8) return SMAP_E_ARG;
-            if (o.in_off < 0 || o.out_off < 0 || o.w_off < 0 || o.bias_off < 0) return SMAP_E_ARG;
+            if (o.in_off < SMAP_ZERO_PAGE || o.out_off < SMAP_ZERO_PAGE || o.w_off < 0 || o.bias_off < 0) return SMAP_E_ARG;
+            // conv A-operand addresses are 32-bit byte offsets from the arena base
+            if (o.in_off + (int64_t)o.B * o.H * o.W * o.in_stride_c * 2 > ((int64_t)1 << 32)) return SMAP_E_ARG;
+            if ((int64_t)o.cout_pad * o.ksize * o.ksize * o.Cin * 2 > ((int64_t)1 << 32)) return SMAP_E_ARG;
             if (o.Ho != (o.H + 2 * o.pad - o.ksize) / o.stride + 1) return SMAP_E_ARG;
             if (o.Wo != (o.W + 2 * o.pad - o.ksize) / o.stride + 1) return SMAP_E_ARG;
             return 0;
@@ -273,11 +279,6 @@ int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan)
     smap_plan* p = new (std::nothrow) smap_plan();
     if (!p) return SMAP_E_ARG;
     p->ops.assign(ops, ops + n_ops);
-    void* z = nullptr;
-    hipError_t e = hipMalloc(&z, 256);
-    if (e == hipSuccess) e = hipMemset(z, 0, 256);
-    if (e != hipSuccess) { delete p; return hip_rc(e); }
-    p->zero = static_cast<_Float16*>(z);
     *plan = p;
     return 0;
 }
@@ -285,7 +286,6 @@ int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan)
 void smap_plan_destroy(smap_plan* plan)
 {
     if (!plan) return;
-    if (plan->zero) (void)hipFree(plan->zero);
     delete plan;
 }
 
@@ -298,20 +298,21 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
     char* ar = static_cast<char*>(arena);
     const char* wb = static_cast<const char*>(weights);
     auto A = [&](int64_t off) -> _Float16* { return off < 0 ? nullptr : reinterpret_cast<_Float16*>(ar + off); };
+    if (hipError_t e = hipMemsetAsync(ar, 0, SMAP_ZERO_PAGE, st); e != hipSuccess) return hip_rc(e);
     for (int i = first; i < first + count; ++i) {
         const smap_op& o = plan->ops[i];
         hipError_t e = hipSuccess;
         switch (o.kind) {
             case SMAP_OP_CONV: {
                 ConvArgs a;
-                a.in = A(o.in_off);
+                a.arena = ar;
+                a.in_off = o.in_off;
                 a.w = reinterpret_cast<const _Float16*>(wb + o.w_off);
                 a.bias = reinterpret_cast<const float*>(wb + o.bias_off);
                 a.out = ar + o.out_off;
                 a.res = A(o.res_off);
                 a.add1 = A(o.add1_off);
                 a.add2 = A(o.add2_off);
-                a.zero = plan->zero;
                 a.H = o.H; a.W = o.W; a.Cin = o.Cin; a.in_stride_c = o.in_stride_c; a.in_c_off = o.in_c_off;
                 a.Ho = o.Ho; a.Wo = o.Wo; a.Cout8 = (o.Cout + 7) & ~7;
                 a.ksize = o.ksize; a.stride = o.stride; a.pad = o.pad; a.relu = o.relu;

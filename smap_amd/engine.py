@@ -266,7 +266,7 @@ class Graph:
             if op.out is not None:
                 op.out.first = i
                 op.out.last = max(op.out.last, i)
-        free, top = [], 0            # free: list of (off, size)
+        free, top = [], ALIGN        # free: list of (off, size); arena[0:256] is the conv zero page
         by_first = {}
         for t in self.tensors:
             by_first.setdefault(t.first, []).append(t)
