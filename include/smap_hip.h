@@ -119,9 +119,9 @@ int smap_sizeof_op(void);
 
 typedef struct smap_plan smap_plan;
 
-/* Copies `ops`; validates geometry.  n_ops <= 4096.  Arena contract: bytes [0,256) are reserved
+/* Copies `ops`; validates geometry.  n_ops <= 4096.  Arena contract: bytes [0,8192) are reserved
  * (smap_plan_run zeroes them: padding taps of the conv kernels read there), every tensor offset is
- * >= 256, and conv inputs must end below 4 GiB (32-bit offsets from the arena base). */
+ * >= 8192, and conv inputs must end below 4 GiB (32-bit offsets from the arena base). */
 int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan);
 void smap_plan_destroy(smap_plan* plan);
 /* Runs the whole schedule on `stream`.

@@ -34,6 +34,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+#ifndef SMAP_ABLATE
+#define SMAP_ABLATE 0            // experiments only (tools/build_ablate.py): 1 no loads, 2 no MFMA, 4 no stores, 8 no epilogue
+#endif
 constexpr int BK = 64;            // halves per K chunk
 constexpr int ROWB = BK * 2;      // bytes per LDS row
 
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     auto stage = [&](int buf) {
         char* sA = smem + buf * STAGE;
         char* sB = sA + BM * ROWB;
-        const char* gA = arena + (unsigned)(s_cc * (BK * 2));
+        const char* gA = arena + (unsigned)(s_cc * (BK * 2));      // invalid taps: a_cur = 0 -> zero page + s_cc*128
         const char* gB = wt + s_boff;
 #pragma unroll
         for (int i = 0; i < BM / 32; ++i)
@@ -133,6 +136,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
             set_tap();                 // past the last tap the mask bit is 0 -> offsets 0, never issued anyway
         }
     };
+
+    // ---- residual prefetch: the epilogue's residual tile (8 channels x PASSES pixels per thread) is
+    //      requested before the K loop so that its HBM latency hides under the whole main loop
+    //      (a pass-by-pass load in the epilogue exposes one full memory round trip per pass).
+    constexpr int CG = BN / 8;                    // channel groups per row
+    constexpr int PASSES = BM * CG / 256;
+    static_assert(BM * CG % 256 == 0, "tile/thread mismatch");
+    half8 rres[PASSES];
+    if (a.res) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int idx = p * 256 + tid;
+            const int row = idx / CG, cg = idx - row * CG;
+            const int m = m0 + row, n = n0 + cg * 8;
+            const long long dense = (m < a.M && n < a.Cout8) ? (long long)m * a.Cout8 + n : 0;
+            rres[p] = *reinterpret_cast<const half8*>(a.res + dense);
+        }
+    }
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -155,18 +176,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     //      whose ds_reads were consumed by MFMAs that precede the barrier in program order.
 #pragma unroll
     for (int st = 0; st < STAGES - 1; ++st)
-        if (st < n_iter) stage(st);
+        if (st < n_iter && !(SMAP_ABLATE & 1)) stage(st);
     int buf = 0, nbuf = STAGES - 1;
     for (int it = 0; it < n_iter; ++it) {
         if (it + STAGES - 1 <= n_iter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + STAGES - 1 < n_iter) stage(nbuf);
+        if (it + STAGES - 1 < n_iter && !(SMAP_ABLATE & 1)) stage(nbuf);
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + BM * ROWB;
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
+        for (int kk = 0; kk < ((SMAP_ABLATE & 2) ? 0 : BK / 16); ++kk) {
             const int slot = ((kk * 2 + lhi) ^ rswz) * 16;
             half8 af[MI], bf[NI];
 #pragma unroll
@@ -185,6 +206,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
     }
     __syncthreads();   // everyone is done reading the staging buffers
+    if (SMAP_ABLATE & 8) {
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(a.out)[tid] = acc[0][0][1];   // keep acc live
+        return;
+    }
 
     // ---- epilogue 1: acc + bias -> fp32 [BM][BN] tile in LDS
     float* Cs = reinterpret_cast<float*>(smem);
@@ -203,15 +228,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     __syncthreads();
 
     // ---- epilogue 2: 8 consecutive channels of one pixel per thread
-    constexpr int CG = BN / 8;                    // channel groups per row
-    constexpr int PASSES = BM * CG / 256;
-    static_assert(BM * CG % 256 == 0, "tile/thread mismatch");
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int idx = p * 256 + tid;
         const int row = idx / CG, cg = idx - row * CG;
         const int m = m0 + row, n = n0 + cg * 8;
         if (m >= a.M || n >= a.Cout8) continue;
+        if ((SMAP_ABLATE & 4) && a.M != 7) continue;
         float v[8];
         {
             const float4 lo = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
@@ -221,9 +244,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         }
         const long long dense = (long long)m * a.Cout8 + n;      // res/add tensors are dense [M][Cout8]
         if (a.res) {
-            const half8 r = *reinterpret_cast<const half8*>(a.res + dense);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+            for (int e = 0; e < 8; ++e) v[e] += (float)rres[p][e];
         }
         if (a.relu) {
 #pragma unroll

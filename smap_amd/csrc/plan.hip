@@ -226,7 +226,7 @@ struct smap_plan {
 
 // The first SMAP_ZERO_PAGE bytes of the arena are the conv kernels' "zero page": padding taps and
 // rows past M fetch their 16 bytes there.  smap_plan_run clears it on the stream before the first op.
-constexpr int64_t SMAP_ZERO_PAGE = 256;
+constexpr int64_t SMAP_ZERO_PAGE = 8192;   // >= max Cin * 2 bytes + 16: a padding tap reads zero page + chunk*128
 
 static int validate(const smap_op& o)
 {
@@ -235,7 +235,7 @@ static int validate(const smap_op& o)
         case SMAP_OP_CONV: {
             int bm, bn;
             if (smap_conv_tile_dims(o.tile, &bm, &bn)) return SMAP_E_ARG;
-            if (o.Cin % 64 || o.cout_pad % bn || o.cout_pad < o.Cout) return SMAP_E_ARG;
+            if (o.Cin % 64 || o.Cin * 2 + 16 > SMAP_ZERO_PAGE || o.cout_pad % bn || o.cout_pad < o.Cout) return SMAP_E_ARG;
             if (o.ksize != 1 && o.ksize != 3) return SMAP_E_ARG;
             if (o.in_stride_c % 8 || o.in_c_off % 8 || o.out_stride_c % 8 || o.out_c_off % 8) return SMAP_E_ARG;
             if (o.out_stride_c < ((o.Cout + 7) & ~7)) return SMAP_E_ARG;

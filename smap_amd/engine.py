@@ -45,6 +45,7 @@ def _tile_remap():
 LAYERS = (3, 4, 6, 3)            # smap.py:299  resnet-50
 PLANES = (64, 128, 256, 512)
 ALIGN = 256
+ZERO_PAGE = 8192              # csrc/plan.hip SMAP_ZERO_PAGE
 
 
 def _rup(x, m):
@@ -266,7 +267,7 @@ class Graph:
             if op.out is not None:
                 op.out.first = i
                 op.out.last = max(op.out.last, i)
-        free, top = [], ALIGN        # free: list of (off, size); arena[0:256] is the conv zero page
+        free, top = [], ZERO_PAGE    # free: list of (off, size); arena[0:8192] is the conv kernels' zero page
         by_first = {}
         for t in self.tensors:
             by_first.setdefault(t.first, []).append(t)

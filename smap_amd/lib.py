@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libsmap_hip.so")
+SO_PATH = os.environ.get("SMAP_HIP_LIB") or os.path.join(HERE, "libsmap_hip.so")   # env override: kernel experiments only
 
 # every symbol include/smap_hip.h declares
 SYMBOLS = [

@@ -46,7 +46,7 @@ def _run_single_conv(B, H, W, Cin, Cout, k, stride, tile, relu, use_res, use_add
     blob = torch.zeros(w_bytes + al(bk.numel() * 4), dtype=torch.uint8)
     blob[:wk.numel() * 2] = wk.view(torch.uint8).reshape(-1)
     blob[w_bytes:w_bytes + bk.numel() * 4] = bk.view(torch.uint8).reshape(-1)
-    parts, offs, cur = [x, res, a1, a2], [], 256          # arena[0:256] = zero page
+    parts, offs, cur = [x, res, a1, a2], [], 8192         # arena[0:8192] = zero page
     for t in parts:
         offs.append(cur if t is not None else -1)
         cur += al(t.numel() * 2) if t is not None else 0

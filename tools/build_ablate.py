@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Build ablated copies of the library for bottleneck experiments (NOT shipped, NOT loaded by
+default): smap_amd/csrc/obj/libsmap_hip_abl<N>.so with -DSMAP_ABLATE=N, selected by
+SMAP_HIP_LIB=<path>.  N bits: 1 no K-loop loads, 2 no ds_read/MFMA, 4 no global stores, 8 no epilogue."""
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from smap_amd import build as B  # noqa: E402
+
+for n in [int(x) for x in sys.argv[1:]] or [1, 2, 8, 9, 10]:
+    objs = []
+    for src, extra in B.SOURCES:
+        op = os.path.join(B.OBJ, f"abl{n}_" + src.rsplit(".", 1)[0] + ".o")
+        subprocess.check_call([B._hipcc()] + B.COMMON + extra + [f"-DSMAP_ABLATE={n}", "-c", os.path.join(B.CSRC, src), "-o", op])
+        objs.append(op)
+    out = os.path.join(B.OBJ, f"libsmap_hip_abl{n}.so")
+    subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    print(out)
