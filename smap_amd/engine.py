@@ -95,7 +95,7 @@ class Op:
     p: dict = field(default_factory=dict)
 
 
-def pick_tile(M, cout):
+def pick_tile_heuristic(M, cout):
     """Largest tile that still gives >= 2 waves of workgroups on 256 CUs."""
     if cout <= 32:
         return 3
@@ -109,6 +109,22 @@ def pick_tile(M, cout):
         if blocks > best_blocks:
             best, best_blocks = t, blocks
     return best
+
+
+_TILE_TABLE = None
+
+
+def pick_tile(M, cout, key=None):
+    """Measured table (tools/autotune.py -> smap_amd/tile_table.json, keyed "B,H,W,Cin,Cout,k,s")
+    when the shape is in it, else the block-count heuristic."""
+    global _TILE_TABLE
+    if _TILE_TABLE is None:
+        import json
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json")
+        _TILE_TABLE = json.load(open(path)) if os.path.exists(path) and not os.environ.get("SMAP_NO_TILE_TABLE") else {}
+    if key is not None and key in _TILE_TABLE:
+        return int(_TILE_TABLE[key])
+    return pick_tile_heuristic(M, cout)
 
 
 DEFAULT_REMAP = {}
@@ -151,7 +167,7 @@ class Graph:
         Ho = (x.H + 2 * pad - ksize) // stride + 1
         Wo = (x.W + 2 * pad - ksize) // stride + 1
         M = self.B * Ho * Wo
-        tile = pick_tile(M, cout)
+        tile = pick_tile(M, cout, f"{self.B},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
         tile = {**DEFAULT_REMAP, **_tile_remap()}.get(tile, tile)
         bn = TILES[tile][1]
         cout_pad = _rup(cout, bn)

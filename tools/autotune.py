@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Pick the fastest conv tile variant per distinct layer shape of the SMAP schedule by measuring
+every candidate on the GPU (single-op plans through the C ABI), and write the table that
+smap_amd/engine.py::pick_tile consults:  smap_amd/tile_table.json  {"B,H,W,Cin,Cout,k,s": tile}.
+
+    python tools/autotune.py [--batch 8] [--iters 20]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402
+from smap_amd import lib as L  # noqa: E402
+from smap_amd.engine import Graph, OP_CONV, TILES  # noqa: E402
+from bench_conv import build  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--out", default=os.path.join(ROOT, "smap_amd", "tile_table.json"))
+    args = ap.parse_args()
+    from types import SimpleNamespace as NS
+    from smap_amd.model.smap import SMAP
+    cfg = NS(MODEL=NS(STAGE_NUM=3, UPSAMPLE_CHANNEL_NUM=256), DATASET=NS(KEYPOINT=NS(NUM=15), PAF=NS(NUM=14)),
+             OUTPUT_SHAPE=(128, 208), LOSS=NS(OHKM=True, TOPK=8, COARSE_TO_FINE=True))
+    torch.manual_seed(0)
+    g = Graph(SMAP(cfg).state_dict(), args.batch, 512, 832)
+    shapes = {}
+    for op in g.ops:
+        if op.kind != OP_CONV:
+            continue
+        p, x = op.p, op.inp
+        key = (args.batch, x.H, x.W, p["Cin"], p["Cout"], p["ksize"], p["stride"])
+        shapes.setdefault(key, [0, op.res is not None])
+        shapes[key][0] += 1
+    dev = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    table, total_best, total_default = {}, 0.0, 0.0
+    for key, (count, has_res) in sorted(shapes.items()):
+        B, H, W, Cin, Cout, k, s = key
+        cands = [t for t, (bm, bn) in TILES.items() if not (Cout <= 32 and bn > 32) and not (Cout <= 64 and bn > 64)]
+        if Cout > 64:
+            cands = [t for t in cands if TILES[t][1] >= 64]
+        res = {}
+        for t in cands:
+            lib, h, arena, blob, flops, byts = build(B, H, W, Cin, Cout, k, s, t, int(has_res), dev)
+            run = lambda: L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()),
+                                                    None, st), "run")
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            res[t] = e0.elapsed_time(e1) * 1e3 / args.iters
+            lib.smap_plan_destroy(h)
+            del arena, blob
+        best = min(res, key=res.get)
+        from smap_amd.engine import pick_tile_heuristic
+        dflt = pick_tile_heuristic(B * ((H + 2 * (k // 2) - k) // s + 1) * ((W + 2 * (k // 2) - k) // s + 1), Cout)
+        table[",".join(map(str, key))] = best
+        total_best += res[best] * count
+        total_default += res.get(dflt, res[best]) * count
+        print(key, "x%d" % count, {t: round(v, 1) for t, v in res.items()}, "best", best, "default", dflt, flush=True)
+    with open(args.out, "w") as f:
+        json.dump(table, f, indent=0, sort_keys=True)
+    print(f"sum best {total_best:.0f} us vs heuristic {total_default:.0f} us -> {args.out}")
+
+
+if __name__ == "__main__":
+    main()
