@@ -8,7 +8,8 @@ Same command line (test.py:156-177) and the same result JSON
            --batch_size 16 --do_flip 1 --dataset_path /path/to/images
 
 Per batch everything stays on the GPU: HIP backbone -> optional flip-TTA merge -> /255,/127 ->
-batched association -> batched lifting (-> RefineNet); only the poses come back.  Launched under
+batched association -> batched lifting (-> RefineNet); only the poses come back, and the
+post-processing of batch k overlaps the backbone of batch k+1 (smap_amd/pipeline.py).  Launched under
 `torch.distributed.run` the image list is split in contiguous per-rank blocks
 (lib/utils/dataloader.py:80-85) and the records are gathered with one RCCL all_gather.
 Only `run_inference` is implemented; `generate_result` / `generate_train` need the training
@@ -27,7 +28,8 @@ from model.refinenet import RefineNet
 from dataset.custom_dataset import CustomDataset
 from smap_amd.dist import gather_json, shard_range
 from exps.stage3_root2.config import cfg
-from exps.stage3_root2.test_util import default_cams, merge_flip, poses_from_outputs, save_result
+from smap_amd.pipeline import PosePipeline
+from exps.stage3_root2.test_util import default_cams, merge_flip
 
 
 def get_logger(name, log_dir, filename):
@@ -60,21 +62,31 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
             it = tqdm(data_loader)
         except ImportError:
             pass
+    pipe, flip_buf = None, None
+
+    def drain(recs):
+        if recs:
+            result["3d_pairs"].extend(recs)
+
+    def flip_merge(engine, imgs, slot):                          # test.py:55-70 on the backbone stream
+        nonlocal flip_buf
+        if flip_buf is None or flip_buf.numel() != slot.out.numel():
+            flip_buf = engine.new_output()
+        hms_flip, _, _ = engine.run(torch.flip(imgs, [-1]), out=flip_buf)
+        merge_flip(slot.hms, hms_flip, cfg)
+
     for batch in it:
         imgs, img_path, scales = batch
-        imgs = imgs.to(device)
+        imgs = imgs.to(device, non_blocking=True).float().contiguous()
+        if pipe is None or pipe.engine.B != len(imgs):           # (last) batch of a different size
+            if pipe is not None:
+                drain(pipe.flush())
+            pipe = PosePipeline(model, cfg, len(imgs), imgs.shape[-2], imgs.shape[-1], device, refine_w)
         with torch.no_grad():
-            outputs_2d, outputs_3d, outputs_rd = model(imgs)
-            if cfg.DO_FLIP:
-                outputs_2d_flip, _, _ = model(torch.flip(imgs, [-1]))
-                merge_flip(outputs_2d, outputs_2d_flip, cfg)
-            cams = default_cams(scales, len(imgs))
-            p2, p3, rz, counts = poses_from_outputs(outputs_2d, outputs_3d, outputs_rd, cams, cfg, refine_w)
-        for i in range(len(imgs)):
-            P = int(counts[i])
-            if P == 0:
-                continue                                                        # test.py:131-132
-            save_result(p2[i, :P], p3[i, :P], None, rz[i, :P], img_path[i], result)
+            drain(pipe.submit(imgs, default_cams(scales, len(imgs)), list(img_path),
+                              flip_merge=flip_merge if cfg.DO_FLIP else None))
+    if pipe is not None:
+        drain(pipe.flush())
     if dist.is_initialized() and dist.get_world_size() > 1:
         parts = gather_json(result["3d_pairs"], device)
         result["3d_pairs"] = [r for part in parts for r in part]                # rank order == frame order

@@ -396,16 +396,25 @@ class BackboneEngine:
         self.n_ops = len(g.ops)
         self.weights = g.weight_blob().to(self.device)
         self.arena = torch.zeros((g.arena_bytes,), dtype=torch.uint8, device=self.device)
-        self.out = torch.zeros((g.out_bytes // 4,), dtype=torch.float32, device=self.device)
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
             _L.check(self.lib.smap_plan_create(self.ops, self.n_ops, C.byref(handle)), "smap_plan_create")
         self.handle = handle
-        n = B * self.h * self.w
-        self.hms = self.out[:n * kpt_paf].view(B, kpt_paf, self.h, self.w)
-        self.det_d = self.out[n * kpt_paf:n * (kpt_paf + paf)].view(B, paf, self.h, self.w)
-        self.root_d = self.out[n * (kpt_paf + paf):].view(B, 1, self.h, self.w)
+        self.kpt_paf, self.paf = kpt_paf, paf
+        self.out_floats = g.out_bytes // 4
+        self.out = self.new_output()                      # default output buffer
+        self.hms, self.det_d, self.root_d = self.views(self.out)
         self.flops_per_batch = g.flops
+
+    def new_output(self):
+        """A fresh fp32 output buffer (hms | det_d | root_d); pass it to run(out=...) to double-buffer."""
+        return torch.zeros((self.out_floats,), dtype=torch.float32, device=self.device)
+
+    def views(self, out):
+        B, n = self.B, self.B * self.h * self.w
+        k, p = self.kpt_paf, self.paf
+        return (out[:n * k].view(B, k, self.h, self.w), out[n * k:n * (k + p)].view(B, p, self.h, self.w),
+                out[n * (k + p):].view(B, 1, self.h, self.w))
 
     def __del__(self):
         try:
@@ -415,9 +424,9 @@ class BackboneEngine:
         except Exception:
             pass
 
-    def run(self, imgs, first=0, count=None):
-        """imgs: [B,3,H,W] fp32 contiguous on the device.  Returns (hms, det_d, root_d) views
-        of the engine's output buffer (overwritten by the next run)."""
+    def run(self, imgs, first=0, count=None, out=None):
+        """imgs: [B,3,H,W] fp32 contiguous on the device.  Returns (hms, det_d, root_d) views of the
+        output buffer `out` (default: the engine's own, overwritten by the next run)."""
         if tuple(imgs.shape) != (self.B, 3, self.H, self.W) or imgs.dtype != torch.float32 or not imgs.is_cuda:
             raise ValueError(f"imgs must be a float32 GPU tensor [{self.B},3,{self.H},{self.W}], got "
                              f"{tuple(imgs.shape)} {imgs.dtype} {imgs.device}")
@@ -427,8 +436,9 @@ class BackboneEngine:
         with torch.cuda.device(self.device):
             _L.check(self.lib.smap_plan_run_range(self.handle, first, count, C.c_void_p(imgs.data_ptr()),
                                                   C.c_void_p(self.arena.data_ptr()), C.c_void_p(self.weights.data_ptr()),
-                                                  C.c_void_p(self.out.data_ptr()), st), "smap_plan_run")
-        return self.hms, self.det_d, self.root_d
+                                                  C.c_void_p((self.out if out is None else out).data_ptr()), st),
+                     "smap_plan_run")
+        return (self.hms, self.det_d, self.root_d) if out is None else self.views(out)
 
     def read_tensor(self, name):
         """Debug/test helper: NHWC activation `name` from the arena (valid with reuse=False)."""

@@ -1,0 +1,124 @@
+"""Two-stream inference pipeline for the SMAP hot path on one GPU.
+
+The reference's loop (exps/stage3_root2/test.py:43-145) is strictly serial per frame: forward,
+`.cpu()` syncs, one `dapalib.connect` per frame, numpy lifting.  Here a batch flows through two
+HIP streams so that the device never waits for the host:
+
+    stream "bb"   : SMAP backbone of batch k+1                      (smap_plan_run)
+    stream "post" : /255,/127 -> nms -> paf -> group -> lift [-> RefineNet] -> async D2H of batch k
+    host          : builds the `3d_pairs` records of batch k from pinned memory meanwhile
+
+Double-buffered network outputs and pinned result buffers make batch k's post-processing
+independent of batch k+1's forward.  `submit()` returns the records of the PREVIOUS batch
+(None for the first call); `flush()` returns the last one.
+"""
+import numpy as np
+import torch
+
+from . import dapalib
+
+NJ, MAXP = 15, 127
+
+
+class _Slot:
+    def __init__(self, engine, device, n_extra):
+        self.out = engine.new_output()
+        self.hms, self.det_d, self.root_d = engine.views(self.out)
+        B = engine.B
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
+        self.host = [dict(p2=mk((B, MAXP, NJ, 4), torch.float32), p3=mk((B, MAXP, NJ, 4), torch.float64),
+                          rz=mk((B, MAXP), torch.float64), counts=mk((B,), torch.int32))
+                     for _ in range(1 + n_extra)]
+        self.ev_bb = torch.cuda.Event()
+        self.ev_post = torch.cuda.Event()
+        self.meta = None
+        self.busy = False
+
+
+class PosePipeline:
+    def __init__(self, model, cfg, batch, H, W, device, refine_weights=None, n_extra=0):
+        self.device = torch.device(device)
+        self.cfg = cfg
+        self.engine = model.engine(batch, H, W, self.device)
+        self.refine = refine_weights
+        self.s_bb = torch.cuda.Stream(self.device)
+        self.s_post = torch.cuda.Stream(self.device)
+        self.s_comm = torch.cuda.Stream(self.device)      # result gather (RCCL) never queues behind compute
+        self.slots = [_Slot(self.engine, self.device, n_extra) for _ in range(2)]
+        self.k = 0
+        self.bb_events = []              # (start, end) HIP events of timed backbone runs
+
+    # -- device side -------------------------------------------------------------------------
+    def _post(self, slot, idx, hms, det_d, root_d, cams, scale):
+        """Association + lifting of one set of maps on the post stream; results -> pinned memory."""
+        if scale:
+            dapalib.scale_hms_(hms)                                             # test.py:111-112
+        bodys, counts = dapalib.connect_batch(hms, root_d, self.cfg.DATASET.ROOT_IDX, True)
+        p2, p3, rz = dapalib.lift_batch(bodys, counts, det_d, root_d, cams)
+        if self.refine is not None:
+            p3 = dapalib.refine_batch(p2, p3, counts, *self.refine)
+        h = slot.host[idx]
+        for k, t in (("p2", p2), ("p3", p3), ("rz", rz), ("counts", counts)):
+            h[k].copy_(t, non_blocking=True)
+
+    def submit(self, imgs, cams, tags, extra=(), flip_merge=None, time_backbone=False):
+        """imgs [B,3,H,W] fp32 on the device; cams [B,9] float64 (host array); tags: B image names.
+        extra: tuples (tag_prefix, hms, root_d, det_d) of already-scaled maps to associate as well
+        (bench only).  Returns the record list of the previous batch or None."""
+        slot = self.slots[self.k & 1]
+        prev = self.slots[(self.k - 1) & 1] if self.k > 0 else None
+        if slot.busy:                                  # its previous results were not collected: collect now
+            raise RuntimeError("pipeline slot still in flight; call collect order submit -> result")
+        cams_d = torch.as_tensor(np.asarray(cams), dtype=torch.float64).to(self.device, non_blocking=True)
+        cur = torch.cuda.current_stream(self.device)
+        self.s_bb.wait_stream(cur)                     # imgs were produced on the caller's stream
+        self.s_post.wait_stream(cur)
+        imgs.record_stream(self.s_bb)
+        cams_d.record_stream(self.s_post)
+        with torch.cuda.stream(self.s_bb):
+            if time_backbone:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self.engine.run(imgs, out=slot.out)
+            if flip_merge is not None:                 # test.py:55-70: second forward + channel-permuted merge
+                flip_merge(self.engine, imgs, slot)
+            if time_backbone:
+                e1.record()
+                self.bb_events.append((e0, e1))
+            slot.ev_bb.record()
+        with torch.cuda.stream(self.s_post):
+            self.s_post.wait_event(slot.ev_bb)
+            self._post(slot, 0, slot.hms, slot.det_d, slot.root_d, cams_d, scale=True)
+            for j, (tag, hms, rd, dd) in enumerate(extra):
+                self._post(slot, 1 + j, hms, slot.det_d if dd is None else dd, rd, cams_d, scale=False)
+            slot.ev_post.record()
+        slot.meta = (list(tags), [t for t, *_ in extra])
+        slot.busy = True
+        self.k += 1
+        return self._collect(prev) if prev is not None else None
+
+    def flush(self):
+        out = None
+        for s in (self.slots[self.k & 1], self.slots[(self.k - 1) & 1]):
+            if s.busy:
+                r = self._collect(s)
+                out = r if out is None else out + r
+        return out
+
+    # -- host side ---------------------------------------------------------------------------
+    def _collect(self, slot):
+        slot.ev_post.synchronize()
+        tags, extra_tags = slot.meta
+        recs = []
+        for idx, h in enumerate(slot.host):
+            counts = h["counts"].numpy()
+            p2, p3, rz = h["p2"].numpy(), h["p3"].numpy(), h["rz"].numpy()
+            for i, P in enumerate(counts):
+                P = int(P)
+                if P == 0:
+                    continue                                                    # test.py:131-132
+                name = tags[i] if idx == 0 else f"{extra_tags[idx - 1]}/{tags[i]}"
+                recs.append({"pred_2d": p2[i, :P].tolist(), "pred_3d": p3[i, :P].tolist(),
+                             "root_d": rz[i, :P].tolist(), "image_path": name, "gt_3d": [], "gt_2d": []})
+        slot.busy = False
+        return recs

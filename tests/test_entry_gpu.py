@@ -87,3 +87,43 @@ def test_run_inference_cli_end_to_end(tmp_path):
         assert got["image_path"] == want["image_path"]
         assert got["pred_2d"] == want["pred_2d"] and got["root_d"] == want["root_d"]       # bit-exact
         assert np.abs(np.asarray(got["pred_3d"]) - np.asarray(want["pred_3d"])).max() < 1e-3 * 100   # 1e-3 m in cm
+
+
+def test_two_stream_pipeline_equals_serial_path():
+    """smap_amd/pipeline.py (post-processing of batch k overlapped with the backbone of batch k+1,
+    double-buffered outputs, pinned D2H) returns exactly what the serial calls return."""
+    from model.smap import SMAP
+    from smap_amd.pipeline import PosePipeline
+    from exps.stage3_root2.config import cfg
+    from exps.stage3_root2.test_util import poses_from_outputs
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((16, 24))).eval()
+    sd = recipe_state_dict(net.state_dict())
+    for k in list(sd):
+        if k.endswith("up4.res_conv2.bn.bias"):
+            sd[k] = sd[k] + 60.0
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    B = 2
+    g = torch.Generator().manual_seed(3)
+    batches = [torch.randn(B, 3, 64, 96, generator=g).to(dev) for _ in range(4)]
+    cams = np.tile(np.array([0.5, 192, 128, 96, 64, 192, 192, 96, 64], np.float64), (B, 1))
+    pipe = PosePipeline(net, cfg, B, 64, 96, dev)
+    got = []
+    for i, x in enumerate(batches):
+        r = pipe.submit(x, cams, [f"b{i}/{j}" for j in range(B)])
+        if r is not None:
+            got.append(r)
+    got.append(pipe.flush())
+    assert len(got) == len(batches)
+    n_people = 0
+    for i, x in enumerate(batches):
+        h, d, rd = net(x)
+        p2, p3, rz, counts = poses_from_outputs(h, d, rd, cams, cfg)
+        want = [(f"b{i}/{j}", p2[j, :c].tolist(), p3[j, :c].tolist(), rz[j, :c].tolist())
+                for j, c in enumerate(counts) if c > 0]
+        have = [(r["image_path"], r["pred_2d"], r["pred_3d"], r["root_d"]) for r in got[i]]
+        assert have == want
+        n_people += int(counts.sum())
+    assert n_people > 0
