@@ -192,6 +192,12 @@ def main():
         fps = frames / dt
         bb = float(np.mean(bb_ms)) * 1e-3
         achieved = ALG_GFLOP_PER_FRAME * B / bb / 1e3            # TFLOP/s over the whole backbone schedule
+        traffic, traffic_src = None, None                        # HBM bytes per batch from committed PMC passes
+        tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tj) and B == 8:
+            t = json.load(open(tj))
+            traffic = t["hbm_read_bytes_per_batch"] + t["hbm_write_bytes_per_batch"]
+            traffic_src = t["source"]
         out = {
             "metric": "frames/sec at 3x512x832 (SMAP backbone + depth-aware association + 3D lifting)",
             "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -204,7 +210,7 @@ def main():
                                      "where the reference is); lifting f64",
                        "pipeline": "2 HIP streams: post-processing of batch k overlaps backbone of batch k+1"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "conv_igemm_kernel (all backbone launches, HIP-event bracket)",
                          "backbone_ms_per_batch": bb * 1e3,
                          "algorithmic_gflop_per_frame": ALG_GFLOP_PER_FRAME},
