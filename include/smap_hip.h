@@ -109,7 +109,9 @@ typedef struct smap_op {
                                        STEM: fp32 [147][64] + fp32 [64])                         */
     int64_t res_off;                /* dense [M][Cout] tensor added before ReLU, or -1           */
     int64_t add1_off, add2_off;     /* dense tensors added AFTER ReLU (smap.py:142-153), or -1   */
-    int64_t aux_off[3];             /* UPADD: aux[0] = low-res t ; HEADSUM: fp32 NHWC head tensors (arena) */
+    int64_t aux_off[3];             /* CONV: aux[0] = optional low-res fp16 [B,aux_h,aux_w,Cout] tensor, bilinearly
+                                       (align_corners) upsampled and added before ReLU (smap.py:213-217);
+                                       UPADD: aux[0] = low-res t ; HEADSUM: fp32 NHWC head tensors (arena) */
     int32_t aux_h[3], aux_w[3];     /* their spatial sizes                                       */
     int64_t ext_off;                /* HEADSUM: byte offset of the [B,Cout,Ho,Wo] block in the fp32 output buffer */
 } smap_op;

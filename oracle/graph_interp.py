@@ -45,6 +45,8 @@ def run_graph(g, imgs, quantize, keep=False):
             y = F.conv2d(x, w.to(dev), b.to(dev), stride=p["stride"], padding=p["pad"])
             if op.res is not None:
                 y = y + T[op.res.name]
+            if op.aux:                                   # fused relu(u_skip(x) + bilinear(up_conv@low))
+                y = y + up(T[op.aux[0].name], y.shape[-2:])
             if p["relu"]:
                 y = F.relu(y)
             if op.add1 is not None:

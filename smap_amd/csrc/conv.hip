@@ -247,6 +247,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)rres[p][e];
         }
+        if (a.up) {        // Upsample_unit: out = relu(u_skip(x) + up_conv(bilinear_up(prev))) (smap.py:213-217), the
+                           // 1x1 up_conv already applied at low resolution; here its bilinear resampling
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            const Lerp ly = lerp_index(oy, a.up_h, a.Ho), lx = lerp_index(ox, a.up_w, a.Wo);
+            const _Float16* tb = a.up + (long long)b * a.up_h * a.up_w * a.Cout8 + n;
+            const half8 v00 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i0) * a.Cout8);
+            const half8 v01 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i1) * a.Cout8);
+            const half8 v10 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i0) * a.Cout8);
+            const half8 v11 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i1) * a.Cout8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                v[e] += ly.l0 * (lx.l0 * (float)v00[e] + lx.l1 * (float)v01[e]) +
+                        ly.l1 * (lx.l0 * (float)v10[e] + lx.l1 * (float)v11[e]);
+        }
         if (a.relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;

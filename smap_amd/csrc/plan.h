@@ -12,12 +12,33 @@ struct ConvArgs {
     const _Float16* res;     // dense [M][Cout8] added before ReLU, or null
     const _Float16* add1;    // dense [M][Cout8] added after ReLU, or null
     const _Float16* add2;
+    const _Float16* up;      // optional low-res [B,up_h,up_w,Cout8] tensor: bilinear(align_corners) added before ReLU
+    int up_h, up_w;
     int H, W, Cin, in_stride_c, in_c_off;
     int Ho, Wo, Cout8;       // Cout rounded up to 8 (channels actually written)
     int ksize, stride, pad, relu;
     int out_stride_c, out_c_off, out_fp32;
     int M, K, m_tiles, n_tiles;
 };
+
+// ATen's index/weight rule for bilinear align_corners=True (UpSample.h compute_source_index_and_lambda):
+// identity when sizes match; else src = dst*(in-1)/(out-1) in fp32, i0 = (int)src, i1 = i0 + (i0 < in-1),
+// l1 = clamp(src - i0, 0, 1), l0 = 1 - l1.
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_index(int dst, int in_size, int out_size)
+{
+    Lerp r;
+    if (in_size == out_size) { r.i0 = dst; r.i1 = dst; r.l0 = 1.f; r.l1 = 0.f; return r; }
+    const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+    const float src = scale * (float)dst;
+    r.i0 = (int)src;
+    r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+    float l1 = src - (float)r.i0;
+    l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+    r.l1 = l1;
+    r.l0 = 1.f - l1;
+    return r;
+}
 
 int smap_conv_tile_dims(int tile, int* bm, int* bn);
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st);

@@ -120,25 +120,7 @@ __global__ void maxpool_kernel(const _Float16* __restrict__ in, _Float16* __rest
     }
 }
 
-// ------------------------------------------------- bilinear align-corners --
-// ATen's index/weight rule for align_corners=True (UpSample.h compute_source_index_and_lambda):
-// identity when sizes match; else src = dst*(in-1)/(out-1) in fp32, i0 = (int)src,
-// i1 = i0 + (i0 < in-1), l1 = clamp(src - i0, 0, 1), l0 = 1 - l1.
-struct Lerp { int i0, i1; float l0, l1; };
-__device__ __forceinline__ Lerp lerp_index(int dst, int in_size, int out_size)
-{
-    Lerp r;
-    if (in_size == out_size) { r.i0 = dst; r.i1 = dst; r.l0 = 1.f; r.l1 = 0.f; return r; }
-    const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
-    const float src = scale * (float)dst;
-    r.i0 = (int)src;
-    r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
-    float l1 = src - (float)r.i0;
-    l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
-    r.l1 = l1;
-    r.l0 = 1.f - l1;
-    return r;
-}
+// bilinear align-corners index rule: lerp_index() in plan.h (shared with the conv epilogue)
 
 // out = relu(a + up(t)); a/out [B,Ho,Wo,C] fp16, t [B,h,w,C] fp16; 8 channels per thread.
 __global__ void upadd_kernel(const _Float16* __restrict__ a, const _Float16* __restrict__ t,
@@ -239,7 +221,8 @@ static int validate(const smap_op& o)
             if (o.ksize != 1 && o.ksize != 3) return SMAP_E_ARG;
             if (o.in_stride_c % 8 || o.in_c_off % 8 || o.out_stride_c % 8 || o.out_c_off % 8) return SMAP_E_ARG;
             if (o.out_stride_c < ((o.Cout + 7) & ~7)) return SMAP_E_ARG;
-            if ((o.res_off >= 0 || o.add1_off >= 0 || o.add2_off >= 0) && o.Cout % 8) return SMAP_E_ARG;
+            if ((o.res_off >= 0 || o.add1_off >= 0 || o.add2_off >= 0 || o.aux_off[0] >= 0) && o.Cout % 8) return SMAP_E_ARG;
+            if (o.aux_off[0] >= 0 && (o.aux_h[0] <= 0 || o.aux_w[0] <= 0)) return SMAP_E_ARG;
             if (o.in_off < SMAP_ZERO_PAGE || o.out_off < SMAP_ZERO_PAGE || o.w_off < 0 || o.bias_off < 0) return SMAP_E_ARG;
             // conv A-operand addresses are 32-bit byte offsets from the arena base
             if (o.in_off + (int64_t)o.B * o.H * o.W * o.in_stride_c * 2 > ((int64_t)1 << 32)) return SMAP_E_ARG;
@@ -313,6 +296,9 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                 a.res = A(o.res_off);
                 a.add1 = A(o.add1_off);
                 a.add2 = A(o.add2_off);
+                a.up = A(o.aux_off[0]);
+                a.up_h = o.aux_h[0];
+                a.up_w = o.aux_w[0];
                 a.H = o.H; a.W = o.W; a.Cin = o.Cin; a.in_stride_c = o.in_stride_c; a.in_c_off = o.in_c_off;
                 a.Ho = o.Ho; a.Wo = o.Wo; a.Cout8 = (o.Cout + 7) & ~7;
                 a.ksize = o.ksize; a.stride = o.stride; a.pad = o.pad; a.relu = o.relu;

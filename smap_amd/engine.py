@@ -156,7 +156,7 @@ class Graph:
         return off
 
     def conv(self, name, prefixes, x, ksize=1, stride=1, relu=True, res=None, add1=None, add2=None,
-             in_c_off=0, cin=None, out_fp32=False):
+             in_c_off=0, cin=None, out_fp32=False, up=None):
         """One conv launch; `prefixes` (list) are concatenated along Cout (shared input)."""
         ws, bs = zip(*[fold_conv_bn(self.sd, p) for p in prefixes])
         w, b = torch.cat(ws, 0), torch.cat(bs, 0)
@@ -178,7 +178,7 @@ class Graph:
         bk[:cout] = b.to(torch.float32)
         out = self.tensor(name, Ho, Wo, _rup(cout, 8), 4 if out_fp32 else 2)
         self.flops += 2 * M * cout * K
-        self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, p=dict(
+        self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, aux=[up] if up is not None else [], p=dict(
             Cin=cin, in_c_off=in_c_off, Cout=cout, ksize=ksize, stride=stride, pad=pad, relu=int(relu),
             cout_pad=cout_pad, tile=tile, out_fp32=int(out_fp32), w_off=self._add_w(wk), bias_off=self._add_w(bk),
             w_ref=w if self.keep_ref else None, b_ref=b if self.keep_ref else None)))
@@ -235,11 +235,14 @@ class Graph:
             if ind == 0:
                 out = self.conv(u + ".out", [u + ".u_skip"], xin, relu=True)
             else:
-                a = self.conv(u + ".u_skip", [u + ".u_skip"], xin, relu=False)
                 tl = self.conv(u + ".up_conv@low", [u + ".up_conv"], out, relu=False)   # commuted with the upsample
-                o = self.tensor(u + ".out", a.H, a.W, a.C)
-                self.ops.append(Op(OP_UPADD, out=o, inp=a, aux=[tl], p=dict(relu=1)))
-                out = o
+                if os.environ.get("SMAP_NO_UPADD_FUSION"):
+                    a = self.conv(u + ".u_skip", [u + ".u_skip"], xin, relu=False)
+                    o = self.tensor(u + ".out", a.H, a.W, a.C)
+                    self.ops.append(Op(OP_UPADD, out=o, inp=a, aux=[tl], p=dict(relu=1)))
+                    out = o
+                else:       # relu(u_skip(x) + bilinear(tl)) in the u_skip conv's epilogue
+                    out = self.conv(u + ".out", [u + ".u_skip"], xin, relu=True, up=tl)
             if gen_skip:
                 lvl = 3 - ind                      # skip lists are fine -> coarse (smap.py:283-284)
                 s1[lvl] = self.conv(u + ".skip1", [u + ".skip1"], xin, relu=True)
@@ -345,6 +348,10 @@ class Graph:
                     if t is not None:
                         assert (t.H, t.W, t.C) == (y.H, y.W, y.C) and t.esize == 2, (y.name, nm)
                         setattr(o, nm + "_off", t.off)
+                if op.aux:
+                    t = op.aux[0]
+                    assert t.C == y.C and t.esize == 2
+                    o.aux_off[0], o.aux_h[0], o.aux_w[0] = t.off, t.H, t.W
             elif op.kind == OP_STEM:
                 y = op.out
                 o.H, o.W, o.Cin, o.Ho, o.Wo, o.Cout = self.H, self.W, 3, y.H, y.W, 64

@@ -22,7 +22,7 @@ def main():
              OUTPUT_SHAPE=(128, 208), LOSS=NS(OHKM=True, TOPK=8, COARSE_TO_FINE=True))
     torch.manual_seed(0)
     g = Graph(SMAP(cfg).state_dict(), B, 512, 832)
-    names = {OP_CONV: "conv_igemm", OP_STEM: "stem_kernel", OP_MAXPOOL: "maxpool", OP_UPADD: "upadd", OP_HEADSUM: "headsum"}
+    names = {OP_CONV: "conv_igemm", OP_STEM: "stem_kernel", OP_MAXPOOL: "maxpool", OP_UPADD: "upadd", OP_HEADSUM: "headsum"}   # set SMAP_NO_UPADD_FUSION=1 for pre-fusion traces
     con = sqlite3.connect(db)
     rows = con.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
     mine = [r for r in rows if any(k in r[0] for k in names.values())]
