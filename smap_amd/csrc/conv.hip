@@ -227,66 +227,84 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     }
     __syncthreads();
 
-    // ---- epilogue 2: 8 consecutive channels of one pixel per thread
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
+    // ---- epilogue 2: 8 consecutive channels of one pixel per thread.  Software-pipelined over the
+    //      passes: the global loads of pass p+1 (bilinear taps, post-ReLU addends) are issued before the
+    //      arithmetic + store of pass p, so one memory round trip is exposed per tile, not per pass.
+    struct Extra { half8 t00, t01, t10, t11, a1, a2; float ly0, ly1, lx0, lx1; bool ok; long long o; int row, cg; };
+    auto load_pass = [&](int p) -> Extra {
+        Extra x;
         const int idx = p * 256 + tid;
-        const int row = idx / CG, cg = idx - row * CG;
-        const int m = m0 + row, n = n0 + cg * 8;
-        if (m >= a.M || n >= a.Cout8) continue;
-        if ((SMAP_ABLATE & 4) && a.M != 7) continue;
+        x.row = idx / CG;
+        x.cg = idx - x.row * CG;
+        const int m = m0 + x.row, n = n0 + x.cg * 8;
+        x.ok = m < a.M && n < a.Cout8 && !((SMAP_ABLATE & 4) && a.M != 7);
+        const int ms = x.ok ? m : 0, ns = x.ok ? n : 0;            // clamped: loads stay in bounds
+        const long long dense = (long long)ms * a.Cout8 + ns;     // res/add tensors are dense [M][Cout8]
+        x.o = (long long)ms * a.out_stride_c + a.out_c_off + ns;
+        if (a.up) {
+            const int b = ms / HoWo, rem = ms - b * HoWo;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            const Lerp ly = lerp_index(oy, a.up_h, a.Ho), lx = lerp_index(ox, a.up_w, a.Wo);
+            const _Float16* tb = a.up + (long long)b * a.up_h * a.up_w * a.Cout8 + ns;
+            x.t00 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i0) * a.Cout8);
+            x.t01 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i1) * a.Cout8);
+            x.t10 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i0) * a.Cout8);
+            x.t11 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i1) * a.Cout8);
+            x.ly0 = ly.l0; x.ly1 = ly.l1; x.lx0 = lx.l0; x.lx1 = lx.l1;
+        }
+        if (a.add1) x.a1 = *reinterpret_cast<const half8*>(a.add1 + dense);
+        if (a.add2) x.a2 = *reinterpret_cast<const half8*>(a.add2 + dense);
+        return x;
+    };
+    auto finish_pass = [&](int p, const Extra& x) {
         float v[8];
         {
-            const float4 lo = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
-            const float4 hi = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
+            const float4 lo = *reinterpret_cast<const float4*>(Cs + x.row * BN + x.cg * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(Cs + x.row * BN + x.cg * 8 + 4);
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
             v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
         }
-        const long long dense = (long long)m * a.Cout8 + n;      // res/add tensors are dense [M][Cout8]
         if (a.res) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)rres[p][e];
         }
-        if (a.up) {        // Upsample_unit: out = relu(u_skip(x) + up_conv(bilinear_up(prev))) (smap.py:213-217), the
-                           // 1x1 up_conv already applied at low resolution; here its bilinear resampling
-            const int b = m / HoWo, rem = m - b * HoWo;
-            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            const Lerp ly = lerp_index(oy, a.up_h, a.Ho), lx = lerp_index(ox, a.up_w, a.Wo);
-            const _Float16* tb = a.up + (long long)b * a.up_h * a.up_w * a.Cout8 + n;
-            const half8 v00 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i0) * a.Cout8);
-            const half8 v01 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i1) * a.Cout8);
-            const half8 v10 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i0) * a.Cout8);
-            const half8 v11 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i1) * a.Cout8);
+        if (a.up) {        // Upsample_unit: out = relu(u_skip(x) + up_conv(bilinear_up(prev))) (smap.py:213-217); the
+                           // 1x1 up_conv was applied at low resolution, this is its bilinear resampling
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                v[e] += ly.l0 * (lx.l0 * (float)v00[e] + lx.l1 * (float)v01[e]) +
-                        ly.l1 * (lx.l0 * (float)v10[e] + lx.l1 * (float)v11[e]);
+                v[e] += x.ly0 * (x.lx0 * (float)x.t00[e] + x.lx1 * (float)x.t01[e]) +
+                        x.ly1 * (x.lx0 * (float)x.t10[e] + x.lx1 * (float)x.t11[e]);
         }
         if (a.relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
         if (a.add1) {
-            const half8 r = *reinterpret_cast<const half8*>(a.add1 + dense);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+            for (int e = 0; e < 8; ++e) v[e] += (float)x.a1[e];
         }
         if (a.add2) {
-            const half8 r = *reinterpret_cast<const half8*>(a.add2 + dense);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+            for (int e = 0; e < 8; ++e) v[e] += (float)x.a2[e];
         }
-        const long long o = (long long)m * a.out_stride_c + a.out_c_off + n;
+        if (!x.ok) return;
         if (a.out_fp32) {
-            float* op = reinterpret_cast<float*>(a.out) + o;
+            float* op = reinterpret_cast<float*>(a.out) + x.o;
             *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
             half8 h;
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
-            *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + o) = h;
+            *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + x.o) = h;
         }
+    };
+    Extra ex[2];
+    ex[0] = load_pass(0);
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        if (p + 1 < PASSES) ex[(p + 1) & 1] = load_pass(p + 1);
+        finish_pass(p, ex[p & 1]);
     }
 }
 
