@@ -106,7 +106,8 @@ typedef struct smap_op {
     int32_t n_aux;                  /* HEADSUM: number of source tensors (1..3)                  */
     int64_t in_off, out_off;        /* arena byte offsets                                        */
     int64_t w_off, bias_off;        /* weight-blob byte offsets (CONV: fp16 [cout_pad][K] + fp32 [cout_pad];
-                                       STEM: fp32 [147][64] + fp32 [64])                         */
+                                       STEM: fp16 [64][176] with K = (kh, c, kw padded to 8) + 8 zero
+                                       columns, + fp32 [64])                         */
     int64_t res_off;                /* dense [M][Cout] tensor added before ReLU, or -1           */
     int64_t add1_off, add2_off;     /* dense tensors added AFTER ReLU (smap.py:142-153), or -1   */
     int64_t aux_off[3];             /* CONV: aux[0] = optional low-res fp16 [B,aux_h,aux_w,Cout] tensor, bilinearly

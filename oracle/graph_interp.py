@@ -28,7 +28,10 @@ def run_graph(g, imgs, quantize, keep=False):
         p = op.p
         if op.kind == OP_STEM:
             w, b = p["w_ref"].float().to(dev), p["b_ref"].float().to(dev)
-            y = F.relu(F.conv2d(imgs.float(), w, b, stride=2, padding=3))
+            x0 = imgs.float()
+            if quantize:                                 # the stem kernel rounds image and weights to fp16
+                x0, w = _q(x0, True), _q(w, True)
+            y = F.relu(F.conv2d(x0, w, b, stride=2, padding=3))
             T[op.out.name] = _q(y, quantize)
         elif op.kind == OP_MAXPOOL:
             T[op.out.name] = F.max_pool2d(T[op.inp.name], 3, 2, 1)

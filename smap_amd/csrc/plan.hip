@@ -21,67 +21,98 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -(1000 + (int)e); }
 
 // ------------------------------------------------------------------ stem --
-// fp32 NCHW image -> NHWC fp16 [B,Ho,Wo,64].  One 16x16 output tile per workgroup,
-// one output pixel (all 64 channels, fp32 accumulators) per thread.  The 37x37x3
-// input patch and the folded [147][64] fp32 weights live in LDS; weight reads are
-// wave-wide broadcasts.
-constexpr int ST_T = 16, ST_P = ST_T * 2 + 5;   // output tile edge, input patch edge
+// ResNet_top conv 7x7 s2 p3, 3 -> 64, + folded BN + ReLU, fp32 NCHW image -> NHWC fp16.
+// Implicit GEMM on the matrix cores with the im2col done by the LDS read addresses:
+//   K order = (kh, c, kw padded 7->8): one 8-wide K granule = 8 consecutive input columns of one
+//   (kh, c) row of the patch, i.e. 16 contiguous bytes of the fp16 patch in LDS; 21 granules + 1
+//   zero granule = 22 = 11 MFMA K-steps of 16.  Weights (A operand, [64][176] fp16) and the
+//   37x38x3 input patch (B operand) both sit in LDS; D[n][pixel] puts 4 consecutive channels of
+//   one pixel in a lane, so the NHWC store is 8 bytes per lane with no transposition.
+// One 16x16 output tile per workgroup, 64 pixels x 64 channels per wave (4 accumulators).
+constexpr int ST_T = 16, ST_PH = ST_T * 2 + 5, ST_PW = 40;     // tile edge, patch rows, padded patch row (halves)
+constexpr int ST_K = 176;                                      // 22 granules x 8
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ wf,
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const _Float16* __restrict__ wk,
                                                    const float* __restrict__ bias, _Float16* __restrict__ out,
                                                    int H, int W, int Ho, int Wo)
 {
-    __shared__ float s_w[147 * 64];
-    __shared__ float s_p[3 * ST_P * ST_P];
-    const int tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) _Float16 s_w[64 * ST_K];
+    __shared__ __attribute__((aligned(16))) _Float16 s_p[3 * ST_PH * ST_PW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, oy0 = blockIdx.y * ST_T, ox0 = blockIdx.x * ST_T;
-    for (int i = tid; i < 147 * 64; i += 256) s_w[i] = wf[i];
+    for (int i = tid; i < 64 * ST_K / 8; i += 256)
+        reinterpret_cast<half8*>(s_w)[i] = reinterpret_cast<const half8*>(wk)[i];
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
-    for (int i = tid; i < 3 * ST_P * ST_P; i += 256) {
-        const int c = i / (ST_P * ST_P), r = i - c * ST_P * ST_P;
-        const int py = r / ST_P, px = r - py * ST_P;
+    for (int i = tid; i < 3 * ST_PH * ST_PW; i += 256) {
+        const int c = i / (ST_PH * ST_PW), r = i - c * ST_PH * ST_PW;
+        const int py = r / ST_PW, px = r - py * ST_PW;
         const int iy = iy0 + py, ix = ix0 + px;
         float v = 0.f;
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
             v = img[(((size_t)b * 3 + c) * H + iy) * W + ix];
-        s_p[i] = v;
+        s_p[i] = (_Float16)v;
     }
     __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
-    float acc[64];
+    const int l31 = lane & 31, lhi = lane >> 5;
+    f32x16 acc[2][2];                                          // [channel tile][pixel tile]
 #pragma unroll
-    for (int co = 0; co < 64; ++co) acc[co] = 0.f;
-    for (int c = 0; c < 3; ++c)
-        for (int kh = 0; kh < 7; ++kh) {
-            const float* prow = s_p + (c * ST_P + ty * 2 + kh) * ST_P + tx * 2;
-            const float* wrow = s_w + ((c * 7 + kh) * 7) * 64;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int kw = 0; kw < 7; ++kw) {
-                const float av = prow[kw];
-                const float4* w4 = reinterpret_cast<const float4*>(wrow + kw * 64);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float4 wv = w4[q];
-                    acc[4 * q] += av * wv.x;
-                    acc[4 * q + 1] += av * wv.y;
-                    acc[4 * q + 2] += av * wv.z;
-                    acc[4 * q + 3] += av * wv.w;
-                }
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // this lane's two pixels (B operand columns): pixel tile t covers output rows 4*wave+2t, +1
+    int pbase[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int py = 4 * wave + 2 * t + (l31 >> 4), px = l31 & 15;
+        pbase[t] = (py * 2) * ST_PW + px * 2;                  // halves; + (c*ST_PH + kh)*ST_PW per granule
+    }
+#pragma unroll
+    for (int ks = 0; ks < ST_K / 16; ++ks) {
+        int g = ks * 2 + lhi;                                  // K granule of this half-wave
+        const int gg = g < 21 ? g : 20;                        // granule 21 has zero weights: any in-bounds read
+        const int kh = gg / 3, c = gg - kh * 3;
+        const int goff = (c * ST_PH + kh) * ST_PW;
+        half8 wf[2], pf[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            wf[nt] = *reinterpret_cast<const half8*>(s_w + (nt * 32 + l31) * ST_K + g * 8);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                          // 8 consecutive columns, 4-byte aligned: 4 x b32
+            const unsigned* q = reinterpret_cast<const unsigned*>(s_p + pbase[t] + goff);
+            union { unsigned u[4]; half8 h; } cv;
+            cv.u[0] = q[0]; cv.u[1] = q[1]; cv.u[2] = q[2]; cv.u[3] = q[3];
+            pf[t] = cv.h;
         }
-    const int oy = oy0 + ty, ox = ox0 + tx;
-    if (oy < Ho && ox < Wo) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], pf[t], acc[nt][t], 0, 0, 0);
+    }
+    // D[n][pixel]: lane = pixel (col l31), reg r -> channel nt*32 + (r&3) + 8*(r>>2) + 4*lhi
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int oy = oy0 + 4 * wave + 2 * t + (l31 >> 4), ox = ox0 + (l31 & 15);
+        if (oy >= Ho || ox >= Wo) continue;
         _Float16* op = out + (((size_t)b * Ho + oy) * Wo + ox) * 64;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            half8 h;
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = acc[g * 8 + e] + bias[g * 8 + e];
-                h[e] = (_Float16)(v > 0.f ? v : 0.f);
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = nt * 32 + 8 * q + 4 * lhi;
+                const float4 bv = *reinterpret_cast<const float4*>(bias + n0);
+                half4 h;
+                float v;
+                v = acc[nt][t][4 * q + 0] + bv.x; h[0] = (_Float16)(v > 0.f ? v : 0.f);
+                v = acc[nt][t][4 * q + 1] + bv.y; h[1] = (_Float16)(v > 0.f ? v : 0.f);
+                v = acc[nt][t][4 * q + 2] + bv.z; h[2] = (_Float16)(v > 0.f ? v : 0.f);
+                v = acc[nt][t][4 * q + 3] + bv.w; h[3] = (_Float16)(v > 0.f ? v : 0.f);
+                *reinterpret_cast<half4*>(op + n0) = h;
             }
-            *reinterpret_cast<half8*>(op + g * 8) = h;
-        }
     }
 }
 
@@ -316,7 +347,7 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                 if (!input) return SMAP_E_ARG;
                 dim3 grid((o.Wo + ST_T - 1) / ST_T, (o.Ho + ST_T - 1) / ST_T, o.B);
                 hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, st, input,
-                                   reinterpret_cast<const float*>(wb + o.w_off),
+                                   reinterpret_cast<const _Float16*>(wb + o.w_off),
                                    reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, o.Ho,
                                    o.Wo);
                 e = hipGetLastError();

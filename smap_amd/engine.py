@@ -189,7 +189,9 @@ class Graph:
         B, H, W, sd = self.B, self.H, self.W, self.sd
         # ResNet_top (smap.py:80-92)
         w, b = fold_conv_bn(sd, "top.conv")
-        wk = w.permute(1, 2, 3, 0).reshape(147, 64).to(torch.float32)
+        wk = torch.zeros((64, 22, 8), dtype=torch.float16)          # K = (kh, c, kw 7->8) + one zero granule
+        wk[:, :21, :7] = w.permute(0, 2, 1, 3).reshape(64, 21, 7).to(torch.float16)
+        wk = wk.reshape(64, 176)
         H2, W2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         t = self.tensor("top.conv", H2, W2, 64)
         self.flops += 2 * B * H2 * W2 * 64 * 147
