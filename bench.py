@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--refine", action="store_true",
+                    help="BASELINE configs[4]: also run the RefineNet post-refinement (model/refinenet.py) on every pose")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -147,7 +149,12 @@ def main():
     from exps.stage3_root2.config import cfg as run_cfg
     torch.manual_seed(0)
     net = SMAP(make_cfg((128, 208))).eval().to(dev)
-    pipe = PosePipeline(net, run_cfg, B, H, W, dev, n_extra=1)
+    refine_w = None
+    if args.refine:
+        from model.refinenet import RefineNet
+        torch.manual_seed(1)
+        refine_w = RefineNet().eval().folded(dev)
+    pipe = PosePipeline(net, run_cfg, B, H, W, dev, refine_weights=refine_w, n_extra=1)
     imgs = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
     scenes = [synth_scene(8, seed=1000 * rank + i)[:2] for i in range(B)]
     s_hms = torch.from_numpy(np.stack([s[0] for s in scenes])).to(dev)
@@ -204,7 +211,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"batch={B} x 3x512x832 per GPU, full SMAP + depth-aware PAF association "
-                                   f"+ lifting (BASELINE configs[2]; configs[3] when n_gpus=8)",
+                                   f"+ lifting{' + RefineNet (configs[4])' if args.refine else ''} "
+                                   f"(BASELINE configs[2]; configs[3] when n_gpus=8)",
                        "frames_per_step": B * world, "persons_in_last_step": sum(len(r) for r in last),
                        "arithmetic": "backbone fp16 storage / fp32 MFMA accumulate, heads fp32; association fp32 (+f64 "
                                      "where the reference is); lifting f64",

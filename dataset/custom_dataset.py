@@ -48,23 +48,19 @@ class CustomDataset(Dataset):
         return (t - self.mean) / self.std, image_name, scale                    # Normalize
 
     def aug_croppad(self, img):
+        from smap_amd.preprocess import letterbox_geometry
         crop_x, crop_y = self.net_input_shape
         w0, h0 = self.image_shape
-        s = min(crop_x / w0, crop_y / h0)
-        scale = dict(scale=s, img_width=w0, img_height=h0, net_width=crop_x, net_height=crop_y)
-        nw, nh = int(round(w0 * s)), int(round(h0 * s))          # cv2.resize(fx, fy): dsize = round(src * f)
+        scale, (nh, nw, top, left) = letterbox_geometry(w0, h0, crop_x, crop_y)   # cv2.resize(fx, fy): dsize = round(src * f)
         t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
         r = F.interpolate(t, size=(nh, nw), mode="bilinear", align_corners=False, antialias=False)
         r = r.round().clamp(0, 255).to(torch.uint8)[0].permute(1, 2, 0).numpy()
         out = np.full((crop_y, crop_x, 3), 128, np.uint8)
-        if nw < crop_x:
-            l = (crop_x - nw) // 2
-            out[:nh, l:l + nw] = r[:crop_y]
-            if nh < crop_y:                       # both short (rounding): centre vertically too
-                out[:] = 128
-                u = (crop_y - nh) // 2
-                out[u:u + nh, l:l + nw] = r
-        else:
-            u = (crop_y - nh) // 2
-            out[u:u + nh, :crop_x] = r[:, :crop_x]
+        hh, ww = min(nh, crop_y - top), min(nw, crop_x - left)
+        out[top:top + hh, left:left + ww] = r[:hh, :ww]
         return out, scale
+
+    def raw(self, index):
+        """(uint8 HxWx3 BGR image, image name) for the device pre-processing path (smap_amd/preprocess.py)."""
+        image_path = self.image_list[index].rstrip()
+        return self._read_bgr(image_path), image_path.replace(self.dataset_path, "").lstrip("/")

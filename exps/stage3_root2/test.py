@@ -44,6 +44,24 @@ def get_logger(name, log_dir, filename):
     return logger
 
 
+class DevicePreprocLoader:
+    """Batches of (imgs on the device, names, scales) with decode on the host and resize / pad /
+    normalise in one HIP kernel per image (smap_amd/preprocess.py)."""
+
+    def __init__(self, dataset, indices, batch_size, cfg, device):
+        self.ds, self.idx, self.bs, self.cfg, self.device = dataset, list(indices), batch_size, cfg, device
+
+    def __len__(self):
+        return (len(self.idx) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        from smap_amd.preprocess import preprocess_batch
+        for s in range(0, len(self.idx), self.bs):
+            raws, names = zip(*[self.ds.raw(i) for i in self.idx[s:s + self.bs]])
+            imgs, scales = preprocess_batch(raws, self.cfg.INPUT.MEANS, self.cfg.INPUT.STDS, self.device)
+            yield imgs, list(names), scales
+
+
 def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, device, output_dir=""):
     os.makedirs(output_dir, exist_ok=True)
     model.eval()
@@ -112,6 +130,8 @@ def main():
     parser.add_argument("--do_flip", type=float, default=0, help="Set to 1 if do flip when test")
     parser.add_argument("--dataset_path", type=str, default="", help='Image dir path of "run_inference" test mode')
     parser.add_argument("--json_name", type=str, default="", help="Add a suffix to the result json.")
+    parser.add_argument("--device_preprocess", type=int, default=0,
+                        help="(addition) 1: resize/pad/normalise on the GPU (smap_preprocess) instead of in the dataset")
     args = parser.parse_args()
     if args.test_mode != "run_inference":
         raise NotImplementedError("only -t run_inference is implemented (the other modes need the training datasets)")
@@ -135,10 +155,15 @@ def main():
     model.to(device)
 
     dataset = CustomDataset(cfg, args.dataset_path)
+    indices = range(len(dataset))
     if world > 1:
         st, ed = shard_range(len(dataset), world, dist.get_rank())
-        dataset = Subset(dataset, range(st, ed))
-    data_loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=False)
+        indices = range(st, ed)
+    if args.device_preprocess:
+        data_loader = DevicePreprocLoader(dataset, indices, args.batch_size, cfg, torch.device(cfg.MODEL.DEVICE, local))
+    else:
+        data_loader = DataLoader(Subset(dataset, indices) if world > 1 else dataset, batch_size=args.batch_size,
+                                 shuffle=False)
 
     refine_model = RefineNet().to(device) if cfg.REFINE else None
     if os.path.exists(args.SMAP_path):

@@ -79,6 +79,12 @@ int smap_refine(const float* pred_2d, const double* pred_3d, const int32_t* coun
 int smap_refine_mlp(const float* x, int N, const float* const* wt, const float* const* bs, float* y,
                     void* stream);
 
+/* dataset/custom_dataset.py:27-68 (cv2 resize to fit, centre pad with 128, ToTensor, Normalize) for one
+ * image on the device.  src: uint8 [h][w][3] BGR; the resized image is nh x nw and sits at (top,left)
+ * of the net_h x net_w canvas; dst: fp32 [3][net_h][net_w]; mean3/std3: HOST pointers to 3 floats. */
+int smap_preprocess(const unsigned char* src, int h, int w, int nh, int nw, int top, int left, float* dst,
+                    int net_h, int net_w, const float* mean3, const float* std3, void* stream);
+
 /* ---- backbone: replaces model/smap.py SMAP.forward (eval) ------------------ */
 
 /* One op of the static inference schedule.  Offsets are BYTE offsets into the

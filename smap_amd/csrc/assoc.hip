@@ -632,6 +632,43 @@ __global__ __launch_bounds__(256) void refine_mlp_kernel(const float* __restrict
     if (t < 45) y[(size_t)i * 45 + t] = act[cur][t];
 }
 
+// ------------------------------------------------------------ preprocess --
+// dataset/custom_dataset.py:41-68 (aug_croppad) + ToTensor + Normalize on the device: bilinear
+// resize (half-pixel centres, no anti-aliasing -- the sampling rule of cv2.INTER_LINEAR and of
+// F.interpolate(align_corners=False)), round to uint8, centre into the net_h x net_w canvas padded
+// with 128, /255, (x - mean) / std.  One thread per canvas pixel, 3 channels; fp32 arithmetic in
+// ATen's operation order so that it matches the host path bit for bit.
+struct PrepArgs { int h, w, nh, nw, top, left, net_h, net_w; float mean[3], stdv[3]; };
+
+__global__ void preprocess_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, PrepArgs p)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= p.net_w) return;
+    float v[3] = {128.f, 128.f, 128.f};
+    const int ry = y - p.top, rx = x - p.left;
+    if ((unsigned)ry < (unsigned)p.nh && (unsigned)rx < (unsigned)p.nw) {
+        const float sh = (float)p.h / (float)p.nh, sw = (float)p.w / (float)p.nw;
+        float fy = sh * ((float)ry + 0.5f) - 0.5f, fx = sw * ((float)rx + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const unsigned char* r0 = src + ((size_t)y0 * p.w) * 3;
+        const unsigned char* r1 = src + ((size_t)y1 * p.w) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a = r0[x0 * 3 + c], b = r0[x1 * 3 + c], cc = r1[x0 * 3 + c], d = r1[x1 * 3 + c];
+            float t = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * cc + lx1 * d);
+            t = rintf(t);                                   // torch.round: half to even
+            v[c] = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        dst[((size_t)c * p.net_h + y) * p.net_w + x] = (v[c] / 255.0f - p.mean[c]) / p.stdv[c];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- C ABI ----
@@ -720,6 +757,16 @@ extern "C" int smap_refine_mlp(const float* x, int N, const float* const* wt, co
         w.bs[l] = bs[l];
     }
     hipLaunchKernelGGL(refine_mlp_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, w, y);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int smap_preprocess(const unsigned char* src, int h, int w, int nh, int nw, int top, int left, float* dst,
+                               int net_h, int net_w, const float* mean3, const float* std3, void* stream)
+{
+    if (!src || !dst || !mean3 || !std3 || h <= 0 || w <= 0 || nh <= 0 || nw <= 0 || net_h <= 0 || net_w <= 0)
+        return SMAP_E_ARG;
+    PrepArgs p{h, w, nh, nw, top, left, net_h, net_w, {mean3[0], mean3[1], mean3[2]}, {std3[0], std3[1], std3[2]}};
+    hipLaunchKernelGGL(preprocess_kernel, dim3((net_w + 255) / 256, net_h), dim3(256), 0, (hipStream_t)stream, src, dst, p);
     return hip_rc(hipGetLastError());
 }
 
