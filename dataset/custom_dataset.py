@@ -3,8 +3,8 @@
 Same outputs: (normalised BGR CHW float tensor letter-boxed to 832x512 with 128-grey padding,
 image name, `scale` dict with scale/img_width/img_height/net_width/net_height).
 cv2 and torchvision are not part of this image: decoding uses PIL (converted to BGR like
-cv2.imread) and the resize uses torch bilinear with half-pixel centres and no anti-aliasing,
-the sampling rule of cv2.INTER_LINEAR.  uint8 rounding can differ from OpenCV's fixed-point
+cv2.imread) and the resize is a plain fp32 bilinear with half-pixel centres and no anti-aliasing
+(smap_amd.preprocess.resize_bilinear_u8), the sampling rule of cv2.INTER_LINEAR.  uint8 rounding can differ from OpenCV's fixed-point
 path by 1 LSB -- pre-processing is outside the measured hot path.
 `.npy` files holding an HxWx3 uint8 BGR array are accepted as well.
 """
@@ -13,7 +13,6 @@ import os.path as osp
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 from torch.utils.data import Dataset
 
 
@@ -48,13 +47,11 @@ class CustomDataset(Dataset):
         return (t - self.mean) / self.std, image_name, scale                    # Normalize
 
     def aug_croppad(self, img):
-        from smap_amd.preprocess import letterbox_geometry
+        from smap_amd.preprocess import letterbox_geometry, resize_bilinear_u8
         crop_x, crop_y = self.net_input_shape
         w0, h0 = self.image_shape
         scale, (nh, nw, top, left) = letterbox_geometry(w0, h0, crop_x, crop_y)   # cv2.resize(fx, fy): dsize = round(src * f)
-        t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
-        r = F.interpolate(t, size=(nh, nw), mode="bilinear", align_corners=False, antialias=False)
-        r = r.round().clamp(0, 255).to(torch.uint8)[0].permute(1, 2, 0).numpy()
+        r = resize_bilinear_u8(img, nh, nw)
         out = np.full((crop_y, crop_x, 3), 128, np.uint8)
         hh, ww = min(nh, crop_y - top), min(nw, crop_x - left)
         out[top:top + hh, left:left + ww] = r[:hh, :ww]

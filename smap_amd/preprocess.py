@@ -26,6 +26,35 @@ def letterbox_geometry(w0, h0, net_w=832, net_h=512):
     return scale, (nh, nw, top, left)
 
 
+def resize_bilinear_u8(img, nh, nw):
+    """Host statement of the resize the HIP kernel performs (one rounding per written fp32 operation,
+    no FMA contraction): half-pixel-centre bilinear, the sampling rule of cv2.INTER_LINEAR /
+    F.interpolate(align_corners=False, antialias=False); result rounded half-to-even to uint8."""
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    f32 = np.float32
+
+    def axis(n_in, n_out):
+        scale = f32(n_in) / f32(n_out)
+        src = scale * (np.arange(n_out, dtype=f32) + f32(0.5)) - f32(0.5)
+        src = np.maximum(src, f32(0))
+        i0 = src.astype(np.int64)
+        i1 = i0 + (i0 < n_in - 1)
+        l1 = (src - i0.astype(f32)).astype(f32)
+        return i0, i1, (f32(1) - l1).astype(f32), l1
+
+    y0, y1, ly0, ly1 = axis(h, nh)
+    x0, x1, lx0, lx1 = axis(w, nw)
+    a = img[y0][:, x0].astype(f32)
+    b = img[y0][:, x1].astype(f32)
+    c = img[y1][:, x0].astype(f32)
+    d = img[y1][:, x1].astype(f32)
+    lx0, lx1 = lx0[None, :, None], lx1[None, :, None]
+    ly0, ly1 = ly0[:, None, None], ly1[:, None, None]
+    t = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * c + lx1 * d)
+    return np.clip(np.rint(t), 0, 255).astype(np.uint8)
+
+
 def preprocess_batch(images, means, stds, device, net_w=832, net_h=512):
     """images: list of uint8 HxWx3 BGR arrays/tensors.  Returns (imgs [B,3,net_h,net_w] fp32 on `device`,
     scales: dict of lists as the DataLoader would collate them)."""

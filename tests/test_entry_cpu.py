@@ -101,3 +101,20 @@ def test_two_rank_gloo_gather(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "GATHER_OK 11" in r.stdout
+
+
+def test_host_resize_matches_torch_bilinear_within_one_lsb():
+    """resize_bilinear_u8 is F.interpolate(bilinear, align_corners=False, antialias=False) up to the
+    FMA contraction inside ATen's vectorised CPU kernel: <= 1 LSB on a tiny fraction of pixels."""
+    import torch.nn.functional as F
+    from smap_amd.preprocess import resize_bilinear_u8
+    rng = np.random.default_rng(2)
+    for (h, w), (nh, nw) in [((300, 1000), (250, 832)), ((900, 400), (512, 228)), ((37, 53), (512, 733)),
+                             ((512, 832), (512, 832))]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = resize_bilinear_u8(img, nh, nw).astype(np.int32)
+        t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+        ref = F.interpolate(t, size=(nh, nw), mode="bilinear", align_corners=False, antialias=False)
+        ref = ref.round().clamp(0, 255)[0].permute(1, 2, 0).numpy().astype(np.int32)
+        diff = np.abs(got - ref)
+        assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, ((h, w), diff.max(), (diff > 0).mean())
