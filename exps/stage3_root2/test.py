@@ -29,7 +29,7 @@ from dataset.custom_dataset import CustomDataset
 from smap_amd.dist import gather_json, shard_range
 from exps.stage3_root2.config import cfg
 from smap_amd.pipeline import PosePipeline
-from exps.stage3_root2.test_util import default_cams, merge_flip
+from exps.stage3_root2.test_util import default_cams
 
 
 def get_logger(name, log_dir, filename):
@@ -80,29 +80,22 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
             it = tqdm(data_loader)
         except ImportError:
             pass
-    pipe, flip_buf = None, None
+    pipe = None
 
     def drain(recs):
         if recs:
             result["3d_pairs"].extend(recs)
 
-    def flip_merge(engine, imgs, slot):                          # test.py:55-70 on the backbone stream
-        nonlocal flip_buf
-        if flip_buf is None or flip_buf.numel() != slot.out.numel():
-            flip_buf = engine.new_output()
-        hms_flip, _, _ = engine.run(torch.flip(imgs, [-1]), out=flip_buf)
-        merge_flip(slot.hms, hms_flip, cfg)
-
     for batch in it:
         imgs, img_path, scales = batch
         imgs = imgs.to(device, non_blocking=True).float().contiguous()
-        if pipe is None or pipe.engine.B != len(imgs):           # (last) batch of a different size
+        if pipe is None or pipe.B != len(imgs):                  # (last) batch of a different size
             if pipe is not None:
                 drain(pipe.flush())
-            pipe = PosePipeline(model, cfg, len(imgs), imgs.shape[-2], imgs.shape[-1], device, refine_w)
+            pipe = PosePipeline(model, cfg, len(imgs), imgs.shape[-2], imgs.shape[-1], device, refine_w,
+                                do_flip=bool(cfg.DO_FLIP))
         with torch.no_grad():
-            drain(pipe.submit(imgs, default_cams(scales, len(imgs)), list(img_path),
-                              flip_merge=flip_merge if cfg.DO_FLIP else None))
+            drain(pipe.submit(imgs, default_cams(scales, len(imgs)), list(img_path)))
     if pipe is not None:
         drain(pipe.flush())
     if dist.is_initialized() and dist.get_world_size() > 1:

@@ -40,6 +40,11 @@ const char* smap_version(void);
  * hms: [B,43,H,W] fp32. */
 int smap_scale_hms(float* hms, int B, int H, int W, void* stream);
 
+/* test.py:55-70 flip-TTA merge, in place on hms [B,43,H,W]: hms[:,i] += s_i * flip_x(hms_flip)[:,pair43[i]]
+ * (s_i = -1 on PAF-x channels 15,17,..), then hms[:,15:] *= 0.5.  pair43: HOST pointer to 43 ints
+ * (KEYPOINT.FLIP_ORDER followed by 15 + PAF.FLIP_CHANNEL, dataset/data_settings.py:22,33-34). */
+int smap_flip_merge(float* hms, const float* hms_flip, const int* pair43, int B, int H, int W, void* stream);
+
 /* nmsBase.cu:10-175 (nmsRegisterKernel + exclusive_scan + writeResultKernel) fused.
  * hms  : [B,C,H,W] fp32, C >= 15 (only channels 0..14 are read)
  * peaks: [B,15,128,3] fp32 out; slot 0 = (count,0,0), slots > count zero-filled.

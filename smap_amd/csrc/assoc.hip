@@ -632,6 +632,29 @@ __global__ __launch_bounds__(256) void refine_mlp_kernel(const float* __restrict
     if (t < 45) y[(size_t)i * 45 + t] = act[cur][t];
 }
 
+// ------------------------------------------------------------- flip-TTA --
+// test.py:55-70: outputs_2d[:, i] += sign_i * flip_x(outputs_2d_flip)[:, pair[i]] for all 43 channels
+// (PAF-x channels negated), then outputs_2d[:, 15:] *= 0.5 -- key-point channels stay a SUM.
+struct FlipTab { int pair[SMAP_HMS_C]; };
+__global__ void flip_merge_kernel(float* __restrict__ hms, const float* __restrict__ flip, FlipTab tab, int W,
+                                  int HW, long long total)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % HW);
+        const long long bc = i / HW;
+        const int c = (int)(bc % SMAP_HMS_C);
+        const long long b = bc / SMAP_HMS_C;
+        const int y = pix / W, x = pix - y * W;
+        const float f = flip[((b * SMAP_HMS_C + tab.pair[c]) * (long long)HW) + y * W + (W - 1 - x)];
+        float v = hms[i];
+        const bool neg = c >= NJ && ((c - NJ) & 1) == 0;
+        v = v + (neg ? f * -1.f : f);
+        if (c >= NJ) v = v * 0.5f;
+        hms[i] = v;
+    }
+}
+
 // ------------------------------------------------------------ preprocess --
 // dataset/custom_dataset.py:41-68 (aug_croppad) + ToTensor + Normalize on the device: bilinear
 // resize (half-pixel centres, no anti-aliasing -- the sampling rule of cv2.INTER_LINEAR and of
@@ -757,6 +780,21 @@ extern "C" int smap_refine_mlp(const float* x, int N, const float* const* wt, co
         w.bs[l] = bs[l];
     }
     hipLaunchKernelGGL(refine_mlp_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, w, y);
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" int smap_flip_merge(float* hms, const float* hms_flip, const int* pair43, int B, int H, int W, void* stream)
+{
+    if (!hms || !hms_flip || !pair43 || B <= 0 || H <= 0 || W <= 0) return SMAP_E_ARG;
+    FlipTab tab;
+    for (int c = 0; c < SMAP_HMS_C; ++c) {
+        if (pair43[c] < 0 || pair43[c] >= SMAP_HMS_C) return SMAP_E_ARG;
+        tab.pair[c] = pair43[c];
+    }
+    const long long total = (long long)B * SMAP_HMS_C * H * W;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(flip_merge_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, hms, hms_flip, tab, W, H * W,
+                       total);
     return hip_rc(hipGetLastError());
 }
 

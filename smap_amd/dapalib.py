@@ -61,6 +61,19 @@ def scale_hms_(hms):
     return hms
 
 
+def flip_merge_(hms, hms_flip, pair):
+    """In place flip-TTA merge (test.py:55-70) of hms [B,43,H,W] with the heat-maps of the mirrored
+    images; pair = KEYPOINT.FLIP_ORDER + [15 + c for c in PAF.FLIP_CHANNEL]."""
+    H, W = _check_hms(hms, True)
+    _check_hms(hms_flip, True)
+    if hms_flip.shape != hms.shape or len(pair) != HMS_C:
+        raise ValueError("hms_flip must match hms and pair must have 43 entries")
+    tab = (C.c_int * HMS_C)(*[int(p) for p in pair])
+    with torch.cuda.device(hms.device):
+        _L.check(_L.load().smap_flip_merge(_p(hms), _p(hms_flip), tab, hms.shape[0], H, W, _stream()), "smap_flip_merge")
+    return hms
+
+
 def extract_batch(hms):
     """hms [B,43,H,W] -> (peaks [B,15,128,3], scores [B,14,127,127]) on the device."""
     H, W = _check_hms(hms, True)

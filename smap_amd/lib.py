@@ -16,7 +16,7 @@ SO_PATH = os.environ.get("SMAP_HIP_LIB") or os.path.join(HERE, "libsmap_hip.so")
 
 # every symbol include/smap_hip.h declares
 SYMBOLS = [
-    "smap_version", "smap_scale_hms", "smap_nms", "smap_paf_score", "smap_group", "smap_lift",
+    "smap_version", "smap_scale_hms", "smap_flip_merge", "smap_nms", "smap_paf_score", "smap_group", "smap_lift",
     "smap_refine", "smap_refine_mlp", "smap_preprocess", "smap_sizeof_op", "smap_plan_create", "smap_plan_destroy", "smap_plan_run", "smap_plan_run_range",
 ]
 
@@ -61,6 +61,7 @@ def load():
     vp, ip, fp = C.c_void_p, C.c_int, C.c_float
     lib.smap_version.restype = C.c_char_p
     lib.smap_scale_hms.argtypes = [vp, ip, ip, ip, vp]
+    lib.smap_flip_merge.argtypes = [vp, vp, C.POINTER(C.c_int), ip, ip, ip, vp]
     lib.smap_nms.argtypes = [vp, ip, ip, ip, ip, fp, vp, vp]
     lib.smap_paf_score.argtypes = [vp, vp, ip, ip, ip, vp, vp]
     lib.smap_group.argtypes = [vp, vp, vp, ip, ip, ip, ip, ip, vp, vp, vp]

@@ -21,10 +21,11 @@ NJ, MAXP = 15, 127
 
 
 class _Slot:
-    def __init__(self, engine, device, n_extra):
+    def __init__(self, engine, device, n_extra, B):
         self.out = engine.new_output()
-        self.hms, self.det_d, self.root_d = engine.views(self.out)
-        B = engine.B
+        hms, det_d, root_d = engine.views(self.out)         # engine batch is 2B with flip-TTA: [frames ; mirrored]
+        self.hms, self.det_d, self.root_d = hms[:B], det_d[:B], root_d[:B]
+        self.hms_flip = hms[B:] if engine.B == 2 * B else None
         mk = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         self.host = [dict(p2=mk((B, MAXP, NJ, 4), torch.float32), p3=mk((B, MAXP, NJ, 4), torch.float64),
                           rz=mk((B, MAXP), torch.float64), counts=mk((B,), torch.int32))
@@ -36,15 +37,19 @@ class _Slot:
 
 
 class PosePipeline:
-    def __init__(self, model, cfg, batch, H, W, device, refine_weights=None, n_extra=0):
+    def __init__(self, model, cfg, batch, H, W, device, refine_weights=None, n_extra=0, do_flip=False):
         self.device = torch.device(device)
         self.cfg = cfg
-        self.engine = model.engine(batch, H, W, self.device)
+        self.B, self.do_flip = batch, bool(do_flip)
+        # flip-TTA (test.py:55-70): frames and their mirror images run as ONE 2B batch
+        self.engine = model.engine(2 * batch if do_flip else batch, H, W, self.device)
+        kpt = cfg.DATASET.KEYPOINT.NUM
+        self.flip_pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
         self.refine = refine_weights
         self.s_bb = torch.cuda.Stream(self.device)
         self.s_post = torch.cuda.Stream(self.device)
         self.s_comm = torch.cuda.Stream(self.device)      # result gather (RCCL) never queues behind compute
-        self.slots = [_Slot(self.engine, self.device, n_extra) for _ in range(2)]
+        self.slots = [_Slot(self.engine, self.device, n_extra, batch) for _ in range(2)]
         self.k = 0
         self.bb_events = []              # (start, end) HIP events of timed backbone runs
 
@@ -61,7 +66,7 @@ class PosePipeline:
         for k, t in (("p2", p2), ("p3", p3), ("rz", rz), ("counts", counts)):
             h[k].copy_(t, non_blocking=True)
 
-    def submit(self, imgs, cams, tags, extra=(), flip_merge=None, time_backbone=False):
+    def submit(self, imgs, cams, tags, extra=(), time_backbone=False):
         """imgs [B,3,H,W] fp32 on the device; cams [B,9] float64 (host array); tags: B image names.
         extra: tuples (tag_prefix, hms, root_d, det_d) of already-scaled maps to associate as well
         (bench only).  Returns the record list of the previous batch or None."""
@@ -79,9 +84,11 @@ class PosePipeline:
             if time_backbone:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            self.engine.run(imgs, out=slot.out)
-            if flip_merge is not None:                 # test.py:55-70: second forward + channel-permuted merge
-                flip_merge(self.engine, imgs, slot)
+            if self.do_flip:
+                self.engine.run(torch.cat([imgs, torch.flip(imgs, [-1])], 0), out=slot.out)
+                dapalib.flip_merge_(slot.hms, slot.hms_flip, self.flip_pair)
+            else:
+                self.engine.run(imgs, out=slot.out)
             if time_backbone:
                 e1.record()
                 self.bb_events.append((e0, e1))

@@ -159,3 +159,17 @@ def test_refinenet_forward_matches_golden(golden_dir):
     net.load_state_dict(recipe_state_dict(net.state_dict()))
     y = net.to(DEV)(torch.from_numpy(z["x"]).to(DEV)).cpu().numpy()
     assert np.abs(y - z["y"]).max() < 1e-4 * max(1.0, np.abs(z["y"]).max())
+
+
+def test_flip_merge_kernel_matches_reference_loop():
+    """smap_flip_merge == the reference's channel loop (test.py:55-70), bit for bit."""
+    import dapalib
+    from exps.stage3_root2.config import cfg
+    from exps.stage3_root2.test_util import merge_flip
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(3, 43, 128, 208, generator=g) * 50
+    b = torch.randn(3, 43, 128, 208, generator=g) * 50
+    want = merge_flip(a.clone(), b, cfg)
+    pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [15 + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
+    got = dapalib.flip_merge_(a.to(DEV), b.to(DEV), pair)
+    assert torch.equal(got.cpu(), want)
