@@ -415,6 +415,17 @@ class BackboneEngine:
         self.hms, self.det_d, self.root_d = self.views(self.out)
         self.flops_per_batch = g.flops
 
+    def sibling(self):
+        """A second executor of the same schedule with its own arena (weights and plan shared), so that
+        two batches can be in flight on two streams."""
+        import copy
+        e = copy.copy(self)
+        e.arena = torch.zeros_like(self.arena)
+        e.out = e.new_output()
+        e.hms, e.det_d, e.root_d = e.views(e.out)
+        e._is_sibling = True
+        return e
+
     def new_output(self):
         """A fresh fp32 output buffer (hms | det_d | root_d); pass it to run(out=...) to double-buffer."""
         return torch.zeros((self.out_floats,), dtype=torch.float32, device=self.device)
@@ -427,6 +438,8 @@ class BackboneEngine:
 
     def __del__(self):
         try:
+            if getattr(self, "_is_sibling", False):
+                return
             if getattr(self, "handle", None):
                 self.lib.smap_plan_destroy(self.handle)
                 self.handle = None

@@ -8,9 +8,12 @@ HIP streams so that the device never waits for the host:
     stream "post" : /255,/127 -> nms -> paf -> group -> lift [-> RefineNet] -> async D2H of batch k
     host          : builds the `3d_pairs` records of batch k from pinned memory meanwhile
 
-Double-buffered network outputs and pinned result buffers make batch k's post-processing
-independent of batch k+1's forward.  `submit()` returns the records of the PREVIOUS batch
-(None for the first call); `flush()` returns the last one.
+Network outputs and pinned result buffers are per slot, so batch k's post-processing is independent
+of later forwards.  With `depth=2` two backbones are in flight on two streams (two arenas, shared
+weights): while batch k sits in its low-resolution, latency-bound layers (layer3/4: 100-400
+workgroups per launch) batch k+1 streams its HBM-bound high-resolution layers on the idle CUs.
+`submit()` returns the records of the batch submitted `depth` calls earlier (None until then);
+`flush()` returns everything still in flight, in order.
 """
 import numpy as np
 import torch
@@ -37,7 +40,7 @@ class _Slot:
 
 
 class PosePipeline:
-    def __init__(self, model, cfg, batch, H, W, device, refine_weights=None, n_extra=0, do_flip=False):
+    def __init__(self, model, cfg, batch, H, W, device, refine_weights=None, n_extra=0, do_flip=False, depth=1):
         self.device = torch.device(device)
         self.cfg = cfg
         self.B, self.do_flip = batch, bool(do_flip)
@@ -46,10 +49,14 @@ class PosePipeline:
         kpt = cfg.DATASET.KEYPOINT.NUM
         self.flip_pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
         self.refine = refine_weights
-        self.s_bb = torch.cuda.Stream(self.device)
+        self.depth = max(1, int(depth))
+        self.engines = [self.engine] + [self.engine.sibling() for _ in range(self.depth - 1)]
+        self.s_bbs = [torch.cuda.Stream(self.device) for _ in range(self.depth)]
+        self.s_bb = self.s_bbs[0]
         self.s_post = torch.cuda.Stream(self.device)
         self.s_comm = torch.cuda.Stream(self.device)      # result gather (RCCL) never queues behind compute
-        self.slots = [_Slot(self.engine, self.device, n_extra, batch) for _ in range(2)]
+        self.nslots = self.depth + 1
+        self.slots = [_Slot(self.engine, self.device, n_extra, batch) for _ in range(self.nslots)]
         self.k = 0
         self.bb_events = []              # (start, end) HIP events of timed backbone runs
 
@@ -70,25 +77,24 @@ class PosePipeline:
         """imgs [B,3,H,W] fp32 on the device; cams [B,9] float64 (host array); tags: B image names.
         extra: tuples (tag_prefix, hms, root_d, det_d) of already-scaled maps to associate as well
         (bench only).  Returns the record list of the previous batch or None."""
-        slot = self.slots[self.k & 1]
-        prev = self.slots[(self.k - 1) & 1] if self.k > 0 else None
-        if slot.busy:                                  # its previous results were not collected: collect now
-            raise RuntimeError("pipeline slot still in flight; call collect order submit -> result")
+        slot = self.slots[self.k % self.nslots]
+        eng, s_bb = self.engines[self.k % self.depth], self.s_bbs[self.k % self.depth]
+        ready = self._collect(slot) if slot.busy else None       # the batch submitted nslots calls ago ...
         cams_d = torch.as_tensor(np.asarray(cams), dtype=torch.float64).to(self.device, non_blocking=True)
         cur = torch.cuda.current_stream(self.device)
-        self.s_bb.wait_stream(cur)                     # imgs were produced on the caller's stream
+        s_bb.wait_stream(cur)                          # imgs were produced on the caller's stream
         self.s_post.wait_stream(cur)
-        imgs.record_stream(self.s_bb)
+        imgs.record_stream(s_bb)
         cams_d.record_stream(self.s_post)
-        with torch.cuda.stream(self.s_bb):
+        with torch.cuda.stream(s_bb):
             if time_backbone:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if self.do_flip:
-                self.engine.run(torch.cat([imgs, torch.flip(imgs, [-1])], 0), out=slot.out)
+                eng.run(torch.cat([imgs, torch.flip(imgs, [-1])], 0), out=slot.out)
                 dapalib.flip_merge_(slot.hms, slot.hms_flip, self.flip_pair)
             else:
-                self.engine.run(imgs, out=slot.out)
+                eng.run(imgs, out=slot.out)
             if time_backbone:
                 e1.record()
                 self.bb_events.append((e0, e1))
@@ -102,11 +108,17 @@ class PosePipeline:
         slot.meta = (list(tags), [t for t, *_ in extra])
         slot.busy = True
         self.k += 1
-        return self._collect(prev) if prev is not None else None
+        # ... or, more eagerly, the oldest batch once `depth` newer ones are queued behind it
+        if ready is None:
+            old = self.slots[(self.k - 1 - self.depth) % self.nslots] if self.k > self.depth else None
+            if old is not None and old.busy:
+                ready = self._collect(old)
+        return ready
 
     def flush(self):
         out = None
-        for s in (self.slots[self.k & 1], self.slots[(self.k - 1) & 1]):
+        for j in range(self.nslots):                   # oldest first
+            s = self.slots[(self.k + j) % self.nslots]
             if s.busy:
                 r = self._collect(s)
                 out = r if out is None else out + r
