@@ -109,24 +109,31 @@ def test_two_stream_pipeline_equals_serial_path():
     g = torch.Generator().manual_seed(3)
     batches = [torch.randn(B, 3, 64, 96, generator=g).to(dev) for _ in range(4)]
     cams = np.tile(np.array([0.5, 192, 128, 96, 64, 192, 192, 96, 64], np.float64), (B, 1))
-    pipe = PosePipeline(net, cfg, B, 64, 96, dev)
-    got = []
+    from exps.stage3_root2.test_util import merge_flip
+    want_all, want_flip, n_people = [], [], 0
     for i, x in enumerate(batches):
-        r = pipe.submit(x, cams, [f"b{i}/{j}" for j in range(B)])
-        if r is not None:
-            got.append(r)
-    got.append(pipe.flush())
-    assert len(got) == len(batches)
-    n_people = 0
-    for i, x in enumerate(batches):
-        h, d, rd = net(x)
-        p2, p3, rz, counts = poses_from_outputs(h, d, rd, cams, cfg)
-        want = [(f"b{i}/{j}", p2[j, :c].tolist(), p3[j, :c].tolist(), rz[j, :c].tolist())
-                for j, c in enumerate(counts) if c > 0]
-        have = [(r["image_path"], r["pred_2d"], r["pred_3d"], r["root_d"]) for r in got[i]]
-        assert have == want
-        n_people += int(counts.sum())
+        for flip, acc in ((False, want_all), (True, want_flip)):
+            h, d, rd = net(x)
+            if flip:
+                hf, _, _ = net(torch.flip(x, [-1]))
+                merge_flip(h, hf, cfg)
+            p2, p3, rz, counts = poses_from_outputs(h, d, rd, cams, cfg)
+            acc += [(f"b{i}/{j}", p2[j, :c].tolist(), p3[j, :c].tolist(), rz[j, :c].tolist())
+                    for j, c in enumerate(counts) if c > 0]
+            n_people += int(counts.sum())
     assert n_people > 0
+    for depth, flip in ((1, False), (2, False), (3, False), (2, True)):
+        pipe = PosePipeline(net, cfg, B, 64, 96, dev, depth=depth, do_flip=flip)
+        got = []
+        for rep in range(2):                                  # reuse of slots / arenas across many submits
+            for i, x in enumerate(batches):
+                r = pipe.submit(x, cams, [f"b{i}/{j}" for j in range(B)])
+                if r is not None:
+                    got += r
+        got += pipe.flush() or []
+        have = [(r["image_path"], r["pred_2d"], r["pred_3d"], r["root_d"]) for r in got]
+        want = want_flip if flip else want_all
+        assert have == want + want, (depth, flip)             # in order, bit for bit
 
 
 def test_device_preprocess_equals_host_dataset(tmp_path):
