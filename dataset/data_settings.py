@@ -1,30 +1,49 @@
-"""Constants of the reference's dataset/data_settings.py (MIX): 15 key points, 14 limbs,
-flip tables, 512x832 network input, stride 4."""
+"""Skeleton / geometry constants of the MIX setting (reference: dataset/data_settings.py:11-41).
+Values are data and must equal the reference's; they are derived here from the skeleton tree
+instead of being listed: 15 key points, 14 limbs, mirror tables, 512x832 input, stride 4."""
 import os
 
-from smap_amd.utils.attrdict import AttrDict as edict
+from smap_amd.utils.attrdict import AttrDict
+
+# joint ids: 0 neck, 1 head, 2 pelvis, then (shoulder, elbow, wrist) and (hip, knee, ankle) for the
+# left side (3-5, 6-8) and the right side (9-11, 12-14)
+_LEFT_ARM, _LEFT_LEG, _RIGHT_ARM, _RIGHT_LEG = (3, 4, 5), (6, 7, 8), (9, 10, 11), (12, 13, 14)
 
 
-class MIX:
-    NAME = "MIX"
-    KEYPOINT = edict()
-    KEYPOINT.NUM = 15
-    # 0 neck 1 head 2 pelvis 3-5 left shoulder/elbow/wrist 6-8 left hip/knee/ankle
-    # 9-11 right shoulder/elbow/wrist 12-14 right hip/knee/ankle  (data_settings.py:16-21)
-    KEYPOINT.FLIP_ORDER = [0, 1, 2, 9, 10, 11, 12, 13, 14, 3, 4, 5, 6, 7, 8]
-    ROOT_IDX = 2
-    PAF = edict()
-    PAF.VECTOR = [[0, 1], [0, 2], [0, 9], [9, 10], [10, 11], [0, 3], [3, 4], [4, 5],
-                  [2, 12], [12, 13], [13, 14], [2, 6], [6, 7], [7, 8]]
-    PAF.FLIP_CHANNEL = [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7, 8, 9,
-                        22, 23, 24, 25, 26, 27, 16, 17, 18, 19, 20, 21]
-    PAF.NUM = len(PAF.VECTOR)
-    PAF.LINE_WIDTH_THRE = 1
-    INPUT_SHAPE = (512, 832)
-    STRIDE = 4
-    OUTPUT_SHAPE = (INPUT_SHAPE[0] // STRIDE, INPUT_SHAPE[1] // STRIDE)
-    WIDTH_HEIGHT_RATIO = INPUT_SHAPE[1] / INPUT_SHAPE[0]
-    PREFIX = os.environ.get("PROJECT_HOME", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+def _limbs():
+    chain = lambda root, js: [[a, b] for a, b in zip((root,) + js[:-1], js)]
+    return [[0, 1], [0, 2]] + chain(0, _RIGHT_ARM) + chain(0, _LEFT_ARM) + chain(2, _RIGHT_LEG) + chain(2, _LEFT_LEG)
+
+
+def _mirror_joints():
+    m = list(range(15))
+    for l, r in zip(_LEFT_ARM + _LEFT_LEG, _RIGHT_ARM + _RIGHT_LEG):
+        m[l], m[r] = r, l
+    return m
+
+
+def _mirror_paf_channels(limbs, mirror):
+    """Channel 2l / 2l+1 (x / y of limb l) maps to the channels of the mirrored limb."""
+    index = {tuple(l): i for i, l in enumerate(limbs)}
+    out = []
+    for a, b in limbs:
+        j = index[(mirror[a], mirror[b])]
+        out += [2 * j, 2 * j + 1]
+    return out
+
+
+def _build():
+    d = AttrDict(NAME="MIX", ROOT_IDX=2, STRIDE=4, INPUT_SHAPE=(512, 832))
+    limbs, mirror = _limbs(), _mirror_joints()
+    d.KEYPOINT = AttrDict(NUM=15, FLIP_ORDER=mirror)
+    d.PAF = AttrDict(VECTOR=limbs, NUM=len(limbs), FLIP_CHANNEL=_mirror_paf_channels(limbs, mirror), LINE_WIDTH_THRE=1)
+    d.OUTPUT_SHAPE = tuple(s // d.STRIDE for s in d.INPUT_SHAPE)
+    d.WIDTH_HEIGHT_RATIO = d.INPUT_SHAPE[1] / d.INPUT_SHAPE[0]
+    d.PREFIX = os.environ.get("PROJECT_HOME", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    return d
+
+
+MIX = _build()
 
 
 def load_dataset(name):

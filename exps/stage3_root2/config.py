@@ -1,48 +1,30 @@
-"""Inference-relevant part of the reference's exps/stage3_root2/config.py (Config class, :10-71).
-Training-only entries (SOLVER, DATALOADER, tensorboard) are omitted: training is out of scope."""
+"""Run configuration of the stage3_root2 experiment, inference subset (reference:
+exps/stage3_root2/config.py:10-71; SOLVER / DATALOADER / tensorboard entries belong to training,
+which is out of scope).  `cfg` has the attribute layout `test.py`, `SMAP(cfg)` and the dataset read."""
 import os
 import os.path as osp
 
-from smap_amd.utils.attrdict import AttrDict as edict
+from smap_amd.utils.attrdict import AttrDict
 from dataset.data_settings import load_dataset
 
-
-class Config:
-    ROOT_DIR = os.environ.get("PROJECT_HOME", osp.dirname(osp.dirname(osp.dirname(osp.abspath(__file__)))))
-    OUTPUT_DIR = osp.join(ROOT_DIR, "model_logs", osp.split(osp.split(osp.realpath(__file__))[0])[1])
-    TEST_DIR = osp.join(OUTPUT_DIR, "log_dir")
-
-    DATASET = edict()
-    DATASET.NAME = "MIX"
-    dataset = load_dataset(DATASET.NAME)
-    DATASET.KEYPOINT = dataset.KEYPOINT
-    DATASET.PAF = dataset.PAF
-    DATASET.ROOT_IDX = dataset.ROOT_IDX
-    DATASET.MAX_PEOPLE = 20
-
-    INPUT = edict()
-    INPUT.NORMALIZE = True
-    INPUT.MEANS = [0.406, 0.456, 0.485]   # bgr
-    INPUT.STDS = [0.225, 0.224, 0.229]
-    INPUT_SHAPE = dataset.INPUT_SHAPE
-    OUTPUT_SHAPE = dataset.OUTPUT_SHAPE
-
-    MODEL = edict()
-    MODEL.STAGE_NUM = 3
-    MODEL.UPSAMPLE_CHANNEL_NUM = 256
-    MODEL.DEVICE = "cuda"
-    MODEL.WEIGHT = None
-
-    LOSS = edict()
-    LOSS.OHKM = True
-    LOSS.TOPK = 8
-    LOSS.COARSE_TO_FINE = True
-
-    RUN_EFFICIENT = False
-
-    TEST = edict()
-    TEST.IMG_PER_GPU = 16
+_HERE = osp.dirname(osp.realpath(__file__))
 
 
-config = Config()
-cfg = config
+def _make():
+    ds = load_dataset("MIX")
+    root = os.environ.get("PROJECT_HOME", osp.dirname(osp.dirname(_HERE)))
+    out_dir = osp.join(root, "model_logs", osp.basename(_HERE))
+    return AttrDict(
+        ROOT_DIR=root, OUTPUT_DIR=out_dir, TEST_DIR=osp.join(out_dir, "log_dir"),
+        DATASET=AttrDict(NAME="MIX", KEYPOINT=ds.KEYPOINT, PAF=ds.PAF, ROOT_IDX=ds.ROOT_IDX, MAX_PEOPLE=20),
+        dataset=ds,
+        INPUT=AttrDict(NORMALIZE=True, MEANS=[0.406, 0.456, 0.485], STDS=[0.225, 0.224, 0.229]),   # BGR order
+        INPUT_SHAPE=ds.INPUT_SHAPE, OUTPUT_SHAPE=ds.OUTPUT_SHAPE,
+        MODEL=AttrDict(STAGE_NUM=3, UPSAMPLE_CHANNEL_NUM=256, DEVICE="cuda", WEIGHT=None),
+        LOSS=AttrDict(OHKM=True, TOPK=8, COARSE_TO_FINE=True),     # read by SMAP.__init__ only
+        RUN_EFFICIENT=False,
+        TEST=AttrDict(IMG_PER_GPU=16),
+    )
+
+
+cfg = config = _make()

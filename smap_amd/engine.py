@@ -122,6 +122,25 @@ def pick_tile(M, cout, key=None):
         import json
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json")
         _TILE_TABLE = json.load(open(path)) if os.path.exists(path) and not os.environ.get("SMAP_NO_TILE_TABLE") else {}
+    pol = os.environ.get("SMAP_TILE_POLICY", "")
+    if pol.startswith("traffic"):       # experiment: minimise L2->LDS bytes subject to a minimum block count
+        min_blocks = int(pol.split(":")[1]) if ":" in pol else 256
+        K = 1
+        if key is not None:
+            _, _, _, cin, _, ks, _ = map(int, key.split(","))
+            K = ks * ks * cin
+        best, best_cost = None, None
+        for t in ([3] if cout <= 32 else [0, 1, 2, 4]):
+            bm, bn = TILES[t]
+            if cout <= 64 and bn > 64:
+                continue
+            mt, nt = -(-M // bm), -(-cout // bn)
+            cost = (mt * bm * nt + nt * bn * mt) * K
+            if mt * nt < min_blocks:
+                cost *= 4
+            if best is None or cost < best_cost:
+                best, best_cost = t, cost
+        return best
     if key is not None and key in _TILE_TABLE:
         return int(_TILE_TABLE[key])
     return pick_tile_heuristic(M, cout)

@@ -118,3 +118,15 @@ def test_host_resize_matches_torch_bilinear_within_one_lsb():
         ref = ref.round().clamp(0, 255)[0].permute(1, 2, 0).numpy().astype(np.int32)
         diff = np.abs(got - ref)
         assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, ((h, w), diff.max(), (diff > 0).mean())
+
+
+def test_derived_skeleton_tables_equal_reference_constants():
+    """dataset/data_settings.py derives limbs and mirror tables from the skeleton tree; the values are
+    the reference's (dataset/data_settings.py:22,28-34)."""
+    from dataset.data_settings import MIX
+    assert MIX.KEYPOINT.FLIP_ORDER == [0, 1, 2, 9, 10, 11, 12, 13, 14, 3, 4, 5, 6, 7, 8]
+    assert MIX.PAF.VECTOR == [[0, 1], [0, 2], [0, 9], [9, 10], [10, 11], [0, 3], [3, 4], [4, 5],
+                              [2, 12], [12, 13], [13, 14], [2, 6], [6, 7], [7, 8]]
+    assert MIX.PAF.FLIP_CHANNEL == [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7, 8, 9,
+                                    22, 23, 24, 25, 26, 27, 16, 17, 18, 19, 20, 21]
+    assert (MIX.INPUT_SHAPE, MIX.OUTPUT_SHAPE, MIX.STRIDE, MIX.ROOT_IDX) == ((512, 832), (128, 208), 4, 2)
