@@ -321,6 +321,7 @@ hipError_t launch(const ConvArgs& a, hipStream_t st)
 //   0..4 : 2-stage (double-buffered) variants; 5..9 : the same tiles with deeper LDS-DMA pipelines
 int smap_conv_tile_dims(int tile, int* bm, int* bn)
 {
+    if (tile >= 10) return smap_conv2_tile_dims(tile, bm, bn);
     switch (tile) {
         case 0: case 5: *bm = 128; *bn = 128; return 0;
         case 1: case 6: *bm = 128; *bn = 64; return 0;
@@ -333,6 +334,7 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
 
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
 {
+    if (tile >= 10) return smap_launch_conv2(a, tile, st);
     switch (tile) {
         case 0: return launch<128, 128, 2, 2, 2>(a, st);
         case 1: return launch<128, 64, 2, 2, 2>(a, st);

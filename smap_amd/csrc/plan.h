@@ -42,3 +42,5 @@ __device__ __forceinline__ Lerp lerp_index(int dst, int in_size, int out_size)
 
 int smap_conv_tile_dims(int tile, int* bm, int* bn);
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st);
+int smap_conv2_tile_dims(int tile, int* bm, int* bn);                       // conv2.hip (tile ids >= 10)
+hipError_t smap_launch_conv2(const ConvArgs& a, int tile, hipStream_t st);

@@ -30,7 +30,10 @@ import os
 
 # tile id -> (BM, BN); ids 5..9 are the same tiles with deeper LDS-DMA pipelines (csrc/conv.hip)
 TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
-         5: (128, 128), 6: (128, 64), 7: (64, 64), 8: (128, 32), 9: (64, 128)}
+         5: (128, 128), 6: (128, 64), 7: (64, 64), 8: (128, 32), 9: (64, 128),
+         # 10..18: csrc/conv2.hip (register epilogue; BK = 32 for 10-13,17; BK = 64 for 14-16,18)
+         10: (128, 128), 11: (128, 64), 12: (64, 64), 13: (64, 128), 14: (128, 128), 15: (128, 64), 16: (64, 64),
+         17: (128, 128), 18: (64, 128)}
 
 
 def _tile_remap():

@@ -108,6 +108,17 @@ CASES = [
     (2, 8, 12, 512, 256, 1, 1, 7, True, True, False),
     (1, 16, 24, 256, 14, 3, 1, 8, False, False, False),
     (1, 32, 52, 256, 512, 1, 2, 9, False, False, False),
+    # second-generation kernel (conv2.hip: BK 32/64, register epilogue), tile ids 10..18
+    (2, 16, 24, 64, 256, 1, 1, 10, False, False, False),
+    (3, 10, 14, 192, 320, 3, 1, 10, True, True, True),
+    (2, 16, 24, 256, 64, 3, 1, 11, True, False, False),
+    (1, 16, 26, 64, 64, 3, 2, 12, True, True, False),
+    (2, 8, 12, 512, 256, 1, 1, 13, True, True, True),
+    (2, 16, 24, 128, 128, 3, 2, 14, True, False, False),
+    (1, 16, 24, 256, 43, 3, 1, 15, False, False, False),
+    (1, 16, 26, 64, 64, 3, 1, 16, True, False, False),
+    (3, 10, 14, 192, 320, 3, 1, 17, True, True, True),
+    (1, 32, 52, 256, 512, 1, 2, 18, False, True, False),
 ]
 
 
