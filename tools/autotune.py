@@ -45,9 +45,14 @@ def main():
     table, total_best, total_default = {}, 0.0, 0.0
     for key, (count, has_res) in sorted(shapes.items()):
         B, H, W, Cin, Cout, k, s = key
-        cands = [t for t, (bm, bn) in TILES.items() if not (Cout <= 32 and bn > 32) and not (Cout <= 64 and bn > 64)]
-        if Cout > 64:
-            cands = [t for t in cands if TILES[t][1] >= 64]
+        if Cout <= 32:
+            cands = [3, 8]
+        elif Cout <= 64:
+            cands = [t for t, (bm, bn) in TILES.items() if bn == 64]
+        else:
+            cands = [t for t, (bm, bn) in TILES.items() if bn >= 64]
+        if has_res is None:
+            pass
         res = {}
         for t in cands:
             lib, h, arena, blob, flops, byts = build(B, H, W, Cin, Cout, k, s, t, int(has_res), dev)
