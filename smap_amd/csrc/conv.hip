@@ -56,6 +56,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
+#ifdef SMAP_TRACE
+    long long tr_t[8]; long long tr_wait = 0;
+    tr_t[0] = __builtin_amdgcn_s_memtime();
+#define TR(i) tr_t[i] = __builtin_amdgcn_s_memtime()
+#else
+#define TR(i)
+#endif
 
     // ---- XCD-aware block order: blocks b, b+8, b+16.. run on one XCD; give each XCD a
     //      contiguous range of logical tiles so that the N-tiles of one M-tile (which
@@ -174,15 +181,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     //      would drain the DMA queue).  RAW: every wave waits for its own slice of tile `it`, then the
     //      barrier publishes all slices.  WAR: the buffer refilled after the barrier held tile it-1,
     //      whose ds_reads were consumed by MFMAs that precede the barrier in program order.
+    TR(1);
 #pragma unroll
     for (int st = 0; st < STAGES - 1; ++st)
         if (st < n_iter && !(SMAP_ABLATE & 1)) stage(st);
     int buf = 0, nbuf = STAGES - 1;
     for (int it = 0; it < n_iter; ++it) {
+#ifdef SMAP_TRACE
+        const long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
         if (it + STAGES - 1 <= n_iter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef SMAP_TRACE
+        tr_wait += __builtin_amdgcn_s_memtime() - tw0;
+        if (it == 0) tr_t[2] = __builtin_amdgcn_s_memtime();
+#endif
         if (it + STAGES - 1 < n_iter && !(SMAP_ABLATE & 1)) stage(nbuf);
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + BM * ROWB;
@@ -205,6 +220,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         buf = buf + 1 == STAGES ? 0 : buf + 1;
         nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
     }
+    TR(3);
     __syncthreads();   // everyone is done reading the staging buffers
     if (SMAP_ABLATE & 8) {
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(a.out)[tid] = acc[0][0][1];   // keep acc live
@@ -299,6 +315,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
             *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + x.o) = h;
         }
     };
+    TR(4);
     Extra ex[2];
     ex[0] = load_pass(0);
 #pragma unroll
@@ -306,6 +323,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         if (p + 1 < PASSES) ex[(p + 1) & 1] = load_pass(p + 1);
         finish_pass(p, ex[p & 1]);
     }
+#ifdef SMAP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR(5);
+    if (a.dbg && tid == 0) {
+        long long* d = a.dbg + (long long)blockIdx.x * 8;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        d[0] = tr_t[0]; d[1] = tr_t[1]; d[2] = tr_t[2]; d[3] = tr_t[3]; d[4] = tr_t[4]; d[5] = tr_t[5]; d[6] = tr_wait; d[7] = hwid;
+    }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES>

@@ -19,6 +19,9 @@ struct ConvArgs {
     int ksize, stride, pad, relu;
     int out_stride_c, out_c_off, out_fp32;
     int M, K, m_tiles, n_tiles;
+#ifdef SMAP_TRACE
+    long long* dbg;          // diagnostics build only (tools/build_ablate.py --trace): per-workgroup phase stamps
+#endif
 };
 
 // ATen's index/weight rule for bilinear align_corners=True (UpSample.h compute_source_index_and_lambda):

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <new>
+#include <cstdlib>
 #include <vector>
 #include "smap_hip.h"
 #include "plan.h"
@@ -330,6 +331,9 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                 a.up = A(o.aux_off[0]);
                 a.up_h = o.aux_h[0];
                 a.up_w = o.aux_w[0];
+#ifdef SMAP_TRACE
+                a.dbg = getenv("SMAP_TRACE_PTR") ? reinterpret_cast<long long*>(strtoull(getenv("SMAP_TRACE_PTR"), nullptr, 0)) : nullptr;
+#endif
                 a.H = o.H; a.W = o.W; a.Cin = o.Cin; a.in_stride_c = o.in_stride_c; a.in_c_off = o.in_c_off;
                 a.Ho = o.Ho; a.Wo = o.Wo; a.Cout8 = (o.Cout + 7) & ~7;
                 a.ksize = o.ksize; a.stride = o.stride; a.pad = o.pad; a.relu = o.relu;

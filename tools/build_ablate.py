@@ -9,6 +9,16 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smap_amd import build as B  # noqa: E402
 
+if "--trace" in sys.argv:       # phase-stamp build: libsmap_hip_trace.so (ConvArgs.dbg <- env SMAP_TRACE_PTR)
+    objs = []
+    for src, extra in B.SOURCES:
+        op = os.path.join(B.OBJ, "trace_" + src.rsplit(".", 1)[0] + ".o")
+        subprocess.check_call([B._hipcc()] + B.COMMON + extra + ["-DSMAP_TRACE=1", "-c", os.path.join(B.CSRC, src), "-o", op])
+        objs.append(op)
+    out = os.path.join(B.OBJ, "libsmap_hip_trace.so")
+    subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    print(out)
+    sys.exit(0)
 for n in [int(x) for x in sys.argv[1:]] or [1, 2, 8, 9, 10]:
     objs = []
     for src, extra in B.SOURCES:
