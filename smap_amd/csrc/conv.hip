@@ -87,23 +87,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
     const int HoWo = a.Ho * a.Wo;
 
-    unsigned a_off[BM / 32];     // byte offset (from the arena base) of tap (0,0), channel granule gch
-    unsigned a_mask[BM / 32];    // bit kh*ksize+kw set <=> that tap is inside the image (and m < M)
+    // Per staged A row: byte offset (from the arena base) of tap (0,0), channel granule gch, and the mask
+    // of in-range taps (bit kh*ksize+kw).  m -> (b, oy, ox) costs two integer divisions ONCE per thread;
+    // the thread's other rows are 32 pixels further along the raster (carry propagation), and the tap
+    // mask is the outer product of three row tests and three column tests (no loop over taps): the
+    // set-up phase was 20-30 % of a short-K workgroup's lifetime (tools/trace_conv.py).
+    unsigned a_off[BM / 32];
+    unsigned a_mask[BM / 32];
+    {
+        int m = m0 + wave * 8 + lrow;
+        int b = m / HoWo, rem = m - b * HoWo;
+        int oy = rem / a.Wo, ox = rem - oy * a.Wo;
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
-        const int m = m0 + i * 32 + wave * 8 + lrow;
-        a_off[i] = 0;
-        a_mask[i] = 0;
-        if (m < a.M) {
-            const int b = m / HoWo, rem = m - b * HoWo;
-            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            const long long e = ((long long)(b * a.H + iy0) * a.W + ix0) * a.in_stride_c + a.in_c_off + gch * 8;
-            a_off[i] = (unsigned)(a.in_off + e * 2);           // wraps for taps above/left of the image; only
-            for (int kh = 0; kh < a.ksize; ++kh)               // used (mod 2^32) when the tap itself is valid
-                for (int kw = 0; kw < a.ksize; ++kw)
-                    if ((unsigned)(iy0 + kh) < (unsigned)a.H && (unsigned)(ix0 + kw) < (unsigned)a.W)
-                        a_mask[i] |= 1u << (kh * a.ksize + kw);
+        for (int i = 0; i < BM / 32; ++i) {
+            a_off[i] = 0;
+            a_mask[i] = 0;
+            if (m < a.M) {
+                const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+                const long long e = ((long long)(b * a.H + iy0) * a.W + ix0) * a.in_stride_c + a.in_c_off + gch * 8;
+                a_off[i] = (unsigned)(a.in_off + e * 2);       // wraps for taps above/left of the image; only
+                unsigned vx = 0, mk = 0;                       // used (mod 2^32) when the tap itself is valid
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    if (kw < a.ksize && (unsigned)(ix0 + kw) < (unsigned)a.W) vx |= 1u << kw;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+                    if (kh < a.ksize && (unsigned)(iy0 + kh) < (unsigned)a.H) mk |= vx << (kh * a.ksize);
+                a_mask[i] = mk;
+            }
+            m += 32;
+            ox += 32;
+            while (ox >= a.Wo) { ox -= a.Wo; ++oy; }
+            while (oy >= a.Ho) { oy -= a.Ho; ++b; }
         }
     }
     unsigned b_off[BN / 32];

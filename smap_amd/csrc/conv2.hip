@@ -67,22 +67,36 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a)
     const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
     const int HoWo = a.Ho * a.Wo;
 
+    // Per staged A row: byte offset of tap (0,0) and the 9-bit mask of in-range taps.  The pixel
+    // decomposition m -> (b, oy, ox) costs two integer divisions ONCE per thread; the thread's other rows
+    // are RPR pixels further along the raster and are reached by carry propagation.  The tap mask is the
+    // outer product of three row tests and three column tests (no loop over taps).
     unsigned a_off[LA], a_mask[LA];
+    {
+        int m = m0 + srow;
+        int b = m / HoWo, rem = m - b * HoWo;
+        int oy = rem / a.Wo, ox = rem - oy * a.Wo;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        const int m = m0 + i * RPR + srow;
-        a_off[i] = 0;
-        a_mask[i] = 0;
-        if (m < a.M) {
-            const int b = m / HoWo, rem = m - b * HoWo;
-            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            const long long e = ((long long)(b * a.H + iy0) * a.W + ix0) * a.in_stride_c + a.in_c_off + gch * 8;
-            a_off[i] = (unsigned)(a.in_off + e * 2);
-            for (int kh = 0; kh < a.ksize; ++kh)
-                for (int kw = 0; kw < a.ksize; ++kw)
-                    if ((unsigned)(iy0 + kh) < (unsigned)a.H && (unsigned)(ix0 + kw) < (unsigned)a.W)
-                        a_mask[i] |= 1u << (kh * a.ksize + kw);
+        for (int i = 0; i < LA; ++i) {
+            a_off[i] = 0;
+            a_mask[i] = 0;
+            if (m < a.M) {
+                const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+                const long long e = ((long long)(b * a.H + iy0) * a.W + ix0) * a.in_stride_c + a.in_c_off + gch * 8;
+                a_off[i] = (unsigned)(a.in_off + e * 2);
+                unsigned vx = 0, mk = 0;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    if (kw < a.ksize && (unsigned)(ix0 + kw) < (unsigned)a.W) vx |= 1u << kw;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+                    if (kh < a.ksize && (unsigned)(iy0 + kh) < (unsigned)a.H) mk |= vx << (kh * a.ksize);
+                a_mask[i] = mk;
+            }
+            m += RPR;
+            ox += RPR;
+            while (ox >= a.Wo) { ox -= a.Wo; ++oy; }
+            while (oy >= a.Ho) { oy -= a.Ho; ++b; }
         }
     }
     unsigned b_off[LB];
