@@ -37,22 +37,26 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 #ifndef SMAP_ABLATE
 #define SMAP_ABLATE 0            // experiments only (tools/build_ablate.py): 1 no loads, 2 no MFMA, 4 no stores, 8 no epilogue
 #endif
-constexpr int BK = 64;            // halves per K chunk
-constexpr int ROWB = BK * 2;      // bytes per LDS row
-
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 {
     static_assert(WM * WN == 4, "4 waves");
     static_assert(STAGES >= 2 && STAGES <= 4, "2..4 LDS stages");
+    static_assert(BK == 32 || BK == 64, "BK = halves per K chunk");
+    constexpr int ROWB = BK * 2;                       // bytes per LDS row
+    constexpr int SPR = ROWB / 16;                     // 16-byte slots per row (8 / 4)
+    constexpr int RPW = 64 / SPR;                      // rows one wave-wide LDS-DMA instruction covers (8 / 16)
+    constexpr int RPR = 4 * RPW;                       // rows per round of the 4 waves (32 / 64)
+    static_assert(BM % RPR == 0 && BN % RPR == 0, "tile must be a multiple of the DMA round");
+    constexpr int LA = BM / RPR, LB = BN / RPR;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     static_assert(MI >= 1 && NI >= 1, "tile too small for the wave grid");
     constexpr int STAGE = (BM + BN) * ROWB;
-    constexpr int LPT = BM / 32 + BN / 32;             // LDS-DMA loads per thread per K tile
+    constexpr int LPT = LA + LB;                       // LDS-DMA loads per thread per K tile
     static_assert((STAGES - 2) * LPT <= 63, "vmcnt is 6 bits");
-    static_assert(STAGES * STAGE >= BM * BN * 4, "epilogue tile must fit in the staging LDS");
-    static_assert(STAGES * STAGE <= 160 * 1024, "LDS is 160 KiB per CU");
-    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE];
+    constexpr int LDS_BYTES = STAGES * STAGE > BM * BN * 4 ? STAGES * STAGE : BM * BN * 4;   // pipeline | fp32 epilogue tile
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS is 160 KiB per CU");
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
@@ -81,8 +85,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     //      the ARENA (whose first 256 bytes are zeros = the padding "zero page"), the B base the
     //      weight matrix.  Per K tile only the uniform part moves, so the loop body carries no
     //      per-lane address arithmetic; the per-lane offsets change once per (kh,kw) tap.
-    const int lrow = lane >> 3, lslot = lane & 7;
-    const int gch = lslot ^ (((wave & 1) << 2) | (lrow >> 1));   // K-granule this lane fetches
+    const int lrow = lane / SPR, lslot = lane % SPR;
+    const int srow = wave * RPW + lrow;                          // row inside a DMA round
+    const int gch = BK == 64 ? (lslot ^ ((srow >> 1) & 7)) : (lslot ^ ((srow >> 2) & 3));   // K-granule this lane fetches
     const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
     const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
     const int HoWo = a.Ho * a.Wo;
@@ -92,14 +97,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     // the thread's other rows are 32 pixels further along the raster (carry propagation), and the tap
     // mask is the outer product of three row tests and three column tests (no loop over taps): the
     // set-up phase was 20-30 % of a short-K workgroup's lifetime (tools/trace_conv.py).
-    unsigned a_off[BM / 32];
-    unsigned a_mask[BM / 32];
+    unsigned a_off[LA];
+    unsigned a_mask[LA];
     {
-        int m = m0 + wave * 8 + lrow;
+        int m = m0 + srow;
         int b = m / HoWo, rem = m - b * HoWo;
         int oy = rem / a.Wo, ox = rem - oy * a.Wo;
 #pragma unroll
-        for (int i = 0; i < BM / 32; ++i) {
+        for (int i = 0; i < LA; ++i) {
             a_off[i] = 0;
             a_mask[i] = 0;
             if (m < a.M) {
@@ -115,16 +120,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
                     if (kh < a.ksize && (unsigned)(iy0 + kh) < (unsigned)a.H) mk |= vx << (kh * a.ksize);
                 a_mask[i] = mk;
             }
-            m += 32;
-            ox += 32;
+            m += RPR;
+            ox += RPR;
             while (ox >= a.Wo) { ox -= a.Wo; ++oy; }
             while (oy >= a.Ho) { oy -= a.Ho; ++b; }
         }
     }
-    unsigned b_off[BN / 32];
+    unsigned b_off[LB];
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i)
-        b_off[i] = (unsigned)(((n0 + i * 32 + wave * 8 + lrow) * a.K + gch * 8) * 2);
+    for (int i = 0; i < LB; ++i)
+        b_off[i] = (unsigned)(((n0 + i * RPR + srow) * a.K + gch * 8) * 2);
 
     const int cchunks = a.Cin / BK;
     const int n_iter = a.ksize * a.ksize * cchunks;
@@ -132,26 +137,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     // staging cursor (all wave-uniform -> SGPRs): tap (s_kh, s_kw), channel chunk s_cc
     int s_kh = 0, s_kw = 0, s_cc = 0;
     unsigned s_boff = 0;                                       // bytes into a weight row: it * 128
-    unsigned a_cur[BM / 32];                                   // per-lane offsets of the current tap (0 = zero page)
+    unsigned a_cur[LA];                                        // per-lane offsets of the current tap (0 = zero page)
     auto set_tap = [&]() {
         const unsigned tap_off = (unsigned)((s_kh * a.W + s_kw) * a.in_stride_c * 2);
         const unsigned bit = 1u << (s_kh * a.ksize + s_kw);
 #pragma unroll
-        for (int i = 0; i < BM / 32; ++i) a_cur[i] = (a_mask[i] & bit) ? a_off[i] + tap_off : 0u;
+        for (int i = 0; i < LA; ++i) a_cur[i] = (a_mask[i] & bit) ? a_off[i] + tap_off : 0u;
     };
     set_tap();
     auto stage = [&](int buf) {
         char* sA = smem + buf * STAGE;
         char* sB = sA + BM * ROWB;
-        const char* gA = arena + (unsigned)(s_cc * (BK * 2));      // invalid taps: a_cur = 0 -> zero page + s_cc*128
+        const char* gA = arena + (unsigned)(s_cc * ROWB);          // invalid taps: a_cur = 0 -> zero page + s_cc*ROWB
         const char* gB = wt + s_boff;
 #pragma unroll
-        for (int i = 0; i < BM / 32; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+        for (int i = 0; i < LA; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
-        s_boff += BK * 2;
+        for (int i = 0; i < LB; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
+        s_boff += ROWB;
         if (++s_cc == cchunks) {
             s_cc = 0;
             if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; }
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int rswz = (l31 >> 1) & 7;
+    const int rswz = BK == 64 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
     const int a_row0 = wm * (BM / WM) + l31;     // + mi*32
     const int b_row0 = wn * (BN / WN) + l31;     // + ni*32
 
@@ -350,10 +355,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64>
 hipError_t launch(const ConvArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -363,8 +368,12 @@ hipError_t launch(const ConvArgs& a, hipStream_t st)
 //   0..4 : 2-stage (double-buffered) variants; 5..9 : the same tiles with deeper LDS-DMA pipelines
 int smap_conv_tile_dims(int tile, int* bm, int* bn)
 {
-    if (tile >= 10) return smap_conv2_tile_dims(tile, bm, bn);
+    if (tile >= 10 && tile < 20) return smap_conv2_tile_dims(tile, bm, bn);
     switch (tile) {
+        case 20: case 24: *bm = 128; *bn = 128; return 0;      // 20..27: BK = 32 staging (smaller LDS, more workgroups per CU)
+        case 21: case 25: *bm = 128; *bn = 64; return 0;
+        case 22: case 26: *bm = 64; *bn = 64; return 0;
+        case 23: case 27: *bm = 64; *bn = 128; return 0;
         case 0: case 5: *bm = 128; *bn = 128; return 0;
         case 1: case 6: *bm = 128; *bn = 64; return 0;
         case 2: case 7: *bm = 64; *bn = 64; return 0;
@@ -376,8 +385,16 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
 
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
 {
-    if (tile >= 10) return smap_launch_conv2(a, tile, st);
+    if (tile >= 10 && tile < 20) return smap_launch_conv2(a, tile, st);
     switch (tile) {
+        case 20: return launch<128, 128, 2, 2, 2, 32>(a, st);   // 64 KiB (fp32 epilogue tile)
+        case 21: return launch<128, 64, 2, 2, 2, 32>(a, st);    // 32 KiB
+        case 22: return launch<64, 64, 2, 2, 2, 32>(a, st);     // 16 KiB
+        case 23: return launch<64, 128, 2, 2, 2, 32>(a, st);    // 32 KiB
+        case 24: return launch<128, 128, 2, 2, 4, 32>(a, st);   // 64 KiB, 3 tiles in flight
+        case 25: return launch<128, 64, 2, 2, 3, 32>(a, st);    // 36 KiB
+        case 26: return launch<64, 64, 2, 2, 4, 32>(a, st);     // 32 KiB
+        case 27: return launch<64, 128, 2, 2, 3, 32>(a, st);    // 36 KiB
         case 0: return launch<128, 128, 2, 2, 2>(a, st);
         case 1: return launch<128, 64, 2, 2, 2>(a, st);
         case 2: return launch<64, 64, 2, 2, 2>(a, st);

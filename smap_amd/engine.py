@@ -33,7 +33,10 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          5: (128, 128), 6: (128, 64), 7: (64, 64), 8: (128, 32), 9: (64, 128),
          # 10..18: csrc/conv2.hip (register epilogue; BK = 32 for 10-13,17; BK = 64 for 14-16,18)
          10: (128, 128), 11: (128, 64), 12: (64, 64), 13: (64, 128), 14: (128, 128), 15: (128, 64), 16: (64, 64),
-         17: (128, 128), 18: (64, 128)}
+         17: (128, 128), 18: (64, 128),
+         # 20..27: csrc/conv.hip with BK = 32 staging (LDS-staged epilogue kept)
+         20: (128, 128), 21: (128, 64), 22: (64, 64), 23: (64, 128), 24: (128, 128), 25: (128, 64), 26: (64, 64),
+         27: (64, 128)}
 
 
 def _tile_remap():

@@ -119,6 +119,15 @@ CASES = [
     (1, 16, 26, 64, 64, 3, 1, 16, True, False, False),
     (3, 10, 14, 192, 320, 3, 1, 17, True, True, True),
     (1, 32, 52, 256, 512, 1, 2, 18, False, True, False),
+    # conv.hip with BK = 32 staging, tile ids 20..27
+    (2, 16, 24, 64, 256, 1, 1, 20, False, True, False),
+    (3, 10, 14, 192, 320, 3, 1, 21, True, True, True),
+    (1, 16, 26, 64, 64, 3, 2, 22, True, False, False),
+    (2, 8, 12, 512, 256, 1, 1, 23, True, True, True),
+    (3, 10, 14, 192, 320, 3, 1, 24, True, True, True),
+    (2, 16, 24, 256, 64, 3, 1, 25, True, False, False),
+    (1, 16, 24, 256, 43, 3, 1, 26, False, False, False),
+    (1, 32, 52, 256, 512, 1, 2, 27, False, True, False),
 ]
 
 
