@@ -92,6 +92,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
     const int HoWo = a.Ho * a.Wo;
 
+    // Weight-tile offsets first, and the weight half of K tile 0 goes out at once: it does not depend on
+    // the pixel arithmetic below, so its L2 latency overlaps the rest of the set-up.
+    unsigned b_off[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i)
+        b_off[i] = (unsigned)(((n0 + i * RPR + srow) * a.K + gch * 8) * 2);
+    auto issue_b = [&](int buf, unsigned boff) {
+        char* sB = smem + buf * STAGE + BM * ROWB;
+        const char* gB = wt + boff;
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
+    };
+    if (!(SMAP_ABLATE & 1)) issue_b(0, 0);
+
     // Per staged A row: byte offset (from the arena base) of tap (0,0), channel granule gch, and the mask
     // of in-range taps (bit kh*ksize+kw).  m -> (b, oy, ox) costs two integer divisions ONCE per thread;
     // the thread's other rows are 32 pixels further along the raster (carry propagation), and the tap
@@ -126,11 +141,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
             while (oy >= a.Ho) { oy -= a.Ho; ++b; }
         }
     }
-    unsigned b_off[LB];
-#pragma unroll
-    for (int i = 0; i < LB; ++i)
-        b_off[i] = (unsigned)(((n0 + i * RPR + srow) * a.K + gch * 8) * 2);
-
     const int cchunks = a.Cin / BK;
     const int n_iter = a.ksize * a.ksize * cchunks;
 
@@ -145,17 +155,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         for (int i = 0; i < LA; ++i) a_cur[i] = (a_mask[i] & bit) ? a_off[i] + tap_off : 0u;
     };
     set_tap();
-    auto stage = [&](int buf) {
+    auto issue_a = [&](int buf) {
         char* sA = smem + buf * STAGE;
-        char* sB = sA + BM * ROWB;
         const char* gA = arena + (unsigned)(s_cc * ROWB);          // invalid taps: a_cur = 0 -> zero page + s_cc*ROWB
-        const char* gB = wt + s_boff;
 #pragma unroll
         for (int i = 0; i < LA; ++i)
             __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < LB; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
+    };
+    auto advance = [&]() {
         s_boff += ROWB;
         if (++s_cc == cchunks) {
             s_cc = 0;
@@ -163,6 +170,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
             set_tap();                 // past the last tap the mask bit is 0 -> offsets 0, never issued anyway
         }
     };
+    auto stage = [&](int buf) {        // all loads of K tile t are issued before any load of tile t+1 (counted vmcnt)
+        issue_a(buf);
+        issue_b(buf, s_boff);
+        advance();
+    };
+    if (!(SMAP_ABLATE & 1)) { issue_a(0); advance(); }           // activation half of K tile 0
 
     // ---- residual prefetch: the epilogue's residual tile (8 channels x PASSES pixels per thread) is
     //      requested before the K loop so that its HBM latency hides under the whole main loop
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     //      whose ds_reads were consumed by MFMAs that precede the barrier in program order.
     TR(1);
 #pragma unroll
-    for (int st = 0; st < STAGES - 1; ++st)
+    for (int st = 1; st < STAGES - 1; ++st)                       // K tile 0 went out during the set-up
         if (st < n_iter && !(SMAP_ABLATE & 1)) stage(st);
     int buf = 0, nbuf = STAGES - 1;
     for (int it = 0; it < n_iter; ++it) {
