@@ -225,3 +225,24 @@ def test_full_size_properties():
     for u, v in zip(a, single):                            # different batch -> different tiling of M
         assert (u[1:2] - v).abs().max().item() <= 2e-2 * u.abs().max().item()
     assert a[0].abs().max().item() > 1e-3
+
+
+def test_full_size_forward_vs_cpu_oracle():
+    """BASELINE configs[1]: batch=1, 3x512x832, forward only -- HIP engine vs the CPU restatement of the
+    reference forward (oracle/backbone_ref.py, fp32), recipe weights.  Tolerance = fp16 activation storage."""
+    from smap_amd.model.smap import SMAP
+    from oracle.backbone_ref import smap_forward
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((128, 208))).eval()
+    sd = recipe_state_dict(net.state_dict())
+    net.load_state_dict(sd)
+    x = torch.randn(1, 3, 512, 832, generator=torch.Generator().manual_seed(1234))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = smap_forward(sd, x)
+    out = [t.cpu() for t in net.to(DEV)(x.to(DEV))]
+    for a, b, k in zip(out, ref, ("hms", "det_d", "root_d")):
+        err = (a - b).abs().max().item() / b.abs().max().item()
+        assert err < 1e-2, (k, err)
+        # the bulk of the map is far tighter than the worst pixel
+        assert ((a - b).abs().mean() / b.abs().mean()).item() < 2e-3, k
