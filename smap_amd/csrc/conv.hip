@@ -37,7 +37,9 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 #ifndef SMAP_ABLATE
 #define SMAP_ABLATE 0            // experiments only (tools/build_ablate.py): 1 no loads, 2 no MFMA, 4 no stores, 8 no epilogue
 #endif
-template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64>
+// FULL = false: epilogue with bias / residual / ReLU only (most layers: ~45 fewer VGPRs, more workgroups per CU);
+// FULL = true : + fused bilinear add and post-ReLU addends.
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 {
     static_assert(WM * WN == 4, "4 waves");
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         const int ms = x.ok ? m : 0, ns = x.ok ? n : 0;            // clamped: loads stay in bounds
         const long long dense = (long long)ms * a.Cout8 + ns;     // res/add tensors are dense [M][Cout8]
         x.o = (long long)ms * a.out_stride_c + a.out_c_off + ns;
-        if (a.up) {
+        if (FULL && a.up) {
             const int b = ms / HoWo, rem = ms - b * HoWo;
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
             const Lerp ly = lerp_index(oy, a.up_h, a.Ho), lx = lerp_index(ox, a.up_w, a.Wo);
@@ -301,8 +303,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
             x.t11 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i1) * a.Cout8);
             x.ly0 = ly.l0; x.ly1 = ly.l1; x.lx0 = lx.l0; x.lx1 = lx.l1;
         }
-        if (a.add1) x.a1 = *reinterpret_cast<const half8*>(a.add1 + dense);
-        if (a.add2) x.a2 = *reinterpret_cast<const half8*>(a.add2 + dense);
+        if (FULL && a.add1) x.a1 = *reinterpret_cast<const half8*>(a.add1 + dense);
+        if (FULL && a.add2) x.a2 = *reinterpret_cast<const half8*>(a.add2 + dense);
         return x;
     };
     auto finish_pass = [&](int p, const Extra& x) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)rres[p][e];
         }
-        if (a.up) {        // Upsample_unit: out = relu(u_skip(x) + up_conv(bilinear_up(prev))) (smap.py:213-217); the
+        if (FULL && a.up) {        // Upsample_unit: out = relu(u_skip(x) + up_conv(bilinear_up(prev))) (smap.py:213-217); the
                            // 1x1 up_conv was applied at low resolution, this is its bilinear resampling
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -328,11 +330,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
-        if (a.add1) {
+        if (FULL && a.add1) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)x.a1[e];
         }
-        if (a.add2) {
+        if (FULL && a.add2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)x.a2[e];
         }
@@ -371,7 +373,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64>
 hipError_t launch(const ConvArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    if (a.up || a.add1 || a.add2)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, true>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
