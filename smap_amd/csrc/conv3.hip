@@ -1,0 +1,276 @@
+// conv3.hip -- 3x3 stride-1 pad-1 conv_bn_relu (model/smap.py:13-45, the Bottleneck 3x3s and the
+// res_* heads) as a HALO-TILED implicit GEMM for gfx950.
+//
+// Why a second 3x3 path: the im2col view of conv.hip fetches every input element nine times, once
+// per tap, through the L2 -> LDS stream that bounds these layers (loads alone are
+// 70-90 % of their time).  Here a workgroup owns a 2-D tile of TH x TW = 128 output pixels; per
+// 64-channel chunk it brings the (TH+2) x (TW+2) input patch into LDS ONCE and serves all nine taps
+// from it (1.4-1.6x the tile instead of 9x); only the 8-16 KB weight tile changes per tap.
+//
+//   K order   : channel chunk cc (outer), tap (kh,kw) (inner) -- weights stay [cout][kh][kw][cin]
+//   LDS       : A patch  2 x PROWS rows x 128 B (row = patch pixel, 16-B slot s holds granule
+//               s ^ ((row>>1)&7), written by LDS-DMA exactly like conv.hip's tile rows)
+//               B tile   NB x BN rows x 128 B
+//   MFMA      : v_mfma_f32_32x32x16_f16; the A fragment of tap (kh,kw) for tile pixel (py,px) is
+//               patch row (py+kh)*(TW+2) + px+kw -- a shifted view, no data movement
+//   pipeline  : iteration = (cc, tap); NB-1 weight tiles and, from tap 0 of a chunk, the next patch are
+//               in flight while the current tap is multiplied (counted vmcnt + raw s_barrier)
+//   epilogue  : fp32 LDS tile -> bias, ReLU -> 16-byte NHWC stores (fp16, or fp32 for the heads)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "smap_hip.h"
+#include "plan.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// s_waitcnt vmcnt(n) for a value that is a constant after unrolling (the switch folds away)
+__device__ __forceinline__ void wait_vm(int n)
+{
+    switch (n) {
+#define W_(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        W_(0) W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15) W_(16)
+        W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24)
+#undef W_
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+template <int BN, int TW, int NB>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int tiles_x, int tiles_y)
+{
+    constexpr int BM = 128, TH = BM / TW, PW = TW + 2, PH = TH + 2;
+    constexpr int PROWS = ((PH * PW + 31) / 32) * 32;          // patch rows rounded to a DMA round (32 rows)
+    constexpr int LA = PROWS / 32, LB = BN / 32;
+    constexpr int ROWB = 128;
+    constexpr int A_BYTES = PROWS * ROWB, B_BYTES = BN * ROWB;
+    constexpr int D = NB - 1;                                   // weight tiles in flight ahead of the one being multiplied
+    static_assert(D >= 1 && D <= 8 && (D - 1) * LB + LA <= 63, "vmcnt is 6 bits");
+    constexpr int PIPE = 2 * A_BYTES + NB * B_BYTES;
+    constexpr int LDS_BYTES = PIPE > BM * BN * 4 ? PIPE : BM * BN * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;           // 2 x 2 waves (wave tile 64 px x BN/2), or 4 x 1 for BN = 32
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+    static_assert(NI >= 1 && MI >= 1, "BN >= 32");
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int logical;                                                // XCD-aware order, n tile fastest
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int n_tile = logical % a.n_tiles;
+    int t = logical / a.n_tiles;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = n_tile * BN;
+
+    // ---- staging offsets (uniform base + 32-bit lane offset; 0 = zero page of the arena)
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int srow = wave * 8 + lrow;
+    const int gch = lslot ^ ((srow >> 1) & 7);                  // (prow>>1)&7 == (srow>>1)&7: rounds are 32 rows
+    const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
+    const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
+
+    unsigned b_off[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) b_off[i] = (unsigned)(((n0 + i * 32 + srow) * a.K + gch * 8) * 2);
+    auto issue_b = [&](int buf, unsigned boff) {
+        char* sB = smem + 2 * A_BYTES + buf * B_BYTES;
+        const char* gB = wt + boff;
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+    };
+    issue_b(0, 0);                                              // weights of (cc 0, tap 0): no pixel math needed
+
+    unsigned a_off[LA];                                         // patch pixel -> byte offset of its channel granule gch
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int prow = i * 32 + srow;
+        const int py = prow / PW, px = prow - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        a_off[i] = 0;
+        if (prow < PH * PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+            const long long e = ((long long)(b * a.H + iy) * a.W + ix) * a.in_stride_c + a.in_c_off + gch * 8;
+            a_off[i] = (unsigned)(a.in_off + e * 2);
+        }
+    }
+    auto issue_a = [&](int buf, int cc) {
+        char* sA = smem + buf * A_BYTES;
+        const char* gA = arena + (unsigned)(cc * ROWB);         // invalid pixels: zero page + cc*128
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_off[i]), (lds_void*)(sA + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+    };
+    issue_a(0, 0);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // tile pixel of this lane's A fragment rows: p = wm*64 + mi*32 + l31 -> (py, px)
+    int prow0[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int p = wm * (MI * 32) + mi * 32 + l31;
+        prow0[mi] = (p / TW) * PW + (p % TW);                   // + kh*PW + kw per tap
+    }
+    const int b_row0 = wn * (BN / WN) + l31;
+    const int bswz = (l31 >> 1) & 7;
+
+    // ---- pipeline.  Flat iteration it = cc*9 + tap needs weight tile it (stage it % NB) and patch cc (stage
+    //      cc & 1).  Weight tiles it+1 .. it+D-1 and, during taps 1..D, the next patch stay in flight across the
+    //      barrier (counted vmcnt: loads retire in issue order).  Issue order per iteration: B(it+D), then at
+    //      tap 0 A(cc+1) -- so A(cc+1) is younger than B(it) exactly while tap <= D.
+    const int cchunks = a.Cin / 64;
+    const int n_iter = cchunks * 9;
+#pragma unroll
+    for (int d = 1; d < D; ++d) issue_b(d, (unsigned)(d * a.Cin * 2));      // taps 1..D-1 of chunk 0 (D <= 9)
+    for (int cc = 0; cc < cchunks; ++cc) {
+        const bool last = cc + 1 == cchunks;
+        const char* sA = smem + (cc & 1) * A_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int it = cc * 9 + tap;
+            if (last) {
+                if (tap + D - 1 >= 9) wait_vm(0);                           // tail: fewer tiles were issued
+                else wait_vm((D - 1) * LB);
+            } else {
+                wait_vm((D - 1) * LB + ((tap >= 1 && tap <= D) ? LA : 0));
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {
+                const int nt = tap + D;                                     // tap index of iteration it+D
+                const int ncc = cc + nt / 9, ntap = nt % 9;
+                if (ncc < cchunks) issue_b((it + D) % NB, (unsigned)((ntap * a.Cin + ncc * 64) * 2));
+                if (tap == 0 && !last) issue_a((cc + 1) & 1, cc + 1);
+            }
+            const char* sB = smem + 2 * A_BYTES + (it % NB) * B_BYTES;
+            const int shift = (tap / 3) * PW + (tap % 3);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int g = kk * 2 + lhi;
+                half8 af[MI], bf[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int prow = prow0[mi] + shift;
+                    af[mi] = *reinterpret_cast<const half8*>(sA + prow * ROWB + ((g ^ ((prow >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    bf[ni] = *reinterpret_cast<const half8*>(sB + (b_row0 + ni * 32) * ROWB + ((g ^ bswz) << 4));
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+    (void)n_iter;
+    __syncthreads();
+
+    // ---- epilogue: acc + bias -> fp32 [128][BN] LDS tile -> ReLU -> 16-byte NHWC stores
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = wn * (BN / WN) + ni * 32 + l31;
+        const float bias = a.bias[n0 + col];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (MI * 32) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                Cs[row * BN + col] = acc[mi][ni][r] + bias;
+            }
+    }
+    __syncthreads();
+    constexpr int CG = BN / 8, PASSES = BM * CG / 256;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int idx = p * 256 + tid;
+        const int row = idx / CG, cg = idx - row * CG;
+        const int oy = oy0 + row / TW, ox = ox0 + row % TW, n = n0 + cg * 8;
+        if (oy >= a.Ho || ox >= a.Wo || n >= a.Cout8) continue;
+        const float4 lo = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        const long long m = ((long long)b * a.Ho + oy) * a.Wo + ox;
+        const long long o = m * a.out_stride_c + a.out_c_off + n;
+        if (a.out_fp32) {
+            float* op = reinterpret_cast<float*>(a.out) + o;
+            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
+            *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + o) = h;
+        }
+    }
+}
+
+template <int BN, int TW, int NB>
+hipError_t launch3(const ConvArgs& a, hipStream_t st)
+{
+    constexpr int TH = 128 / TW;
+    const int B = a.M / (a.Ho * a.Wo);
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a, tiles_x,
+                       tiles_y);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// tile ids 30..39: halo-tiled 3x3 (BM is always 128 output pixels)
+int smap_conv3_tile_dims(int tile, int* bm, int* bn)
+{
+    switch (tile) {
+        case 30: case 32: case 34: case 36: *bm = 128; *bn = 64; return 0;       // 8x16 / 4x32 pixel tiles
+        case 31: case 33: case 35: case 37: *bm = 128; *bn = 128; return 0;
+        case 38: case 39: *bm = 128; *bn = 32; return 0;
+        default: return -1;
+    }
+}
+
+// Only plain 3x3 stride-1 convs qualify (no residual / addends / bilinear add): the schedule's Bottleneck
+// 3x3s and head convs.  Returns hipErrorInvalidValue otherwise (plan validation rejects such ops earlier).
+hipError_t smap_launch_conv3(const ConvArgs& a, int tile, hipStream_t st)
+{
+    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.res || a.add1 || a.add2 || a.up) return hipErrorInvalidValue;
+    switch (tile) {
+        case 30: return launch3<64, 16, 2>(a, st);      //  64 KiB LDS
+        case 31: return launch3<128, 16, 2>(a, st);     //  80 KiB
+        case 32: return launch3<64, 32, 2>(a, st);      //  72 KiB
+        case 33: return launch3<128, 32, 2>(a, st);     //  88 KiB
+        case 34: return launch3<64, 16, 4>(a, st);      //  80 KiB: three weight tiles in flight
+        case 35: return launch3<128, 16, 3>(a, st);     //  96 KiB: two
+        case 36: return launch3<64, 32, 3>(a, st);      //  80 KiB: two
+        case 37: return launch3<128, 32, 3>(a, st);     // 104 KiB: two
+        case 38: return launch3<32, 16, 4>(a, st);      //  64 KiB: Cout <= 32 heads, 4 x 1 waves
+        case 39: return launch3<32, 32, 4>(a, st);      //  72 KiB
+        default: return hipErrorInvalidValue;
+    }
+}

@@ -47,3 +47,5 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn);
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st);
 int smap_conv2_tile_dims(int tile, int* bm, int* bn);                       // conv2.hip (tile ids >= 10)
 hipError_t smap_launch_conv2(const ConvArgs& a, int tile, hipStream_t st);
+int smap_conv3_tile_dims(int tile, int* bm, int* bn);                       // conv3.hip (tile ids 30..33, halo-tiled 3x3)
+hipError_t smap_launch_conv3(const ConvArgs& a, int tile, hipStream_t st);

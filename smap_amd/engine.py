@@ -36,7 +36,11 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          17: (128, 128), 18: (64, 128),
          # 20..27: csrc/conv.hip with BK = 32 staging (LDS-staged epilogue kept)
          20: (128, 128), 21: (128, 64), 22: (64, 64), 23: (64, 128), 24: (128, 128), 25: (128, 64), 26: (64, 64),
-         27: (64, 128)}
+         27: (64, 128),
+         # 30..39: csrc/conv3.hip halo-tiled 3x3 stride-1 (BM = 128 output pixels as an 8x16 / 4x32 patch)
+         30: (128, 64), 31: (128, 128), 32: (128, 64), 33: (128, 128),
+         34: (128, 64), 35: (128, 128), 36: (128, 64), 37: (128, 128),     # 34..37: deeper weight pipeline
+         38: (128, 32), 39: (128, 32)}                                     # Cout <= 32 heads
 
 
 def _tile_remap():
@@ -126,7 +130,7 @@ def pick_tile(M, cout, key=None):
     global _TILE_TABLE
     if _TILE_TABLE is None:
         import json
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json")
+        path = os.environ.get("SMAP_TILE_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json")
         _TILE_TABLE = json.load(open(path)) if os.path.exists(path) and not os.environ.get("SMAP_NO_TILE_TABLE") else {}
     pol = os.environ.get("SMAP_TILE_POLICY", "")
     if pol.startswith("traffic"):       # experiment: minimise L2->LDS bytes subject to a minimum block count
@@ -194,6 +198,15 @@ class Graph:
         M = self.B * Ho * Wo
         tile = pick_tile(M, cout, f"{self.B},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
         tile = {**DEFAULT_REMAP, **_tile_remap()}.get(tile, tile)
+        plain3 = ksize == 3 and stride == 1 and res is None and add1 is None and add2 is None and up is None
+        if tile >= 30 and not plain3:                # the halo-tiled kernel has no fused epilogues (table keyed by shape only)
+            tile = pick_tile_heuristic(M, cout)
+        halo = os.environ.get("SMAP_HALO3", "")     # A/B hook: "16" / "32" = pixel-tile width, optional ":64" / ":128" = BN
+        if halo and plain3 and cout > 32:
+            tw, _, hbn = halo.partition(":")
+            hbn = int(hbn) if hbn else min(TILES[tile][1], 128 if cout > 64 else 64)
+            tile = {(16, 64): 30, (16, 128): 31, (32, 64): 32, (32, 128): 33}[(int(tw), max(hbn, 64))]
+            tile += 4 if os.environ.get("SMAP_HALO3_DEEP") else 0
         bn = TILES[tile][1]
         cout_pad = _rup(cout, bn)
         K = ksize * ksize * cin

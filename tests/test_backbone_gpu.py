@@ -128,6 +128,19 @@ CASES = [
     (2, 16, 24, 256, 64, 3, 1, 25, True, False, False),
     (1, 16, 24, 256, 43, 3, 1, 26, False, False, False),
     (1, 32, 52, 256, 512, 1, 2, 27, False, True, False),
+    # halo-tiled 3x3 stride-1 kernel (conv3.hip), tile ids 30..33: ragged pixel tiles in both directions
+    (2, 16, 24, 64, 64, 3, 1, 30, True, False, False),
+    (3, 10, 14, 192, 320, 3, 1, 31, True, False, False),
+    (1, 16, 26, 128, 64, 3, 1, 32, True, False, False),
+    (2, 13, 52, 256, 256, 3, 1, 33, False, False, False),
+    (1, 16, 24, 256, 43, 3, 1, 30, False, False, False),
+    (1, 9, 40, 64, 128, 3, 1, 32, True, False, False),
+    (1, 16, 24, 256, 14, 3, 1, 38, False, False, False),
+    (2, 10, 40, 128, 1, 3, 1, 39, False, False, False),
+    (2, 16, 24, 128, 128, 3, 1, 34, True, False, False),
+    (1, 12, 20, 192, 256, 3, 1, 35, True, False, False),
+    (1, 16, 36, 64, 64, 3, 1, 36, True, False, False),
+    (1, 16, 36, 128, 256, 3, 1, 37, False, False, False),
 ]
 
 
@@ -145,6 +158,22 @@ def test_single_conv_fp32_out_and_channel_slice():
     got, ref, cout = _run_single_conv(1, 16, 24, 256, 43, 3, 1, 1, False, False, False, out_fp32=True,
                                       in_stride=768, in_off=256, seed=5)
     assert (got[..., :cout] - ref).abs().max().item() < 2e-4 * ref.abs().max().item() + 1e-4
+
+
+@pytest.mark.parametrize("tile", [30, 32])
+def test_halo_conv_fp32_out_and_channel_slice(tile):
+    got, ref, cout = _run_single_conv(1, 16, 24, 256, 43, 3, 1, tile, False, False, False, out_fp32=True,
+                                      in_stride=768, in_off=256, seed=6)
+    assert (got[..., :cout] - ref).abs().max().item() < 2e-4 * ref.abs().max().item() + 1e-4
+
+
+def test_halo_conv_rejects_fused_epilogues():
+    # the halo kernel has no residual / addend path: the plan must refuse such an op, not mis-run it
+    from smap_amd.lib import SmapError
+    with pytest.raises(SmapError):
+        _run_single_conv(1, 16, 24, 64, 64, 3, 1, 30, True, True, False)
+    with pytest.raises(SmapError):
+        _run_single_conv(1, 16, 24, 64, 64, 1, 1, 30, True, False, False)
 
 
 @pytest.fixture(scope="module")

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default=os.path.join(ROOT, "smap_amd", "tile_table.json"))
+    ap.add_argument("--halo", type=float, default=0.0, metavar="GAIN",
+                    help="only revisit the plain 3x3 stride-1 shapes: keep the tile of the existing table unless a "
+                         "halo-tiled variant (csrc/conv3.hip, ids 30..37) is at least GAIN (e.g. 0.05) faster")
     args = ap.parse_args()
     from types import SimpleNamespace as NS
     from smap_amd.model.smap import SMAP
@@ -38,21 +41,30 @@ def main():
             continue
         p, x = op.p, op.inp
         key = (args.batch, x.H, x.W, p["Cin"], p["Cout"], p["ksize"], p["stride"])
-        shapes.setdefault(key, [0, op.res is not None])
+        fused = op.res is not None or op.add1 is not None or op.add2 is not None or bool(op.aux)
+        shapes.setdefault(key, [0, op.res is not None, True])
         shapes[key][0] += 1
+        shapes[key][2] &= not fused                      # halo kernel: plain epilogue only
     dev = torch.device("cuda:0")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     table, total_best, total_default = {}, 0.0, 0.0
-    for key, (count, has_res) in sorted(shapes.items()):
+    old = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table.json"))) if args.halo else {}
+    table.update(old)
+    for key, (count, has_res, plain) in sorted(shapes.items()):
         B, H, W, Cin, Cout, k, s = key
+        halo_ok = plain and k == 3 and s == 1
+        skey = ",".join(map(str, key))
+        if args.halo and not (halo_ok and skey in old):
+            continue
         if Cout <= 32:
-            cands = [3, 8]
+            cands = [3, 8, 38, 39]
         elif Cout <= 64:
             cands = [t for t, (bm, bn) in TILES.items() if bn == 64]
         else:
             cands = [t for t, (bm, bn) in TILES.items() if bn >= 64]
-        if has_res is None:
-            pass
+        cands = [t for t in cands if t < 30 or halo_ok]
+        if args.halo:
+            cands = [old[skey]] + [t for t in cands if t >= 30]
         res = {}
         for t in cands:
             lib, h, arena, blob, flops, byts = build(B, H, W, Cin, Cout, k, s, t, int(has_res), dev)
@@ -71,6 +83,8 @@ def main():
             lib.smap_plan_destroy(h)
             del arena, blob
         best = min(res, key=res.get)
+        if args.halo and res[best] > (1.0 - args.halo) * res[old[skey]]:
+            best = old[skey]
         from smap_amd.engine import pick_tile_heuristic
         dflt = pick_tile_heuristic(B * ((H + 2 * (k // 2) - k) // s + 1) * ((W + 2 * (k // 2) - k) // s + 1), Cout)
         table[",".join(map(str, key))] = best

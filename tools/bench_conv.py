@@ -23,6 +23,8 @@ PRESETS = {          # B, H, W, Cin, Cout, k, stride, tile, residual
     "L6": (8, 16, 26, 512, 512, 3, 1, 2, 0),      # layer4 3x3
     "L7": (8, 64, 104, 128, 512, 1, 1, 0, 1),     # layer2 c3
     "L8": (8, 64, 104, 128, 128, 3, 1, 1, 0),     # layer2 3x3
+    "L9": (8, 128, 208, 256, 43, 3, 1, 2, 0),     # last-stage keypoint/PAF head 3x3
+    "L10": (8, 128, 208, 256, 14, 3, 1, 8, 0),    # last-stage head, Cout 14
 }
 
 
