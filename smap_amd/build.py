@@ -21,6 +21,7 @@ SOURCES = [
     ("conv.hip", []),
     ("conv2.hip", []),
     ("conv3.hip", []),
+    ("conv1.hip", []),
     ("plan.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),

@@ -388,6 +388,7 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
 {
     if (tile >= 10 && tile < 20) return smap_conv2_tile_dims(tile, bm, bn);
     if (tile >= 30 && tile < 40) return smap_conv3_tile_dims(tile, bm, bn);
+    if (tile >= 40 && tile < 50) return smap_conv1_tile_dims(tile, bm, bn);
     switch (tile) {
         case 20: case 24: *bm = 128; *bn = 128; return 0;      // 20..27: BK = 32 staging (smaller LDS, more workgroups per CU)
         case 21: case 25: *bm = 128; *bn = 64; return 0;
@@ -406,6 +407,7 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
 {
     if (tile >= 10 && tile < 20) return smap_launch_conv2(a, tile, st);
     if (tile >= 30 && tile < 40) return smap_launch_conv3(a, tile, st);
+    if (tile >= 40 && tile < 50) return smap_launch_conv1(a, tile, st);
     switch (tile) {
         case 20: return launch<128, 128, 2, 2, 2, 32>(a, st);   // 64 KiB (fp32 epilogue tile)
         case 21: return launch<128, 64, 2, 2, 2, 32>(a, st);    // 32 KiB

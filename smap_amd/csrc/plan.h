@@ -49,3 +49,5 @@ int smap_conv2_tile_dims(int tile, int* bm, int* bn);                       // c
 hipError_t smap_launch_conv2(const ConvArgs& a, int tile, hipStream_t st);
 int smap_conv3_tile_dims(int tile, int* bm, int* bn);                       // conv3.hip (tile ids 30..33, halo-tiled 3x3)
 hipError_t smap_launch_conv3(const ConvArgs& a, int tile, hipStream_t st);
+int smap_conv1_tile_dims(int tile, int* bm, int* bn);                       // conv1.hip (tile ids 40..41, weight-stationary 1x1)
+hipError_t smap_launch_conv1(const ConvArgs& a, int tile, hipStream_t st);

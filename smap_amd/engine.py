@@ -40,7 +40,9 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          # 30..39: csrc/conv3.hip halo-tiled 3x3 stride-1 (BM = 128 output pixels as an 8x16 / 4x32 patch)
          30: (128, 64), 31: (128, 128), 32: (128, 64), 33: (128, 128),
          34: (128, 64), 35: (128, 128), 36: (128, 64), 37: (128, 128),     # 34..37: deeper weight pipeline
-         38: (128, 32), 39: (128, 32)}                                     # Cout <= 32 heads
+         38: (128, 32), 39: (128, 32),                                     # Cout <= 32 heads
+         # 40..41: csrc/conv1.hip weight-stationary persistent 1x1 stride-1 (Cin 64/128/256, 256 channels per workgroup)
+         40: (64, 256), 41: (64, 256)}
 
 
 def _tile_remap():
@@ -201,6 +203,13 @@ class Graph:
         plain3 = ksize == 3 and stride == 1 and res is None and add1 is None and add2 is None and up is None
         if tile >= 30 and not plain3:                # the halo-tiled kernel has no fused epilogues (table keyed by shape only)
             tile = pick_tile_heuristic(M, cout)
+        ws1 = os.environ.get("SMAP_WS1", "")          # A/B hook: "40" / "41" -> weight-stationary kernel for every eligible 1x1
+        if tile >= 40 and not (ksize == 1 and stride == 1 and cin in (64, 128, 256)):
+            tile = pick_tile_heuristic(M, cout)
+        if ws1 and ksize == 1 and stride == 1 and cin in (64, 128, 256) and cout % 256 == 0:
+            lim = os.environ.get("SMAP_WS1_MIN_M", "")
+            if not lim or M >= int(lim):
+                tile = int(ws1)
         halo = os.environ.get("SMAP_HALO3", "")     # A/B hook: "16" / "32" = pixel-tile width, optional ":64" / ":128" = BN
         if halo and plain3 and cout > 32:
             tw, _, hbn = halo.partition(":")

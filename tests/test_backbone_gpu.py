@@ -141,6 +141,13 @@ CASES = [
     (1, 12, 20, 192, 256, 3, 1, 35, True, False, False),
     (1, 16, 36, 64, 64, 3, 1, 36, True, False, False),
     (1, 16, 36, 128, 256, 3, 1, 37, False, False, False),
+    # weight-stationary persistent 1x1 (conv1.hip), tile ids 40..41: K = 64/128/256, ragged M, Cout not a tile multiple
+    (2, 16, 24, 64, 256, 1, 1, 40, False, False, False),
+    (2, 16, 24, 256, 256, 1, 1, 40, True, True, True),
+    (1, 13, 17, 128, 512, 1, 1, 41, True, True, False),
+    (3, 10, 14, 256, 320, 1, 1, 40, True, False, True),
+    (8, 32, 52, 64, 256, 1, 1, 41, True, True, False),
+    (4, 64, 104, 256, 256, 1, 1, 40, True, False, False),      # several tiles per workgroup
 ]
 
 
@@ -174,6 +181,10 @@ def test_halo_conv_rejects_fused_epilogues():
         _run_single_conv(1, 16, 24, 64, 64, 3, 1, 30, True, True, False)
     with pytest.raises(SmapError):
         _run_single_conv(1, 16, 24, 64, 64, 1, 1, 30, True, False, False)
+    with pytest.raises(SmapError):                     # weight-stationary kernel: 1x1 stride-1, Cin <= 256 only
+        _run_single_conv(1, 16, 24, 64, 256, 3, 1, 40, True, False, False)
+    with pytest.raises(SmapError):
+        _run_single_conv(1, 16, 24, 512, 256, 1, 1, 40, True, False, False)
 
 
 @pytest.fixture(scope="module")
@@ -212,6 +223,24 @@ def test_small_schedule_every_tensor_vs_interpreter(golden_dir, small):
     for a, b, k in zip(outs, ref, ("hms", "det_d", "root_d")):
         assert (a - b).abs().max().item() < 5e-3 * b.abs().max().item(), k
         # and against the imported reference model itself
+        assert np.abs(a.numpy() - z[k]).max() < 1e-2 * np.abs(z[k]).max(), k
+
+
+@pytest.mark.parametrize("env", [{"SMAP_WS1": "40"}, {"SMAP_WS1": "41", "SMAP_HALO3": "16"},
+                                 {"SMAP_HALO3": "32", "SMAP_HALO3_DEEP": "1"}], ids=["ws40", "ws41+halo16", "halo32deep"])
+def test_small_schedule_with_specialised_kernels(golden_dir, small, monkeypatch, env):
+    """The whole schedule with every eligible conv routed to the weight-stationary 1x1 / halo-tiled 3x3 kernels
+    (all their fused epilogues: residual, skip addends, bilinear add, fp32 heads) against the golden outputs."""
+    from smap_amd.engine import BackboneEngine
+    _, sd = small
+    z = np.load(f"{golden_dir}/backbone_small.npz")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False)
+    tiles = {op.p["tile"] for op in eng.graph.ops if op.kind == 0}
+    assert any(t >= 30 for t in tiles), tiles
+    outs = [o.cpu() for o in eng.run(torch.from_numpy(z["x"]).to(DEV))]
+    for a, k in zip(outs, ("hms", "det_d", "root_d")):
         assert np.abs(a.numpy() - z[k]).max() < 1e-2 * np.abs(z[k]).max(), k
 
 

@@ -26,8 +26,9 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default=os.path.join(ROOT, "smap_amd", "tile_table.json"))
     ap.add_argument("--halo", type=float, default=0.0, metavar="GAIN",
-                    help="only revisit the plain 3x3 stride-1 shapes: keep the tile of the existing table unless a "
-                         "halo-tiled variant (csrc/conv3.hip, ids 30..37) is at least GAIN (e.g. 0.05) faster")
+                    help="only revisit the shapes the specialised kernels cover: keep the tile of the existing table unless "
+                         "a halo-tiled 3x3 (csrc/conv3.hip, ids 30..39) or weight-stationary 1x1 (csrc/conv1.hip, ids "
+                         "40..41) variant is at least GAIN (e.g. 0.05) faster")
     args = ap.parse_args()
     from types import SimpleNamespace as NS
     from smap_amd.model.smap import SMAP
@@ -54,7 +55,8 @@ def main():
         B, H, W, Cin, Cout, k, s = key
         halo_ok = plain and k == 3 and s == 1
         skey = ",".join(map(str, key))
-        if args.halo and not (halo_ok and skey in old):
+        ws_ok = k == 1 and s == 1 and Cin in (64, 128, 256) and Cout % 256 == 0
+        if args.halo and not ((halo_ok or ws_ok) and skey in old):
             continue
         if Cout <= 32:
             cands = [3, 8, 38, 39]
@@ -62,9 +64,9 @@ def main():
             cands = [t for t, (bm, bn) in TILES.items() if bn == 64]
         else:
             cands = [t for t, (bm, bn) in TILES.items() if bn >= 64]
-        cands = [t for t in cands if t < 30 or halo_ok]
+        cands = [t for t in cands if t < 30 or (halo_ok and t < 40)]
         if args.halo:
-            cands = [old[skey]] + [t for t in cands if t >= 30]
+            cands = [old[skey]] + [t for t in cands if t >= 30] + ([40, 41] if ws_ok else [])
         res = {}
         for t in cands:
             lib, h, arena, blob, flops, byts = build(B, H, W, Cin, Cout, k, s, t, int(has_res), dev)
