@@ -40,6 +40,12 @@ def _build():
     d.OUTPUT_SHAPE = tuple(s // d.STRIDE for s in d.INPUT_SHAPE)
     d.WIDTH_HEIGHT_RATIO = d.INPUT_SHAPE[1] / d.INPUT_SHAPE[0]
     d.PREFIX = os.environ.get("PROJECT_HOME", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    # where the annotated datasets live (data_settings.py:45-54); only the ground-truth modes of test.py read them
+    for name, folder, ann in (("COCO", "coco2017", "coco_keypoints_train2017"), ("MUCO", "MuCo", "MuCo"),
+                              ("CMUP", "Panoptic", "Panoptic"), ("H36M", "Human3.6M", "H36M")):
+        d[name + "_ROOT_PATH"] = os.path.join(d.PREFIX, "data", folder)
+        d[name + "_JSON_PATH"] = os.path.join(d[name + "_ROOT_PATH"], "annotations", ann + ".json")
+    d.USED_3D_DATASETS = ["MUCO"]
     return d
 
 

@@ -23,7 +23,10 @@ def _make():
         MODEL=AttrDict(STAGE_NUM=3, UPSAMPLE_CHANNEL_NUM=256, DEVICE="cuda", WEIGHT=None),
         LOSS=AttrDict(OHKM=True, TOPK=8, COARSE_TO_FINE=True),     # read by SMAP.__init__ only
         RUN_EFFICIENT=False,
-        TEST=AttrDict(IMG_PER_GPU=16),
+        DATALOADER=AttrDict(NUM_WORKERS=int(os.environ.get("SMAP_NUM_WORKERS", 0))),
+        # generate_result / generate_train read the MuPoTS annotations from here (config.py:67-70)
+        TEST=AttrDict(IMG_PER_GPU=16, ROOT_PATH=os.environ.get("SMAP_TEST_ROOT", "/data/MultiPersonTestSet"),
+                      JSON_PATH=osp.join(os.environ.get("SMAP_TEST_ROOT", "/data/MultiPersonTestSet"), "M3E_gt.json")),
     )
 
 

@@ -12,8 +12,11 @@ batched association -> batched lifting (-> RefineNet); only the poses come back,
 post-processing of batch k overlaps the backbone of batch k+1 (smap_amd/pipeline.py).  Launched under
 `torch.distributed.run` the image list is split in contiguous per-rank blocks
 (lib/utils/dataloader.py:80-85) and the records are gathered with one RCCL all_gather.
-Only `run_inference` is implemented; `generate_result` / `generate_train` need the training
-datasets."""
+
+The ground-truth modes (test.py:73-95,142-143) run on the same pipeline: `-t generate_result` registers the
+persons to the annotations of cfg.TEST.JSON_PATH on the device (smap_register_gt) and writes one record per frame
+with the ground truth attached (the input of lib/eval/convert.py); `-t generate_train -d generation|test` writes
+one record per matched person, the RefineNet training pairs (dataset/p2p_dataset.py)."""
 import argparse
 import json
 import logging
@@ -30,6 +33,7 @@ from smap_amd.dist import gather_json, shard_range
 from exps.stage3_root2.config import cfg
 from smap_amd.pipeline import PosePipeline
 from exps.stage3_root2.test_util import default_cams
+from smap_amd.records import annotation_camera, kept_annotations
 
 
 def get_logger(name, log_dir, filename):
@@ -87,15 +91,22 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
             result["3d_pairs"].extend(recs)
 
     for batch in it:
-        imgs, img_path, scales = batch
+        annotations = None
+        if cfg.TEST_MODE == "run_inference":
+            imgs, img_path, scales = batch
+            cams = default_cams(scales, len(imgs))
+        else:                                                    # test.py:50-51,73-95
+            imgs, meta_data, img_path, scales = batch
+            annotations = [kept_annotations(m.numpy(), cfg.DATASET.ROOT_IDX) for m in meta_data]
+            cams = [annotation_camera(a, s) if len(a) else [1.0] * 9 for a, s in zip(annotations, scales)]
         imgs = imgs.to(device, non_blocking=True).float().contiguous()
         if pipe is None or pipe.B != len(imgs):                  # (last) batch of a different size
             if pipe is not None:
                 drain(pipe.flush())
             pipe = PosePipeline(model, cfg, len(imgs), imgs.shape[-2], imgs.shape[-1], device, refine_w,
-                                do_flip=bool(cfg.DO_FLIP))
+                                do_flip=bool(cfg.DO_FLIP), record_mode=cfg.TEST_MODE)
         with torch.no_grad():
-            drain(pipe.submit(imgs, default_cams(scales, len(imgs)), list(img_path)))
+            drain(pipe.submit(imgs, cams, list(img_path), annotations=annotations))
     if pipe is not None:
         drain(pipe.flush())
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -126,8 +137,6 @@ def main():
     parser.add_argument("--device_preprocess", type=int, default=0,
                         help="(addition) 1: resize/pad/normalise on the GPU (smap_preprocess) instead of in the dataset")
     args = parser.parse_args()
-    if args.test_mode != "run_inference":
-        raise NotImplementedError("only -t run_inference is implemented (the other modes need the training datasets)")
     cfg.TEST_MODE = args.test_mode
     cfg.DATA_MODE = args.data_mode
     cfg.REFINE = len(args.RefineNet_path) > 0
@@ -147,12 +156,20 @@ def main():
     device = torch.device(cfg.MODEL.DEVICE, local)
     model.to(device)
 
-    dataset = CustomDataset(cfg, args.dataset_path)
-    indices = range(len(dataset))
-    if world > 1:
-        st, ed = shard_range(len(dataset), world, dist.get_rank())
-        indices = range(st, ed)
-    if args.device_preprocess:
+    if args.test_mode != "run_inference":
+        from lib.utils.dataloader import get_test_loader
+        data_loader = get_test_loader(cfg, num_gpu=world, local_rank=dist.get_rank() if world > 1 else 0,
+                                      stage=args.data_mode)
+        dataset = indices = None
+    else:
+        dataset = CustomDataset(cfg, args.dataset_path)
+        indices = range(len(dataset))
+        if world > 1:
+            st, ed = shard_range(len(dataset), world, dist.get_rank())
+            indices = range(st, ed)
+    if dataset is None:
+        pass
+    elif args.device_preprocess:
         data_loader = DevicePreprocLoader(dataset, indices, args.batch_size, cfg, torch.device(cfg.MODEL.DEVICE, local))
     else:
         data_loader = DataLoader(Subset(dataset, indices) if world > 1 else dataset, batch_size=args.batch_size,

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 import dapalib
+from smap_amd.records import frame_record, train_records
 
 
 def default_cams(scales, n):
@@ -48,16 +49,10 @@ def poses_from_outputs(outputs_2d, outputs_3d, outputs_rd, cams, cfg, refine_wei
 
 
 def save_result(pred_bodys_2d, pred_bodys_3d, gt_bodys, pred_rdepths, img_path, result):
-    """One record of result['3d_pairs'] (test_util.py:146-158)."""
-    pair = dict()
-    pair["pred_2d"] = np.asarray(pred_bodys_2d).tolist()
-    pair["pred_3d"] = np.asarray(pred_bodys_3d).tolist()
-    pair["root_d"] = np.asarray(pred_rdepths).tolist()
-    pair["image_path"] = img_path
-    if gt_bodys is not None:
-        pair["gt_3d"] = gt_bodys[:, :, 4:].tolist()
-        pair["gt_2d"] = gt_bodys[:, :, :4].tolist()
-    else:
-        pair["gt_3d"] = list()
-        pair["gt_2d"] = list()
-    result["3d_pairs"].append(pair)
+    """One per-frame record of result['3d_pairs'] (test_util.py:146-158)."""
+    result["3d_pairs"].append(frame_record(pred_bodys_2d, pred_bodys_3d, pred_rdepths, img_path, gt_bodys))
+
+
+def save_result_for_train_refine(pred_bodys_2d, pred_bodys_3d, gt_bodys, pred_rdepths, result, root_n=2):
+    """One record per matched person, the RefineNet training pairs (test_util.py:134-143)."""
+    result["3d_pairs"].extend(train_records(pred_bodys_2d, pred_bodys_3d, pred_rdepths, gt_bodys, root_n))

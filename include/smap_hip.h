@@ -80,6 +80,27 @@ int smap_lift(const float* bodys, const int32_t* counts, const float* det_d,
 int smap_refine(const float* pred_2d, const double* pred_3d, const int32_t* counts, int B,
                 const float* const* wt, const float* const* bs, double* refined, void* stream);
 
+/* ---- ground-truth modes of test.py (-t generate_result / generate_train), SURVEY.md 8f rank 4 ----
+ * register_pred WITH ground truth (test_util.py:18-42), batched: greedy nearest-root matching (< 30 px,
+ * ties in row-major (annotation, prediction) order) of connect's persons to the kept annotations.
+ * bodys/counts: smap_group's outputs; gt_roots: [B,G,2] fp32 root joint (x,y) of the annotations whose root is
+ * visible (test.py:76-80), network pixels; gt_counts: [B] int32 (<= G <= 64).
+ * matched: [B,127,15,4] fp32 out -- row g = the prediction assigned to annotation g (heat-map pixels) or zeros;
+ * matched_counts: [B] int32 out = gt_counts[b], or 0 when the frame has no prediction / no annotation. */
+int smap_register_gt(const float* bodys, const int32_t* counts, const float* gt_roots,
+                     const int32_t* gt_counts, int B, int G, float* matched, int32_t* matched_counts,
+                     void* stream);
+
+/* smap_lift for those modes: the person array is float64 there (test_util.py:37), so pred_2d is f64 and no
+ * intermediate is rounded to fp32; cams carries the annotation's intrinsics (test.py:84-93). */
+int smap_lift_gt(const float* bodys, const int32_t* counts, const float* det_d, const float* root_d,
+                 const double* cams, int B, int H, int W, double* pred_2d, double* pred_3d, double* root_z,
+                 void* stream);
+
+/* smap_refine on the f64 pred_2d of smap_lift_gt. */
+int smap_refine_gt(const double* pred_2d, const double* pred_3d, const int32_t* counts, int B,
+                   const float* const* wt, const float* const* bs, double* refined, void* stream);
+
 /* refinenet.py:34-37 RefineNet.forward alone: x [N,75] fp32 -> y [N,45] fp32 (same weight format). */
 int smap_refine_mlp(const float* x, int N, const float* const* wt, const float* const* bs, float* y,
                     void* stream);

@@ -41,6 +41,10 @@ def lib():
         _lib.smap_oracle_sort_depth.argtypes = [fp, ip, C.POINTER(C.c_int), fp]
         _lib.smap_oracle_connect.argtypes = [fp, fp, ip, ip, ip, ip, fp, fp, fp]
         _lib.smap_oracle_connect.restype = ip
+        _lib.smap_oracle_register_gt.argtypes = [fp, ip, fp, ip, fp]
+        _lib.smap_oracle_register_gt.restype = ip
+        _lib.smap_oracle_lift_gt.argtypes = [fp, ip, fp, fp, ip, ip, dp, dp, dp, dp]
+        _lib.smap_oracle_refine_gt.argtypes = [dp, dp, ip, C.POINTER(fp), C.POINTER(fp), dp]
     return _lib
 
 
@@ -118,6 +122,45 @@ def refine(pred_2d, pred_3d, weights, biases):
     out = np.zeros((P, NJ, 4), np.float64)
     if P:
         lib().smap_oracle_refine(_f(pred_2d), _d(pred_3d), P, wp, bp, _d(out))
+    return out
+
+
+def register_gt(bodys, gt_root):
+    """register_pred with ground truth (test_util.py:18-42): [G,15,4] fp32 in heat-map pixels."""
+    bodys, gt_root = _c32(bodys), _c32(gt_root)
+    P, Gn = bodys.shape[0], gt_root.shape[0]
+    out = np.zeros((Gn, NJ, 4), np.float32)
+    if Gn:
+        lib().smap_oracle_register_gt(_f(bodys), P, _f(gt_root), Gn, _f(out))
+    return out
+
+
+def lift_gt(bodys, det_d, root_d, cam):
+    """lift() for the ground-truth modes (f64 person array): pred_2d comes back as float64."""
+    bodys, det_d, root_d = _c32(bodys), _c32(det_d), _c32(root_d)
+    cam = np.ascontiguousarray(cam, np.float64)
+    P = bodys.shape[0]
+    _, H, W = det_d.shape
+    p2 = np.zeros((P, NJ, 4), np.float64)
+    p3 = np.zeros((P, NJ, 4), np.float64)
+    rz = np.zeros((P,), np.float64)
+    if P:
+        lib().smap_oracle_lift_gt(_f(bodys), P, _f(det_d), _f(root_d), H, W, _d(cam), _d(p2), _d(p3), _d(rz))
+    return p2, p3, rz
+
+
+def refine_gt(pred_2d, pred_3d, weights, biases):
+    pred_2d = np.ascontiguousarray(pred_2d, np.float64)
+    pred_3d = np.ascontiguousarray(pred_3d, np.float64)
+    P = pred_2d.shape[0]
+    ws = [_c32(w) for w in weights]
+    bs = [_c32(b) for b in biases]
+    fp = C.POINTER(C.c_float)
+    wp = (fp * 5)(*[_f(w) for w in ws])
+    bp = (fp * 5)(*[_f(b) for b in bs])
+    out = np.zeros((P, NJ, 4), np.float64)
+    if P:
+        lib().smap_oracle_refine_gt(_d(pred_2d), _d(pred_3d), P, wp, bp, _d(out))
     return out
 
 

@@ -19,6 +19,7 @@
 //   bodys  [B,127,15,4] (x, y, 0, score) heat-map pixels, persons sorted near -> far
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "smap_hip.h"
 
 namespace {
@@ -458,23 +459,29 @@ __device__ __forceinline__ double np_lerp(double a, double b, double t)
     return t >= 0.5 ? b - d * (1 - t) : a + d * t;
 }
 
+// GT = true: the ground-truth modes of test.py (generate_result / generate_train), where register_pred hands
+// back a FLOAT64 person array (test_util.py:37): the Z column, the un-letter-boxed x / y and the absolute depth
+// are never rounded to fp32, pred_2d is f64, and the root depth is an all-fp32 product (np.float32 map value x
+// Python float scale x np.float32 focal length under numpy 2's weak-scalar promotion).
+template <bool GT>
 __global__ __launch_bounds__(128) void lift_kernel(const float* __restrict__ bodys_all,
                                                    const int* __restrict__ counts,
                                                    const float* __restrict__ det_d_all,
                                                    const float* __restrict__ root_d_all,
                                                    const double* __restrict__ cams, int H, int W,
-                                                   float* __restrict__ pred_2d_all,
+                                                   typename std::conditional<GT, double, float>::type* __restrict__ pred_2d_all,
                                                    double* __restrict__ pred_3d_all,
                                                    double* __restrict__ root_z_all)
 {
+    typedef typename std::conditional<GT, double, float>::type T2;
     constexpr int STRIDE = 4, NPTS = 10, root_n = 2;
     const int b = blockIdx.x, i = threadIdx.x;
     const int P = counts[b];
-    float* p2 = pred_2d_all + ((size_t)b * MAXP + i) * NJ * 4;
+    T2* p2 = pred_2d_all + ((size_t)b * MAXP + i) * NJ * 4;
     double* o = pred_3d_all + ((size_t)b * MAXP + i) * NJ * 4;
     if (i >= MAXP) return;
     if (i >= P) {
-        for (int k = 0; k < NJ * 4; ++k) { p2[k] = 0.f; o[k] = 0.0; }
+        for (int k = 0; k < NJ * 4; ++k) { p2[k] = (T2)0; o[k] = 0.0; }
         root_z_all[(size_t)b * MAXP + i] = 0.0;
         return;
     }
@@ -484,7 +491,8 @@ __global__ __launch_bounds__(128) void lift_kernel(const float* __restrict__ bod
     const double* cam = cams + (size_t)b * 9;
     const double scale = cam[0], img_w = cam[1], img_h = cam[2], net_w = cam[3], net_h = cam[4],
                  fx = cam[5], fy = cam[6], cx = cam[7], cy = cam[8];
-    float bx[NJ], by[NJ], bz[NJ], bs[NJ];
+    float bx[NJ], by[NJ], bs[NJ];
+    T2 bz[NJ];                                   // fp32 storage in run_inference, f64 in the ground-truth modes
     for (int j = 0; j < NJ; ++j) {
         bx[j] = src[4 * j] * (float)STRIDE;
         by[j] = src[4 * j + 1] * (float)STRIDE;
@@ -496,7 +504,8 @@ __global__ __launch_bounds__(128) void lift_kernel(const float* __restrict__ bod
     double rz = 0.0;
     if (bs[root_n] > 0) {
         const int ry = (int)by[root_n], rx = (int)bx[root_n];
-        rz = (double)root_d[(ry / STRIDE) * W + rx / STRIDE] * scale * fx;
+        if (GT) rz = (double)((root_d[(ry / STRIDE) * W + rx / STRIDE] * (float)scale) * (float)fx);
+        else rz = (double)root_d[(ry / STRIDE) * W + rx / STRIDE] * scale * fx;
         for (int k = 0; k < NL; ++k) {
             const int js = c_pairs[2 * k], jd = c_pairs[2 * k + 1];
             if (!(bs[jd] > 0 && bs[js] > 0)) continue;
@@ -531,21 +540,21 @@ __global__ __launch_bounds__(128) void lift_kernel(const float* __restrict__ bod
             r += v[9];
             depth_v[k] = (double)(r / (float)NPTS);
         }
-        bz[2] = 0.f;
-        bz[0] = (float)((double)bz[2] - depth_v[1]);
-        bz[1] = (float)((double)bz[0] + depth_v[0]);
+        bz[2] = (T2)0;
+        bz[0] = (T2)((double)bz[2] - depth_v[1]);
+        bz[1] = (T2)((double)bz[0] + depth_v[0]);
         for (int k = 2; k < NL; ++k)
-            bz[c_pairs[2 * k + 1]] = (float)((double)bz[c_pairs[2 * k]] + depth_v[k]);
+            bz[c_pairs[2 * k + 1]] = (T2)((double)bz[c_pairs[2 * k]] + depth_v[k]);
     }
     root_z_all[(size_t)b * MAXP + i] = rz;
     const bool live = bs[root_n] != 0;
     for (int j = 0; j < NJ; ++j) {
         p2[4 * j] = bx[j]; p2[4 * j + 1] = by[j]; p2[4 * j + 2] = bz[j]; p2[4 * j + 3] = bs[j];
-        const float x = (float)((double)bx[j] / scale - (net_w / scale - img_w) / 2);
-        const float y = (float)((double)by[j] / scale - (net_h / scale - img_h) / 2);
+        const T2 x = (T2)((double)bx[j] / scale - (net_w / scale - img_w) / 2);
+        const T2 y = (T2)((double)by[j] / scale - (net_h / scale - img_h) / 2);
         double X = 0.0, Y = 0.0, Z = 0.0, Sc = bs[j];
         if (live) {
-            const float z = (float)((double)bz[j] + rz);
+            const T2 z = (T2)((double)bz[j] + rz);
             X = ((double)x - cx) * (double)z / fx;
             Y = ((double)y - cy) * (double)z / fy;
             Z = z;
@@ -555,13 +564,82 @@ __global__ __launch_bounds__(128) void lift_kernel(const float* __restrict__ bod
     }
 }
 
+// ------------------------------------------------------- GT registration --
+// register_pred with ground truth (test_util.py:18-42) for the generate_result / generate_train modes: one wave64
+// per frame.  dist[g][p] = |gt root g - predicted root p| in fp32 (sqrt(dx*dx + dy*dy), np.linalg.norm(axis=2));
+// the greedy loop retires the smallest distance < 30 px -- ties in row-major (g, p) order -- and accepts the pair
+// when neither side is taken.  matched[g] = the accepted prediction (heat-map pixels, as connect wrote it) or
+// zeros; matched_counts = number of annotations, or 0 when the frame has no prediction or no annotation (the
+// caller skips such frames, test.py:81-82 / test_util.py:19-20).
+constexpr int REG_MAXG = 64;
+__global__ __launch_bounds__(64) void register_gt_kernel(const float* __restrict__ bodys_all,
+                                                         const int* __restrict__ counts,
+                                                         const float* __restrict__ gt_roots_all,
+                                                         const int* __restrict__ gt_counts, int Gmax,
+                                                         float* __restrict__ matched_all,
+                                                         int* __restrict__ matched_counts)
+{
+    constexpr int root_n = 2;
+    __shared__ float dist[REG_MAXG * MAXP];
+    __shared__ int corres[REG_MAXG];
+    __shared__ int occupied[MAXP];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int P = counts[b];
+    int G = gt_counts[b];
+    G = G < 0 ? 0 : (G > Gmax ? Gmax : G);
+    const float* bodys = bodys_all + (size_t)b * MAXP * NJ * 4;
+    const float* gt = gt_roots_all + (size_t)b * Gmax * 2;
+    float* out = matched_all + (size_t)b * MAXP * NJ * 4;
+    for (int k = lane; k < MAXP * NJ * 4; k += 64) out[k] = 0.f;
+    if (lane == 0) matched_counts[b] = (P > 0 && G > 0) ? G : 0;
+    if (P <= 0 || G <= 0) return;
+    const int n = G * P;
+    for (int k = lane; k < n; k += 64) {
+        const int g = k / P, p = k - g * P;
+        const float px = bodys[(p * NJ + root_n) * 4] * 4.0f, py = bodys[(p * NJ + root_n) * 4 + 1] * 4.0f;
+        const float dx = gt[2 * g] - px, dy = gt[2 * g + 1] - py;
+        dist[k] = sqrtf(dx * dx + dy * dy);
+    }
+    for (int k = lane; k < G; k += 64) corres[k] = -1;
+    for (int k = lane; k < P; k += 64) occupied[k] = 0;
+    __syncthreads();
+    for (;;) {
+        float bv = INFINITY;
+        int bi = 0x7fffffff;
+        for (int k = lane; k < n; k += 64) {
+            const float v = dist[k];
+            if (v < bv) { bv = v; bi = k; }                 // strided scan: the first hit per lane is its lowest index
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ov = __shfl_xor(bv, d);
+            const int oi = __shfl_xor(bi, d);
+            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (!(bv < 30.0f)) break;
+        const int g = bi / P, p = bi - g * P;
+        if (lane == 0) {
+            dist[bi] = 50.0f;
+            if (corres[g] < 0 && !occupied[p]) { corres[g] = p; occupied[p] = 1; }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int k = lane; k < G * NJ * 4; k += 64) {
+        const int g = k / (NJ * 4), e = k - g * (NJ * 4);
+        const int p = corres[g];
+        if (p >= 0) out[k] = bodys[p * NJ * 4 + e];
+    }
+}
+
 // ----------------------------------------------------------------- refine --
 // One workgroup per (frame, person); the 5 layers run back to back with the
 // activations in LDS and the folded, transposed weights [in][out] streamed from L2
 // (thread o reads Wt[k][o]: coalesced across the wave).
 struct RefineW { const float* wt[5]; const float* bs[5]; };
 
-__global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ pred_2d_all,
+// T2 = float: run_inference (fp32 2D offsets); T2 = double: ground-truth modes (f64 offsets, rounded once by `.float()`)
+template <typename T2>
+__global__ __launch_bounds__(256) void refine_kernel(const T2* __restrict__ pred_2d_all,
                                                      const double* __restrict__ pred_3d_all,
                                                      const int* __restrict__ counts, RefineW w,
                                                      double* __restrict__ refined_all)
@@ -575,14 +653,14 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ p
         if (t < NJ * 4) out[t] = 0.0;
         return;
     }
-    const float* p2 = pred_2d_all + ((size_t)b * MAXP + i) * NJ * 4;
+    const T2* p2 = pred_2d_all + ((size_t)b * MAXP + i) * NJ * 4;
     const double* p3 = pred_3d_all + ((size_t)b * MAXP + i) * NJ * 4;
     if (t < 75) {
         const int j = t / 5, d = t % 5;
         double v = 0.0;
         if (j == root_n) v = d < 2 ? (double)p2[4 * j + d] : p3[4 * j + d - 2];
         else if (p3[4 * j + 3] > 0)
-            v = d < 2 ? (double)(float)(p2[4 * j + d] - p2[4 * root_n + d]) : p3[4 * j + d - 2] - p3[4 * root_n + d - 2];
+            v = d < 2 ? (double)(T2)(p2[4 * j + d] - p2[4 * root_n + d]) : p3[4 * j + d - 2] - p3[4 * root_n + d - 2];
         act[0][t] = (float)v;
     }
     __syncthreads();
@@ -746,8 +824,30 @@ int smap_lift(const float* bodys, const int32_t* counts, const float* det_d, con
 {
     if (!bodys || !counts || !det_d || !root_d || !cams || !pred_2d || !pred_3d || !root_z || B <= 0)
         return SMAP_E_ARG;
-    hipLaunchKernelGGL(lift_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, bodys, counts, det_d, root_d,
+    hipLaunchKernelGGL(lift_kernel<false>, dim3(B), dim3(128), 0, (hipStream_t)stream, bodys, counts, det_d, root_d,
                        cams, H, W, pred_2d, pred_3d, root_z);
+    return hip_rc(hipGetLastError());
+}
+
+int smap_lift_gt(const float* bodys, const int32_t* counts, const float* det_d, const float* root_d,
+                 const double* cams, int B, int H, int W, double* pred_2d, double* pred_3d, double* root_z,
+                 void* stream)
+{
+    if (!bodys || !counts || !det_d || !root_d || !cams || !pred_2d || !pred_3d || !root_z || B <= 0)
+        return SMAP_E_ARG;
+    hipLaunchKernelGGL(lift_kernel<true>, dim3(B), dim3(128), 0, (hipStream_t)stream, bodys, counts, det_d, root_d,
+                       cams, H, W, pred_2d, pred_3d, root_z);
+    return hip_rc(hipGetLastError());
+}
+
+int smap_register_gt(const float* bodys, const int32_t* counts, const float* gt_roots, const int32_t* gt_counts,
+                     int B, int G, float* matched, int32_t* matched_counts, void* stream)
+{
+    if (!bodys || !counts || !gt_roots || !gt_counts || !matched || !matched_counts || B <= 0 || G <= 0 ||
+        G > REG_MAXG)
+        return SMAP_E_ARG;
+    hipLaunchKernelGGL(register_gt_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, bodys, counts, gt_roots,
+                       gt_counts, G, matched, matched_counts);
     return hip_rc(hipGetLastError());
 }
 
@@ -761,7 +861,22 @@ int smap_refine(const float* pred_2d, const double* pred_3d, const int32_t* coun
         w.wt[l] = wt[l];
         w.bs[l] = bs[l];
     }
-    hipLaunchKernelGGL(refine_kernel, dim3(MAXP, B), dim3(256), 0, (hipStream_t)stream, pred_2d, pred_3d,
+    hipLaunchKernelGGL(refine_kernel<float>, dim3(MAXP, B), dim3(256), 0, (hipStream_t)stream, pred_2d, pred_3d,
+                       counts, w, refined);
+    return hip_rc(hipGetLastError());
+}
+
+int smap_refine_gt(const double* pred_2d, const double* pred_3d, const int32_t* counts, int B,
+                   const float* const* wt, const float* const* bs, double* refined, void* stream)
+{
+    if (!pred_2d || !pred_3d || !counts || !wt || !bs || !refined || B <= 0) return SMAP_E_ARG;
+    RefineW w;
+    for (int l = 0; l < 5; ++l) {
+        if (!wt[l] || !bs[l]) return SMAP_E_ARG;
+        w.wt[l] = wt[l];
+        w.bs[l] = bs[l];
+    }
+    hipLaunchKernelGGL(refine_kernel<double>, dim3(MAXP, B), dim3(256), 0, (hipStream_t)stream, pred_2d, pred_3d,
                        counts, w, refined);
     return hip_rc(hipGetLastError());
 }

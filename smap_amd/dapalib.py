@@ -110,11 +110,34 @@ def connect_batch(hms, rdepth, rootIdx=2, distFlag=True, return_intermediate=Fal
     return bodys, counts
 
 
-def lift_batch(bodys, counts, det_d, root_d, cams):
+def register_gt_batch(bodys, counts, gt_roots, gt_counts):
+    """register_pred WITH ground truth (test_util.py:18-42) for the generate_result / generate_train modes.
+    bodys [B,127,15,4] / counts [B]: connect_batch's outputs; gt_roots [B,G,2] fp32: root joint (x,y), network
+    pixels, of the annotations whose root is visible (test.py:76-80), zero padded; gt_counts [B] int.
+    -> matched [B,127,15,4] fp32 (row g = prediction assigned to annotation g, or zeros), matched_counts [B]
+    (= gt_counts, or 0 for frames the reference skips: no prediction or no kept annotation)."""
+    B = bodys.shape[0]
+    dev = bodys.device
+    gt_roots = torch.as_tensor(gt_roots, dtype=torch.float32).to(dev).contiguous()
+    gt_counts = torch.as_tensor(gt_counts).to(device=dev, dtype=torch.int32).contiguous()
+    if gt_roots.dim() != 3 or gt_roots.shape[0] != B or gt_roots.shape[2] != 2 or not 0 < gt_roots.shape[1] <= 64:
+        raise ValueError("gt_roots must be [B,G,2] with 1 <= G <= 64")
+    if tuple(gt_counts.shape) != (B,):
+        raise ValueError("gt_counts must be [B]")
+    matched = torch.empty((B, MAXP, NJ, 4), dtype=torch.float32, device=dev)
+    mcounts = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _L.check(_L.load().smap_register_gt(_p(bodys), _p(counts), _p(gt_roots), _p(gt_counts), B, gt_roots.shape[1],
+                                            _p(matched), _p(mcounts), _stream()), "smap_register_gt")
+    return matched, mcounts
+
+
+def lift_batch(bodys, counts, det_d, root_d, cams, gt_mode=False):
     """Batched 3D lifting (test.py:116-134, test_util.py:45-99, post_3d.py).
     det_d [B,14,H,W], root_d [B,H,W] or [B,1,H,W], cams [B,9] float64
     (scale,img_w,img_h,net_w,net_h,f_x,f_y,cx,cy).
-    -> pred_2d [B,127,15,4] fp32, pred_3d [B,127,15,4] f64, root_z [B,127] f64 (device)."""
+    -> pred_2d [B,127,15,4] fp32, pred_3d [B,127,15,4] f64, root_z [B,127] f64 (device).
+    gt_mode: the float64 person array of the ground-truth modes (pred_2d comes back as f64)."""
     B = bodys.shape[0]
     if root_d.dim() == 4:
         root_d = root_d[:, 0]
@@ -127,12 +150,13 @@ def lift_batch(bodys, counts, det_d, root_d, cams):
     cams = torch.as_tensor(cams, dtype=torch.float64).to(dev).contiguous()
     if tuple(cams.shape) != (B, 9):
         raise ValueError("cams must be [B,9]")
-    p2 = torch.empty((B, MAXP, NJ, 4), dtype=torch.float32, device=dev)
+    p2 = torch.empty((B, MAXP, NJ, 4), dtype=torch.float64 if gt_mode else torch.float32, device=dev)
     p3 = torch.empty((B, MAXP, NJ, 4), dtype=torch.float64, device=dev)
     rz = torch.empty((B, MAXP), dtype=torch.float64, device=dev)
+    fn = _L.load().smap_lift_gt if gt_mode else _L.load().smap_lift
     with torch.cuda.device(dev):
-        _L.check(_L.load().smap_lift(_p(bodys), _p(counts), _p(det_d), _p(root_d), _p(cams), B, H, W,
-                                     _p(p2), _p(p3), _p(rz), _stream()), "smap_lift")
+        _L.check(fn(_p(bodys), _p(counts), _p(det_d), _p(root_d), _p(cams), B, H, W, _p(p2), _p(p3), _p(rz), _stream()),
+                 "smap_lift_gt" if gt_mode else "smap_lift")
     return p2, p3, rz
 
 
@@ -144,9 +168,11 @@ def refine_batch(pred_2d, pred_3d, counts, wt, bs):
     out = torch.empty((B, MAXP, NJ, 4), dtype=torch.float64, device=dev)
     wp = (C.c_void_p * 5)(*[w.data_ptr() for w in wt])
     bp = (C.c_void_p * 5)(*[b.data_ptr() for b in bs])
+    gt_mode = pred_2d.dtype == torch.float64       # the f64 pred_2d of lift_batch(gt_mode=True)
+    fn = _L.load().smap_refine_gt if gt_mode else _L.load().smap_refine
     with torch.cuda.device(dev):
-        _L.check(_L.load().smap_refine(_p(pred_2d), _p(pred_3d), _p(counts), B, wp, bp, _p(out), _stream()),
-                 "smap_refine")
+        _L.check(fn(_p(pred_2d), _p(pred_3d), _p(counts), B, wp, bp, _p(out), _stream()),
+                 "smap_refine_gt" if gt_mode else "smap_refine")
     return out
 
 

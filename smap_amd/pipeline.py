@@ -19,8 +19,10 @@ import numpy as np
 import torch
 
 from . import dapalib
+from .records import frame_record, train_records
 
 NJ, MAXP = 15, 127
+MAXG = 64                       # annotations per frame the registration kernel accepts (cfg.DATASET.MAX_PEOPLE = 20)
 
 
 class _Slot:
@@ -33,6 +35,7 @@ class _Slot:
         self.host = [dict(p2=mk((B, MAXP, NJ, 4), torch.float32), p3=mk((B, MAXP, NJ, 4), torch.float64),
                           rz=mk((B, MAXP), torch.float64), counts=mk((B,), torch.int32))
                      for _ in range(1 + n_extra)]
+        self.p2_f64 = None               # ground-truth modes: the f64 pred_2d (allocated on first use)
         self.ev_bb = torch.cuda.Event()
         self.ev_post = torch.cuda.Event()
         self.meta = None
@@ -40,7 +43,13 @@ class _Slot:
 
 
 class PosePipeline:
-    def __init__(self, model, cfg, batch, H, W, device, refine_weights=None, n_extra=0, do_flip=False, depth=1):
+    def __init__(self, model, cfg, batch, H, W, device, refine_weights=None, n_extra=0, do_flip=False, depth=1,
+                 record_mode="run_inference"):
+        """record_mode: test.py's -t: "run_inference" (no ground truth), "generate_result" (one record per frame
+        with the annotations attached) or "generate_train" (one record per matched person); the last two need
+        `annotations=` in submit()."""
+        assert record_mode in ("run_inference", "generate_result", "generate_train")
+        self.record_mode = record_mode
         self.device = torch.device(device)
         self.cfg = cfg
         self.B, self.do_flip = batch, bool(do_flip)
@@ -61,22 +70,47 @@ class PosePipeline:
         self.bb_events = []              # (start, end) HIP events of timed backbone runs
 
     # -- device side -------------------------------------------------------------------------
-    def _post(self, slot, idx, hms, det_d, root_d, cams, scale):
-        """Association + lifting of one set of maps on the post stream; results -> pinned memory."""
+    def _post(self, slot, idx, hms, det_d, root_d, cams, scale, gt=None):
+        """Association + lifting of one set of maps on the post stream; results -> pinned memory.
+        gt = (gt_roots [B,G,2], gt_counts [B]) on the device: register the persons to the annotations first
+        (test_util.py:18-42) and lift in the f64 flavour of the ground-truth modes."""
         if scale:
             dapalib.scale_hms_(hms)                                             # test.py:111-112
         bodys, counts = dapalib.connect_batch(hms, root_d, self.cfg.DATASET.ROOT_IDX, True)
-        p2, p3, rz = dapalib.lift_batch(bodys, counts, det_d, root_d, cams)
+        if gt is not None:
+            bodys, counts = dapalib.register_gt_batch(bodys, counts, *gt)
+        p2, p3, rz = dapalib.lift_batch(bodys, counts, det_d, root_d, cams, gt_mode=gt is not None)
         if self.refine is not None:
             p3 = dapalib.refine_batch(p2, p3, counts, *self.refine)
         h = slot.host[idx]
-        for k, t in (("p2", p2), ("p3", p3), ("rz", rz), ("counts", counts)):
+        if gt is not None:
+            if slot.p2_f64 is None:
+                slot.p2_f64 = torch.empty(tuple(p2.shape), dtype=torch.float64).pin_memory()
+            slot.p2_f64.copy_(p2, non_blocking=True)
+        else:
+            h["p2"].copy_(p2, non_blocking=True)
+        for k, t in (("p3", p3), ("rz", rz), ("counts", counts)):
             h[k].copy_(t, non_blocking=True)
 
-    def submit(self, imgs, cams, tags, extra=(), time_backbone=False):
+    def submit(self, imgs, cams, tags, extra=(), time_backbone=False, annotations=None):
         """imgs [B,3,H,W] fp32 on the device; cams [B,9] float64 (host array); tags: B image names.
         extra: tuples (tag_prefix, hms, root_d, det_d) of already-scaled maps to associate as well
-        (bench only).  Returns the record list of the previous batch or None."""
+        (bench only).  annotations (ground-truth modes): B arrays [G_i,15,C] of the KEPT annotations of each
+        frame (records.kept_annotations; G_i may be 0 -- the frame is skipped, test.py:81-82).
+        Returns the record list of the previous batch or None."""
+        gt = None
+        if self.record_mode != "run_inference":
+            if annotations is None or len(annotations) != len(tags):
+                raise ValueError("record_mode %r needs one annotation array per frame" % self.record_mode)
+            gmax = max(1, max(len(a) for a in annotations))
+            if gmax > MAXG:
+                raise ValueError("at most %d annotations per frame" % MAXG)
+            roots = np.zeros((len(tags), gmax, 2), np.float32)
+            for i, a in enumerate(annotations):
+                if len(a):
+                    roots[i, :len(a)] = np.asarray(a)[:, self.cfg.DATASET.ROOT_IDX, :2]
+            gt = (torch.from_numpy(roots).to(self.device, non_blocking=True),
+                  torch.tensor([len(a) for a in annotations], dtype=torch.int32).to(self.device, non_blocking=True))
         slot = self.slots[self.k % self.nslots]
         eng, s_bb = self.engines[self.k % self.depth], self.s_bbs[self.k % self.depth]
         ready = self._collect(slot) if slot.busy else None       # the batch submitted nslots calls ago ...
@@ -86,6 +120,9 @@ class PosePipeline:
         self.s_post.wait_stream(cur)
         imgs.record_stream(s_bb)
         cams_d.record_stream(self.s_post)
+        if gt is not None:
+            gt[0].record_stream(self.s_post)
+            gt[1].record_stream(self.s_post)
         with torch.cuda.stream(s_bb):
             if time_backbone:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -101,11 +138,11 @@ class PosePipeline:
             slot.ev_bb.record()
         with torch.cuda.stream(self.s_post):
             self.s_post.wait_event(slot.ev_bb)
-            self._post(slot, 0, slot.hms, slot.det_d, slot.root_d, cams_d, scale=True)
+            self._post(slot, 0, slot.hms, slot.det_d, slot.root_d, cams_d, scale=True, gt=gt)
             for j, (tag, hms, rd, dd) in enumerate(extra):
                 self._post(slot, 1 + j, hms, slot.det_d if dd is None else dd, rd, cams_d, scale=False)
             slot.ev_post.record()
-        slot.meta = (list(tags), [t for t, *_ in extra])
+        slot.meta = (list(tags), [t for t, *_ in extra], annotations)
         slot.busy = True
         self.k += 1
         # ... or, more eagerly, the oldest batch once `depth` newer ones are queued behind it
@@ -127,17 +164,23 @@ class PosePipeline:
     # -- host side ---------------------------------------------------------------------------
     def _collect(self, slot):
         slot.ev_post.synchronize()
-        tags, extra_tags = slot.meta
+        tags, extra_tags, annotations = slot.meta
         recs = []
         for idx, h in enumerate(slot.host):
             counts = h["counts"].numpy()
-            p2, p3, rz = h["p2"].numpy(), h["p3"].numpy(), h["rz"].numpy()
+            gt_mode = idx == 0 and annotations is not None
+            p2 = slot.p2_f64.numpy() if gt_mode else h["p2"].numpy()
+            p3, rz = h["p3"].numpy(), h["rz"].numpy()
             for i, P in enumerate(counts):
                 P = int(P)
                 if P == 0:
-                    continue                                                    # test.py:131-132
+                    continue                                                    # test.py:81-82,131-132
                 name = tags[i] if idx == 0 else f"{extra_tags[idx - 1]}/{tags[i]}"
-                recs.append({"pred_2d": p2[i, :P].tolist(), "pred_3d": p3[i, :P].tolist(),
-                             "root_d": rz[i, :P].tolist(), "image_path": name, "gt_3d": [], "gt_2d": []})
+                if gt_mode and self.record_mode == "generate_train":            # test.py:142-143
+                    recs.extend(train_records(p2[i, :P], p3[i, :P], rz[i, :P], np.asarray(annotations[i]),
+                                              self.cfg.DATASET.ROOT_IDX))
+                else:
+                    recs.append(frame_record(p2[i, :P], p3[i, :P], rz[i, :P], name,
+                                             np.asarray(annotations[i]) if gt_mode else None))
         slot.busy = False
         return recs

@@ -65,7 +65,7 @@ def test_smap_forward_has_no_cpu_path():
 def test_product_never_imports_oracle():
     """The oracle is test infrastructure: nothing under the product tree may reference it."""
     bad = []
-    for base in ("smap_amd", "model", "exps", "dapalib.py"):
+    for base in ("smap_amd", "model", "exps", "dataset", "lib", "dapalib.py"):
         p = os.path.join(ROOT, base)
         files = [p] if os.path.isfile(p) else [os.path.join(d, f) for d, _, fs in os.walk(p) for f in fs
                                                if f.endswith((".py", ".hip", ".h", ".cpp"))]

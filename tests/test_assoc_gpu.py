@@ -152,6 +152,76 @@ def test_lift_and_refine_match_reference_golden(golden_dir):
         assert np.array_equal(p3[c, :P], o3) and np.array_equal(p2[c, :P], o2) and np.array_equal(rz[c, :P], orz)
 
 
+def test_ground_truth_modes_match_reference_golden(golden_dir):
+    """register_gt + f64 lifting + RefineNet on the device against the imported reference (lift_gt.npz) and,
+    bit for bit, against the CPU oracle."""
+    import dapalib
+    from smap_amd.model.refinenet import RefineNet
+    z = np.load(f"{golden_dir}/lift_gt.npz")
+    net = RefineNet().eval()
+    net.load_state_dict(recipe_state_dict(net.state_dict()))
+    wt, bs = net.folded(DEV)
+    n, G = int(z["n_cases"]), 20
+    bodys = torch.zeros(n, 127, 15, 4)
+    counts = torch.zeros(n, dtype=torch.int32)
+    gt_roots = torch.zeros(n, G, 2)
+    gt_counts = torch.zeros(n, dtype=torch.int32)
+    det, root, cams = [], [], []
+    for c in range(n):
+        p = f"c{c}_"
+        b = z[p + "bodys"]
+        bodys[c, :len(b)] = torch.from_numpy(b)
+        counts[c] = len(b)
+        ann = z[p + "ann"]
+        kept = ann[ann[:, 2, 3] > 1]                                   # test.py:76-80
+        gt_roots[c, :len(kept)] = torch.from_numpy(kept[:, 2, :2])
+        gt_counts[c] = len(kept)
+        det.append(expand(z[p + "det_c"], 0.05))
+        root.append(expand(z[p + "root_c"], 0.002)[0])
+        cams.append(z[p + "cam"] if not int(z[p + "empty"]) else np.ones(9))
+    matched, mc = dapalib.register_gt_batch(bodys.to(DEV), counts.to(DEV), gt_roots, gt_counts)
+    p2, p3, rz = dapalib.lift_batch(matched, mc, torch.from_numpy(np.stack(det)).to(DEV),
+                                    torch.from_numpy(np.stack(root)).to(DEV), np.stack(cams), gt_mode=True)
+    ref = dapalib.refine_batch(p2, p3, mc, wt, bs)
+    assert p2.dtype == torch.float64
+    mc, p2, p3, rz, ref = mc.cpu().numpy(), p2.cpu().numpy(), p3.cpu().numpy(), rz.cpu().numpy(), ref.cpu().numpy()
+    for c in range(n):
+        p = f"c{c}_"
+        if int(z[p + "empty"]):
+            assert mc[c] == 0 and not p3[c].any()                      # the reference skips such frames
+            continue
+        P = len(z[p + "gt"])
+        assert mc[c] == P
+        assert np.array_equal(p2[c, :P], z[p + "matched"])             # matching + Z column, bit-exact
+        assert np.array_equal(p3[c, :P], z[p + "pred_3d"]) and np.array_equal(rz[c, :P], z[p + "root_z"])
+        assert np.abs(ref[c, :P] - z[p + "refined"]).max() < 1e-2
+        assert not p3[c, P:].any() and not ref[c, P:].any()
+        W, Bv = [w.t().contiguous().cpu().numpy() for w in wt], [b.cpu().numpy() for b in bs]
+        assert np.array_equal(ref[c, :P], O.refine_gt(p2[c, :P], p3[c, :P], W, Bv))
+
+
+def test_register_gt_random_vs_oracle():
+    import dapalib
+    rng = np.random.default_rng(5)
+    B, G = 6, 24
+    bodys = np.zeros((B, 127, 15, 4), np.float32)
+    counts = np.array([0, 1, 9, 40, 127, 17], np.int32)
+    gtc = np.array([3, 0, 24, 20, 11, 1], np.int32)
+    gt = np.zeros((B, G, 2), np.float32)
+    for b in range(B):
+        bodys[b, :counts[b], :, :2] = rng.integers(0, 52, (counts[b], 15, 2)) * 4 + 0.5   # coarse grid: many exact ties
+        bodys[b, :counts[b], :, 3] = rng.uniform(0.2, 1, (counts[b], 15))
+        gt[b, :gtc[b]] = rng.integers(0, 104, (gtc[b], 2)) * 8 + 2.0
+    m, mc = dapalib.register_gt_batch(torch.from_numpy(bodys).to(DEV), torch.from_numpy(counts).to(DEV), gt, gtc)
+    m, mc = m.cpu().numpy(), mc.cpu().numpy()
+    for b in range(B):
+        if counts[b] == 0 or gtc[b] == 0:
+            assert mc[b] == 0 and not m[b].any()
+            continue
+        want = O.register_gt(bodys[b, :counts[b]], gt[b, :gtc[b]])
+        assert mc[b] == gtc[b] and np.array_equal(m[b, :gtc[b]], want) and not m[b, gtc[b]:].any()
+
+
 def test_refinenet_forward_matches_golden(golden_dir):
     from model.refinenet import RefineNet
     z = np.load(f"{golden_dir}/refine.npz")

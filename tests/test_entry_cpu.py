@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -130,3 +131,94 @@ def test_derived_skeleton_tables_equal_reference_constants():
     assert MIX.PAF.FLIP_CHANNEL == [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7, 8, 9,
                                     22, 23, 24, 25, 26, 27, 16, 17, 18, 19, 20, 21]
     assert (MIX.INPUT_SHAPE, MIX.OUTPUT_SHAPE, MIX.STRIDE, MIX.ROOT_IDX) == ((512, 832), (128, 208), 4, 2)
+
+
+def test_record_builders_reproduce_reference_json(golden_dir):
+    """frame_record / train_records (test_util.py:134-158) on the golden arrays give the reference's JSON."""
+    from smap_amd.records import annotation_camera, frame_record, kept_annotations, train_records
+    z = np.load(f"{golden_dir}/lift_gt.npz")
+    seen = 0
+    for c in range(int(z["n_cases"])):
+        p = f"c{c}_"
+        ann = z[p + "ann"]
+        gt = kept_annotations(ann)
+        if int(z[p + "empty"]):
+            continue
+        assert np.array_equal(gt, z[p + "gt"])
+        want_r = json.loads(bytes(z[p + "json_result"]).decode())["3d_pairs"]
+        want_t = json.loads(bytes(z[p + "json_train"]).decode())["3d_pairs"]
+        got_r = frame_record(z[p + "matched"], z[p + "refined"], z[p + "root_z"], want_r[0]["image_path"], gt)
+        assert [got_r] == want_r
+        assert train_records(z[p + "matched"], z[p + "refined"], z[p + "root_z"], gt) == want_t
+        s, w, h = z[p + "scale"]
+        cam = annotation_camera(gt, {"scale": s, "img_width": w, "img_height": h, "net_width": 832, "net_height": 512})
+        assert np.array_equal(cam, z[p + "cam"])
+        seen += len(want_t)
+    assert seen > 0
+    # annotations without intrinsics columns: f from column 7, principal point at the image centre (test.py:84-88)
+    short = np.zeros((1, 15, 8), np.float32)
+    short[0, :, 7] = 1234.5
+    cam = annotation_camera(short, {"scale": 0.5, "img_width": 640, "img_height": 480, "net_width": 832, "net_height": 512})
+    assert cam.tolist() == [0.5, 640, 480, 832, 512, 1234.5, 1234.5, 320, 240]
+
+
+def test_p2p_dataset_matches_reference_golden(golden_dir, tmp_path):
+    from dataset.p2p_dataset import P2PDataset
+    z = np.load(f"{golden_dir}/p2p.npz")
+    path = tmp_path / "train.json"
+    path.write_text(bytes(z["json"]).decode())
+    ds = P2PDataset(dataset_path=str(path))
+    assert len(ds) == len(z["inp"])
+    for i in range(len(ds)):
+        a, b = ds[i]
+        assert a.dtype == torch.float32 and np.array_equal(a.numpy(), z["inp"][i]) and np.array_equal(b.numpy(), z["gt"][i])
+
+
+def test_joint_dataset_croppad_and_loader(tmp_path):
+    """The no-augmentation aug_croppad (ImageAugmentation.py:54-111): geometry, annotation transform, the
+    off-canvas rule, the isValidation split and the contiguous per-rank split of get_test_loader."""
+    from exps.stage3_root2.config import cfg
+    from dataset.base_dataset import JointDataset, croppad_geometry
+    from lib.utils.dataloader import get_test_loader
+    # 1920x1080: scale 832/1920, resized 832x468, pasted 22 rows down; 2048x2048: scale 0.25, 512x512, 160 columns in
+    s, (nh, nw), (left, top) = croppad_geometry(1920, 1080, 832, 512)
+    assert (nh, nw, left, top) == (468, 832, 0, 22) and s == 832 / 1920
+    s, (nh, nw), (left, top) = croppad_geometry(2048, 2048, 832, 512)
+    assert (nh, nw, left, top, s) == (512, 512, 160, 0, 0.25)
+    # a frame larger than the canvas in one direction after scaling cannot happen (scale = min ratio); odd sizes:
+    s, (nh, nw), (left, top) = croppad_geometry(641, 479, 832, 512)
+    assert nw <= 832 and nh <= 512 and left == int(416 - int(320 * s)) and top == int(256 - int(239 * s))
+    root = tmp_path / "set"
+    root.mkdir()
+    rng = np.random.default_rng(0)
+    entries = []
+    for i, (h, w) in enumerate([(1080, 1920), (2048, 2048), (480, 640), (512, 832), (300, 400)]):
+        np.save(root / f"f{i}.npy", rng.integers(0, 255, (h, w, 3), dtype=np.uint8))
+        bodys = np.zeros((2, 15, 11))
+        bodys[0, :, 0], bodys[0, :, 1], bodys[0, :, 3] = w / 2, h / 2, 2          # image centre
+        bodys[1, :, 0], bodys[1, :, 1], bodys[1, :, 3] = -5.0, h / 2, 2          # left of the image
+        bodys[:, :, 7:] = [1000, 1001, w / 2, h / 2]
+        entries.append({"dataset": "muco", "img_paths": f"f{i}.npy", "img_width": w, "img_height": h,
+                        "isValidation": int(i != 4), "bodys": bodys.tolist()})
+    (root / "gt.json").write_text(json.dumps({"root": entries}))
+    cfg.TEST.ROOT_PATH, cfg.TEST.JSON_PATH = str(root), str(root / "gt.json")
+    ds = JointDataset(cfg, "test")
+    assert len(ds) == 4
+    img, meta, path, scale = ds[0]
+    assert img.shape == (3, 512, 832) and meta.shape == (cfg.DATASET.MAX_PEOPLE, 15, 11) and meta.dtype == torch.float32
+    assert path == "f0.npy" and scale == {"scale": 832 / 1920, "img_width": 1920, "img_height": 1080,
+                                          "net_width": 832, "net_height": 512}
+    assert torch.allclose(meta[0, :, :2], torch.tensor([416.0, 256.0]).expand(15, 2))     # centre -> canvas centre
+    assert (meta[0, :, 3] == 2).all() and (meta[1, :, 3] == 0).all()                       # off-canvas joints: score 0
+    assert not meta[2:].any()
+    grey = (128 / 255 - torch.tensor(cfg.INPUT.MEANS)) / torch.tensor(cfg.INPUT.STDS)
+    assert torch.allclose(img[:, :22].amax((1, 2)), grey) and torch.allclose(img[:, 490:].amin((1, 2)), grey)   # 128-grey bands
+    img1, meta1, _, _ = ds[1]
+    assert torch.allclose(img1[:, :, :160].amax((1, 2)), grey) and torch.allclose(meta1[0, 0, :2], torch.tensor([416.0, 256.0]))
+    with pytest.raises(NotImplementedError):
+        JointDataset(cfg, "train")
+    cfg.TEST.IMG_PER_GPU = 2
+    parts = [[p for b in get_test_loader(cfg, 2, r, "test") for p in b[2]] for r in range(2)]
+    assert parts == [["f0.npy", "f1.npy"], ["f2.npy", "f3.npy"]]
+    b = next(iter(get_test_loader(cfg, 1, 0, "test")))
+    assert b[0].shape == (2, 3, 512, 832) and b[1].shape == (2, cfg.DATASET.MAX_PEOPLE, 15, 11) and len(b[3]) == 2

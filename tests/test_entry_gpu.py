@@ -155,3 +155,140 @@ def test_device_preprocess_equals_host_dataset(tmp_path):
         assert torch.equal(got[i].cpu(), want), (name, (got[i].cpu() - want).abs().max().item())
         for k in scale:
             assert scales[k][i] == scale[k]
+
+
+def _annotated_set(tmp_path, net, dev, sizes, seed):
+    """A tiny annotated dataset whose ground truth sits near (some of) the persons the recipe network detects:
+    images first, then annotations placed by inverting the letter-box of the detected roots."""
+    from exps.stage3_root2.config import cfg
+    from dataset.base_dataset import JointDataset, croppad_geometry
+    rng = np.random.default_rng(seed)
+    root = tmp_path / "MultiPersonTestSet"
+    entries = []
+    for i, (h, w) in enumerate(sizes):
+        (root / f"TS{i + 1}").mkdir(parents=True, exist_ok=True)
+        np.save(root / f"TS{i + 1}" / f"img_{i:06d}.npy", rng.integers(0, 255, (h, w, 3), dtype=np.uint8))
+        entries.append({"dataset": "MUCO", "img_paths": f"TS{i + 1}/img_{i:06d}.npy", "img_width": w, "img_height": h,
+                        "isValidation": 1 if i % 3 else 0, "bodys": np.zeros((1, 15, 11)).tolist()})
+    (root / "M3E_gt.json").write_text(json.dumps({"root": entries}))
+    cfg.TEST.ROOT_PATH, cfg.TEST.JSON_PATH = str(root), str(root / "M3E_gt.json")
+    for e in entries:                                                     # detect, then annotate
+        h, w = e["img_height"], e["img_width"]
+        scale, (nh, nw), (left, top) = croppad_geometry(w, h, 832, 512)
+        img = np.load(root / e["img_paths"])
+        from smap_amd.preprocess import resize_bilinear_u8
+        canvas = np.full((512, 832, 3), 128, np.uint8)
+        r = resize_bilinear_u8(img, nh, nw)
+        x0, y0, x1, y1 = max(left, 0), max(top, 0), min(left + nw, 832), min(top + nh, 512)
+        canvas[y0:y1, x0:x1] = r[y0 - top:y1 - top, x0 - left:x1 - left]
+        t = torch.from_numpy(canvas).permute(2, 0, 1).float().div(255.0)
+        t = (t - torch.tensor(cfg.INPUT.MEANS).view(3, 1, 1)) / torch.tensor(cfg.INPUT.STDS).view(3, 1, 1)
+        hm, _, rd = net(t[None].to(dev))
+        hm = hm.cpu()
+        hm[:, :15] /= 255
+        hm[:, 15:] /= 127
+        bodys, _, _ = O.connect(hm[0].numpy(), rd[0, 0].cpu().numpy())
+        P = len(bodys)
+        G = max(2, min(P, 5))
+        ann = np.zeros((G, 15, 11))
+        for g in range(G):
+            if g < P and g % 3 != 2:                                    # near a detected root (matched)
+                net_xy = bodys[g, 2, :2] * 4 + rng.normal(0, 5, 2)
+            else:                                                        # far from everything, or occluded below
+                net_xy = np.array([rng.uniform(5, 825), rng.uniform(5, 505)])
+            for j in range(15):
+                xy = net_xy + (rng.normal(0, 30, 2) if j != 2 else 0)
+                ann[g, j, :2] = (xy - np.array([left, top])) / scale
+                ann[g, j, 2] = rng.uniform(200, 500)
+                ann[g, j, 3] = 2
+                ann[g, j, 4:7] = rng.normal(0, 60, 3) + np.array([0, 0, 300])
+                ann[g, j, 7:11] = [1500.0, 1490.0, w / 2 + 1.5, h / 2 - 0.5]
+        ann[G - 1, 2, 3] = 1                                              # occluded root: dropped (test.py:78)
+        e["bodys"] = ann.tolist()
+    (root / "M3E_gt.json").write_text(json.dumps({"root": entries}))
+    muco = tmp_path / "data" / "MuCo"
+    (muco / "annotations").mkdir(parents=True, exist_ok=True)
+    for e in entries:                                                     # the same frames double as the "MuCo" set
+        (muco / os.path.dirname(e["img_paths"])).mkdir(parents=True, exist_ok=True)
+        np.save(muco / e["img_paths"], np.load(root / e["img_paths"]))
+    (muco / "annotations" / "MuCo.json").write_text(json.dumps({"root": entries}))
+    return root
+
+
+@pytest.mark.parametrize("mode,data_mode,refine", [("generate_result", "test", True), ("generate_train", "generation", True),
+                                                   ("generate_train", "test", False)])
+def test_ground_truth_modes_cli_end_to_end(tmp_path, mode, data_mode, refine):
+    """`test.py -t generate_result|generate_train` (test.py:73-95,142-143) on a tiny annotated set: the JSON must
+    equal what the CPU oracle (register_gt + f64 lifting + RefineNet) makes of the SAME network output."""
+    from model.smap import SMAP
+    from model.refinenet import RefineNet
+    from exps.stage3_root2.config import cfg
+    from dataset.base_dataset import JointDataset
+    from smap_amd.records import annotation_camera, frame_record, kept_annotations, train_records
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((128, 208))).eval()
+    sd = recipe_state_dict(net.state_dict())
+    for k in list(sd):
+        if k.endswith("up4.res_conv2.bn.bias"):
+            sd[k] = sd[k] + 40.0
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    rnet = RefineNet().eval()
+    rsd = recipe_state_dict(rnet.state_dict())
+    rnet.load_state_dict(rsd)
+    torch.save({"model": sd}, tmp_path / "SMAP.pth")
+    torch.save(rsd, tmp_path / "RefineNet.pth")
+    root = _annotated_set(tmp_path, net, dev, [(512, 832), (480, 640), (1080, 1920), (2048, 2048), (600, 800)], seed=11)
+    env = dict(os.environ, PROJECT_HOME=str(tmp_path), SMAP_TEST_ROOT=str(root),
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, os.path.join(ROOT, "exps", "stage3_root2", "test.py"), "-p", str(tmp_path / "SMAP.pth"),
+           "-t", mode, "-d", data_mode, "--batch_size", "2", "--json_name", "gt"]
+    if refine:
+        cmd += ["-rp", str(tmp_path / "RefineNet.pth")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = tmp_path / "model_logs" / "stage3_root2" / "result" / f"stage3_root2_{mode}_{data_mode}_gt.json"
+    res = json.loads(out.read_text())
+    # expectation: same dataset items, network in-process, CPU oracle after the network
+    cfg.dataset.MUCO_ROOT_PATH = str(tmp_path / "data" / "MuCo")
+    cfg.dataset.MUCO_JSON_PATH = str(tmp_path / "data" / "MuCo" / "annotations" / "MuCo.json")
+    ds = JointDataset(cfg, data_mode)
+    assert len(ds) == (3 if data_mode == "test" else 2)                   # isValidation split (base_dataset.py:86-90)
+    wt, bs = rnet.folded("cpu")
+    W, Bs = [w.t().contiguous().numpy() for w in wt], [b.numpy() for b in bs]
+    expect, n_matched = [], 0
+    for i in range(len(ds)):
+        img, meta, path, scale = ds[i]
+        gt = kept_annotations(meta.numpy())
+        if len(gt) == 0:
+            continue
+        hm, d, rd = net(img[None].to(dev))
+        hm = hm.cpu()
+        hm[:, :15] /= 255
+        hm[:, 15:] /= 127
+        bodys, _, _ = O.connect(hm[0].numpy(), rd[0, 0].cpu().numpy())
+        if len(bodys) == 0:
+            continue
+        m = O.register_gt(bodys, gt[:, 2, :2])
+        p2, p3, rz = O.lift_gt(m, d[0].cpu().numpy(), rd[0, 0].cpu().numpy(), annotation_camera(gt, scale))
+        if refine:
+            p3 = O.refine_gt(p2, p3, W, Bs)
+        n_matched += int((p2[:, 2, 3] != 0).sum())
+        if mode == "generate_train":
+            expect += train_records(p2, p3, rz, gt)
+        else:
+            expect.append(frame_record(p2, p3, rz, path, gt))
+    assert n_matched >= 2, "test setup must produce matched persons"
+    assert len(res["3d_pairs"]) == len(expect) and len(expect) >= 1
+    for got, want in zip(res["3d_pairs"], expect):
+        assert set(got) == set(want)
+        for k in want:
+            if k == "pred_3d" and refine:
+                assert np.abs(np.asarray(got[k]) - np.asarray(want[k])).max() < 1e-3 * 100     # 1e-3 m, in cm
+            else:
+                assert got[k] == want[k], k                             # matching, 2D, depths, ground truth: exact
+    if mode == "generate_result":                                        # and the evaluation hand-off accepts the file
+        from lib.eval.convert import convert
+        p3d, p2d = convert(str(out), out_dir=str(tmp_path))
+        assert set(p3d) == {r["image_path"] for r in res["3d_pairs"]}

@@ -42,6 +42,77 @@ def test_refine_matches_reference_golden(golden_dir):
         assert np.abs(out - z[p + "refined"]).max() < 1e-2
 
 
+# ------------------------------------------------------------------ ground-truth modes (golden)
+def test_register_gt_lift_refine_match_reference_golden(golden_dir):
+    """generate_result / generate_train: register_pred with ground truth, f64 lifting, RefineNet -- bit-exact
+    (matching, 2D, 3D, root depth) against the imported reference (tests/golden/gen_golden_gt.py)."""
+    z = np.load(f"{golden_dir}/lift_gt.npz")
+    W, B, _ = _refine_folded()
+    seen_unmatched = seen_matched = 0
+    for c in range(int(z["n_cases"])):
+        p = f"c{c}_"
+        if int(z[p + "empty"]):
+            continue
+        gt = z[p + "gt"]
+        m = O.register_gt(z[p + "bodys"], gt[:, 2, :2])
+        det, root = expand(z[p + "det_c"], 0.05), expand(z[p + "root_c"], 0.002)[0]
+        p2, p3, rz = O.lift_gt(m, det, root, z[p + "cam"])
+        assert p2.dtype == np.float64 and np.array_equal(p2, z[p + "matched"])
+        assert np.array_equal(p3, z[p + "pred_3d"]) and np.array_equal(rz, z[p + "root_z"])
+        out = O.refine_gt(p2, p3, W, B)
+        assert np.abs(out - z[p + "refined"]).max() < 1e-2
+        assert np.array_equal(out[:, :, 3], z[p + "refined"][:, :, 3])        # score column: 0 for unmatched persons
+        seen_unmatched += int((p2[:, 2, 3] == 0).sum())
+        seen_matched += int((p2[:, 2, 3] != 0).sum())
+    assert seen_unmatched > 0 and seen_matched > 0
+
+
+def test_register_gt_known_answers():
+    bodys = np.zeros((3, 15, 4), np.float32)
+    bodys[:, 2, 3] = 1.0
+    bodys[0, 2, :2] = (10, 10)          # x4 -> (40, 40)
+    bodys[1, 2, :2] = (12, 10)          # x4 -> (48, 40)
+    bodys[2, 2, :2] = (100, 60)         # x4 -> (400, 240)
+    bodys[:, 0, 0] = (1, 2, 3)          # marks which prediction landed where
+    # annotation 0 and 1 sit exactly between predictions 0 and 1 (distance 4 each): ties go in row-major order, so
+    # annotation 0 takes prediction 0 and annotation 1 then gets prediction 1; annotation 2 is 29.x px from
+    # prediction 2 (accepted), annotation 3 is exactly 30 px away from it (strict <: rejected, and it is taken)
+    gt = np.array([[44, 40], [44, 40], [400, 269.5], [430, 240]], np.float32)
+    m = O.register_gt(bodys, gt)
+    assert m[:, 0, 0].tolist() == [1.0, 2.0, 3.0, 0.0]
+    assert not m[3].any()
+    # no prediction at all -> zeros (the caller skips the frame)
+    assert not O.register_gt(np.zeros((0, 15, 4), np.float32), gt).any()
+
+
+def test_convert_matches_reference_golden(golden_dir, tmp_path):
+    """lib/eval/convert.py against the imported reference's .mat output (tests/golden/gen_golden_gt.py)."""
+    import json
+    import scipy.io as scio
+    from lib.eval.convert import convert
+    z = np.load(f"{golden_dir}/convert.npz")
+    src = tmp_path / "result.json"
+    src.write_text(bytes(z["json"]).decode())
+    p3, p2 = convert(str(src), out_dir=str(tmp_path))
+    m3 = scio.loadmat(str(tmp_path / "pose3d.mat"))["preds_3d_kpt"]
+    m2 = scio.loadmat(str(tmp_path / "pose2d.mat"))["preds_2d_kpt"]
+    assert list(m3.dtype.names) == [str(n) for n in z["names"]]
+    for k, name in enumerate(z["names"]):
+        assert np.array_equal(p3[str(name)], z[f"p3_{k}"]) and np.array_equal(p2[str(name)], z[f"p2_{k}"])
+        assert np.array_equal(m3[str(name)][0, 0], z[f"p3_{k}"]) and np.array_equal(m2[str(name)][0, 0], z[f"p2_{k}"])
+    # the writer's own key names are accepted too
+    doc = json.loads(bytes(z["json"]).decode())
+    for r in doc["3d_pairs"]:
+        del r["pred"], r["gt"]
+    src.write_text(json.dumps(doc))
+    q3, _ = convert(str(src), out_dir=str(tmp_path))
+    assert all(np.array_equal(q3[k], p3[k]) for k in p3)
+    doc["3d_pairs"][0]["image_path"] = "/data/TS21/img.jpg"
+    src.write_text(json.dumps(doc))
+    with pytest.raises(NotImplementedError):
+        convert(str(src), out_dir=str(tmp_path))
+
+
 def test_refinenet_module_keys(golden_dir):
     z = np.load(f"{golden_dir}/refine.npz")
     _, _, net = _refine_folded()
