@@ -251,7 +251,7 @@ static int validate(const smap_op& o)
             if (smap_conv_tile_dims(o.tile, &bm, &bn)) return SMAP_E_ARG;
             if (o.Cin % 64 || o.Cin * 2 + 16 > SMAP_ZERO_PAGE || o.cout_pad % bn || o.cout_pad < o.Cout) return SMAP_E_ARG;
             if (o.ksize != 1 && o.ksize != 3) return SMAP_E_ARG;
-            if (o.tile >= 40 && (o.ksize != 1 || o.stride != 1 || (o.Cin != 64 && o.Cin != 128 && o.Cin != 256)))
+            if (o.tile >= 40 && o.tile < 50 && (o.ksize != 1 || o.stride != 1 || (o.Cin != 64 && o.Cin != 128 && o.Cin != 256)))
                 return SMAP_E_ARG;                       // weight-stationary kernel: 1x1 stride-1, weights fit the register file
             if (o.tile >= 30 && o.tile < 40 && (o.ksize != 3 || o.stride != 1 || o.pad != 1 || o.res_off >= 0 || o.add1_off >= 0 ||
                                  o.add2_off >= 0 || o.aux_off[0] >= 0))

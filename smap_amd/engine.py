@@ -201,10 +201,10 @@ class Graph:
         tile = pick_tile(M, cout, f"{self.B},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
         tile = {**DEFAULT_REMAP, **_tile_remap()}.get(tile, tile)
         plain3 = ksize == 3 and stride == 1 and res is None and add1 is None and add2 is None and up is None
-        if tile >= 30 and not plain3:                # the halo-tiled kernel has no fused epilogues (table keyed by shape only)
+        if 30 <= tile < 40 and not plain3:                # the halo-tiled kernel has no fused epilogues (table keyed by shape only)
             tile = pick_tile_heuristic(M, cout)
         ws1 = os.environ.get("SMAP_WS1", "")          # A/B hook: "40" / "41" -> weight-stationary kernel for every eligible 1x1
-        if tile >= 40 and not (ksize == 1 and stride == 1 and cin in (64, 128, 256)):
+        if 40 <= tile < 50 and not (ksize == 1 and stride == 1 and cin in (64, 128, 256)):
             tile = pick_tile_heuristic(M, cout)
         if ws1 and ksize == 1 and stride == 1 and cin in (64, 128, 256) and cout % 256 == 0:
             lim = os.environ.get("SMAP_WS1_MIN_M", "")

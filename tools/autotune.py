@@ -55,7 +55,7 @@ def main():
         B, H, W, Cin, Cout, k, s = key
         halo_ok = plain and k == 3 and s == 1
         skey = ",".join(map(str, key))
-        ws_ok = k == 1 and s == 1 and Cin in (64, 128, 256) and Cout % 256 == 0
+        ws_ok = k == 1 and s == 1 and Cin in (64, 128, 256) and Cout % 256 == 0 and not os.environ.get("SMAP_AUTOTUNE_ONLY3")
         if args.halo and not ((halo_ok or ws_ok) and skey in old):
             continue
         if Cout <= 32:

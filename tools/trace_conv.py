@@ -31,7 +31,7 @@ def main():
         bm, bn = TILES[p[7]]
         Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
         nblk = -(-(B * Ho * Wo) // bm) * (-(-Cout // bn))
-        trace = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
+        trace = torch.zeros((max(nblk, 16384), 8), dtype=torch.int64, device=dev)      # halo tiles: 2-D pixel tiles, more blocks
         os.environ["SMAP_TRACE_PTR"] = str(trace.data_ptr())
         run = lambda: L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()), None, st), "run")
         for _ in range(3):
@@ -40,7 +40,13 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); run(); e1.record()
         torch.cuda.synchronize()
-        t = trace.cpu().numpy().astype(np.float64)
+        t = trace.cpu().numpy()
+        t = t[t[:, 0] != 0]
+        nblk = len(t)
+        vmw, barw = (t[:, 6] & 0xffffffff).astype(np.float64), (t[:, 6] >> 32).astype(np.float64)
+        t = t.astype(np.float64)
+        if p[7] >= 30:
+            t[:, 6] = vmw + barw
         tick = 0.01                                   # us per s_memtime tick (100 MHz)
         t0 = t[:, 0].min()
         start = (t[:, 0] - t0) * tick
@@ -56,6 +62,8 @@ def main():
         print(f"{n} {tuple(p)} tile {bm}x{bn}: kernel {e0.elapsed_time(e1) * 1e3:.1f} us, stamp span {span:.1f} us, blocks {nblk}")
         f = lambda a: f"{np.mean(a):7.2f} (p10 {np.percentile(a, 10):6.2f} p90 {np.percentile(a, 90):6.2f})"
         print(f"   setup {f(setup)}\n   first tile {f(first)}\n   K loop rest {f(loop)}  of which waits(all iters) {f(wait)}\n   staging {f(stg)}\n   epilogue+drain {f(epi)}\n   lifetime {f(life)}")
+        if p[7] >= 30:
+            print(f"   waits split: vmcnt {f(vmw * tick)}  barrier {f(barw * tick)}")
         hist, edges = np.histogram(start, bins=8)
         print("   block start times (us):", " ".join(f"{int(c)}@{e:.0f}" for c, e in zip(hist, edges)))
         lib.smap_plan_destroy(h)
