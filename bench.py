@@ -230,7 +230,7 @@ def main():
                          "backbone_ms_per_batch": bb * 1e3,
                          "algorithmic_gflop_per_frame": ALG_GFLOP_PER_FRAME},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:              # reported at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(scenes)
         print(json.dumps(out), flush=True)
     if world > 1:

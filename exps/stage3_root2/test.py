@@ -104,7 +104,8 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
             if pipe is not None:
                 drain(pipe.flush())
             pipe = PosePipeline(model, cfg, len(imgs), imgs.shape[-2], imgs.shape[-1], device, refine_w,
-                                do_flip=bool(cfg.DO_FLIP), record_mode=cfg.TEST_MODE)
+                                do_flip=bool(cfg.DO_FLIP), record_mode=cfg.TEST_MODE,
+                                depth=int(os.environ.get("SMAP_PIPELINE_DEPTH", 2)))   # two backbones in flight (+19 %)
         with torch.no_grad():
             drain(pipe.submit(imgs, cams, list(img_path), annotations=annotations))
     if pipe is not None:
