@@ -22,10 +22,12 @@ def main():
              OUTPUT_SHAPE=(128, 208), LOSS=NS(OHKM=True, TOPK=8, COARSE_TO_FINE=True))
     torch.manual_seed(0)
     g = Graph(SMAP(cfg).state_dict(), B, 512, 832)
-    names = {OP_CONV: "conv_igemm", OP_STEM: "stem_kernel", OP_MAXPOOL: "maxpool", OP_UPADD: "upadd", OP_HEADSUM: "headsum"}   # set SMAP_NO_UPADD_FUSION=1 for pre-fusion traces
+    # kernel-name fragments per op kind (conv ops run conv.hip, conv2.hip, conv3.hip or conv1.hip kernels, by tile id)
+    names = {OP_CONV: ("conv_igemm", "conv3x3_halo", "conv1x1_ws"), OP_STEM: ("stem_kernel",), OP_MAXPOOL: ("maxpool",),
+             OP_UPADD: ("upadd",), OP_HEADSUM: ("headsum",)}       # set SMAP_NO_UPADD_FUSION=1 for pre-fusion traces
     con = sqlite3.connect(db)
     rows = con.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
-    mine = [r for r in rows if any(k in r[0] for k in names.values())]
+    mine = [r for r in rows if any(k in r[0] for ks in names.values() for k in ks)]
     n = len(g.ops)
     assert len(mine) % n == 0, (len(mine), n)
     runs = len(mine) // n
@@ -33,7 +35,7 @@ def main():
     for r in range(runs):
         for i in range(n):
             k = mine[r * n + i]
-            assert names[g.ops[i].kind] in k[0], (i, k[0])
+            assert any(f in k[0] for f in names[g.ops[i].kind]), (i, k[0])
             acc[i].append((k[2] - k[1]) / 1e3)
     tot = 0
     agg = {}
@@ -51,7 +53,7 @@ def main():
             by = B * x.H * x.W * p["Cin"] * 2 + y.nbytes + p["cout_pad"] * K * 2
             by += sum(t.nbytes for t in (op.res, op.add1, op.add2) if t is not None)
             shape = f"M{M} N{p['Cout']} K{K} k{p['ksize']}s{p['stride']}"
-            tile = "x".join(map(str, TILES[p["tile"]]))
+            tile = "x".join(map(str, TILES[p["tile"]])) + f"#{p['tile']}"
             key = (shape, tile)
             a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += d; a[2] += fl; a[3] += by
