@@ -120,6 +120,59 @@ def cpu_baseline(scenes, budget_s=12.0):
     return out
 
 
+def forward_only(args, dev, rank, world, B):
+    """BASELINE configs[1]: SMAP forward only (HIP conv engine), inputs resident, K forwards back to back on one
+    stream, timed with HIP events around the K schedules and with the host clock around barrier + synchronize."""
+    from helpers import make_cfg
+    from model.smap import SMAP
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((128, 208))).eval().to(dev)
+    eng = net.engine(B, H, W, dev)
+    imgs = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    out = eng.new_output()
+    if args.graph:
+        replay = eng.capture(out)
+        eng_run = lambda x, out=None: replay(x)
+    else:
+        eng_run = eng.run
+    for _ in range(args.warmup):
+        eng_run(imgs, out=out)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        eng_run(imgs, out=out)
+    e1.record()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ev = e0.elapsed_time(e1) * 1e-3
+        achieved = ALG_GFLOP_PER_FRAME * B * args.steps / ev / 1e3
+        print(json.dumps({
+            "metric": "frames/sec at 3x512x832 (SMAP backbone forward only)", "value": B * world * args.steps / dt,
+            "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"batch={B} x 3x512x832 per GPU, SMAP forward only, no association "
+                                   f"(BASELINE configs[1] when batch=1)", "frames_per_step": B * world,
+                       "launch": "one HIP graph per forward" if args.graph else "kernel by kernel"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F16_TFLOPS, "traffic": None,
+                         "kernel": "all backbone launches of the schedule (HIP events around the K schedules)",
+                         "algorithmic_gflop_per_frame": ALG_GFLOP_PER_FRAME}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +183,12 @@ def main():
     ap.add_argument("--depth", type=int, default=2,
                     help="backbones in flight per GPU (2 = two streams/arenas: batch k+1 fills the CUs that batch k's "
                          "low-resolution layers leave idle)")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="BASELINE configs[1] (use with --batch 1): time the backbone forward alone, no association / "
+                         "lifting / result records; prints its own JSON line")
+    ap.add_argument("--graph", action="store_true",
+                    help="with --forward-only: replay the schedule as one HIP graph (BackboneEngine.capture) instead of "
+                         "launching its ~208 kernels one by one")
     ap.add_argument("--refine", action="store_true",
                     help="BASELINE configs[4]: also run the RefineNet post-refinement (model/refinenet.py) on every pose")
     args = ap.parse_args()
@@ -148,6 +207,8 @@ def main():
     from smap_amd.dist import gather_json
 
     B = args.batch
+    if args.forward_only:
+        return forward_only(args, dev, rank, world, B)
     from smap_amd.pipeline import PosePipeline
     from exps.stage3_root2.config import cfg as run_cfg
     torch.manual_seed(0)
