@@ -18,6 +18,7 @@ network's own output is trivial -- to keep representative association work insid
 region, every step ALSO associates + lifts a resident batch of synthetic 8-person scenes.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -234,25 +235,44 @@ def main():
         with torch.cuda.stream(pipe.s_comm):
             last[0] = gather_json(recs, dev)
 
+    host = {"submit": 0.0, "finish": 0.0}
+
     def step(timed):
         # backbone(k) on one stream; association+lift+D2H of batch k on another; records of batch k-1 on the host
-        finish(pipe.submit(imgs, cams, tags, extra=[("synth", s_hms, s_rd, None)], time_backbone=timed))
+        t0 = time.perf_counter()
+        recs = pipe.submit(imgs, cams, tags, extra=[("synth", s_hms, s_rd, None)], time_backbone=timed)
+        t1 = time.perf_counter()
+        finish(recs)
+        if timed:
+            host["submit"] += t1 - t0
+            host["finish"] += time.perf_counter() - t1
+            host.setdefault("steps", []).append((t1 - t0) * 1e3)
 
     for _ in range(args.warmup):
         step(False)
     finish(pipe.flush())
+    # The set-up leaves ~2 M long-lived Python objects behind (state dict, folded weights, op lists); a full cyclic-GC
+    # pass over them costs ~35 ms and lands on some step or other of the timed loop depending on K and W.  Freeze them
+    # into the permanent generation: collections during the loop then only look at what the loop itself allocates.
+    gc.collect()
+    gc.freeze()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    t_loop = time.perf_counter() - t0
     finish(pipe.flush())                      # the K-th batch is complete inside the timed region
+    t_flush = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     bb_ms = [e0.elapsed_time(e1) for e0, e1 in pipe.bb_events]
+    # idle time of a backbone stream between two consecutive schedules (batch k-depth's end -> batch k's start)
+    ev = pipe.bb_events
+    gap_ms = [ev[k - args.depth][1].elapsed_time(ev[k][0]) for k in range(args.depth, len(ev))]
     last = last[0]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -283,12 +303,18 @@ def main():
                        "frames_per_step": B * world, "persons_in_last_step": sum(len(r) for r in last),
                        "arithmetic": "backbone fp16 storage / fp32 MFMA accumulate, heads fp32; association fp32 (+f64 "
                                      "where the reference is); lifting f64",
-                       "pipeline": f"post-processing of batch k overlaps later backbones; {args.depth} backbone(s) in flight"},
+                       "pipeline": f"post-processing of batch k overlaps later backbones; {args.depth} backbone(s) in flight",
+                       "host_ms_per_step": {k: v / args.steps * 1e3 for k, v in host.items() if k != "steps"},
+                       "host_submit_ms_quantiles": [float(np.percentile(host["steps"], q)) for q in (0, 10, 50, 90, 100)],
+                       "host_submit_slowest_step": int(np.argmax(host["steps"])),
+                       "host_timeline_ms": {"submit_loop_done": t_loop * 1e3, "flush_done": t_flush * 1e3, "total": dt * 1e3}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "conv_igemm_kernel (all backbone launches; HIP events: per-schedule span below, "
                                    "rate = algorithmic FLOPs of the timed region / its duration when depth > 1)",
                          "backbone_ms_per_batch": bb * 1e3,
+                         "backbone_stream_idle_ms_between_batches": float(np.mean(gap_ms)) if gap_ms else None,
+                         "first_backbone_start_to_last_end_ms": ev[0][0].elapsed_time(max(ev[-1][1], ev[-2][1], key=lambda e: ev[0][0].elapsed_time(e))) if len(ev) > 1 else None,
                          "algorithmic_gflop_per_frame": ALG_GFLOP_PER_FRAME},
         }
         if not args.no_cpu_baseline and world == 1:              # reported at N = 1 only (the other ranks would idle)
