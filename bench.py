@@ -21,6 +21,7 @@ import argparse
 import gc
 import json
 import os
+import pickle
 import sys
 import time
 
@@ -205,7 +206,7 @@ def main():
     import dapalib
     from helpers import make_cfg, synth_scene
     from model.smap import SMAP
-    from smap_amd.dist import gather_json
+    from smap_amd.dist import gather_bytes
 
     B = args.batch
     if args.forward_only:
@@ -229,11 +230,18 @@ def main():
     last = [None]
 
     def finish(recs):
-        """Records of a completed batch -> (RCCL) gather to every rank, on the comm stream."""
+        """Records of a completed batch -> (RCCL) all_gather of every rank's serialised records to every rank, on the comm
+        stream (BASELINE configs[3]).  Serialisation is pickle, like the reference's gather helper (lib/utils/comm.py:
+        57-59); the gathered payloads stay bytes -- decoding 8 ranks' records on every rank every step is not part of
+        the path (rank 0 writes the JSON file once, after the run: test.py:147-151).  Nothing to do at N = 1."""
         if recs is None:
             return
+        if world == 1:
+            last[0] = recs
+            return
+        payload = pickle.dumps(recs, protocol=pickle.HIGHEST_PROTOCOL)
         with torch.cuda.stream(pipe.s_comm):
-            last[0] = gather_json(recs, dev)
+            last[0] = gather_bytes(payload, dev)
 
     host = {"submit": 0.0, "finish": 0.0}
 
@@ -273,7 +281,7 @@ def main():
     # idle time of a backbone stream between two consecutive schedules (batch k-depth's end -> batch k's start)
     ev = pipe.bb_events
     gap_ms = [ev[k - args.depth][1].elapsed_time(ev[k][0]) for k in range(args.depth, len(ev))]
-    last = last[0]
+    last = [last[0]] if world == 1 else [pickle.loads(b) for b in last[0]]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -29,7 +29,7 @@ from torch.utils.data import DataLoader, Subset
 from model.smap import SMAP
 from model.refinenet import RefineNet
 from dataset.custom_dataset import CustomDataset
-from smap_amd.dist import gather_json, shard_range
+from smap_amd.dist import gather_records, shard_range
 from exps.stage3_root2.config import cfg
 from smap_amd.pipeline import PosePipeline
 from exps.stage3_root2.test_util import default_cams
@@ -111,7 +111,7 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
     if pipe is not None:
         drain(pipe.flush())
     if dist.is_initialized() and dist.get_world_size() > 1:
-        parts = gather_json(result["3d_pairs"], device)
+        parts = gather_records(result["3d_pairs"], device)
         result["3d_pairs"] = [r for part in parts for r in part]                # rank order == frame order
     if rank == 0:
         dir_name = os.path.split(os.path.split(os.path.realpath(__file__))[0])[1]

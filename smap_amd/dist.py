@@ -3,11 +3,11 @@
 Frames are independent everywhere on the path (eval-mode BN, per-frame association), so
 ranks never exchange data while computing.  The only collective is the gather of the
 per-frame result records, following the reference's own helper
-(lib/utils/comm.py:47-87: all_gather of byte lengths, then of uint8 buffers padded to the
+(lib/utils/comm.py:47-87: pickle, all_gather of byte lengths, then of uint8 buffers padded to the
 maximum) and its contiguous per-rank split (lib/utils/dataloader.py:80-85).
 """
-import json
 import math
+import pickle
 
 import torch
 import torch.distributed as dist
@@ -20,24 +20,38 @@ def shard_range(num_items, world_size, rank):
     return st, min(num_items, st + per)
 
 
-def gather_json(records, device=None):
-    """records: JSON-serialisable object of this rank.  Returns the list of every rank's
-    object, in rank order, on every rank.  Works for backend nccl (=RCCL; tensors on `device`)
+def gather_bytes(payload, device=None):
+    """payload: bytes of this rank.  Returns every rank's bytes, in rank order, on every rank: all_gather of the
+    lengths, then of the uint8 buffers padded to the maximum (lib/utils/comm.py:47-87); two host syncs per call (the
+    lengths, the payloads), both on the CURRENT stream only.  Works for backend nccl (= RCCL; tensors on `device`)
     and gloo (CPU tensors)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return [records]
+        return [bytes(payload)]
     world = dist.get_world_size()
     backend = dist.get_backend()
     dev = torch.device(device if device is not None else ("cuda" if backend == "nccl" else "cpu"))
-    payload = json.dumps(records, separators=(",", ":")).encode()
-    buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
-    n = torch.tensor([buf.numel()], dtype=torch.int64, device=dev)
+    buf = torch.frombuffer(bytearray(payload) or bytearray(1), dtype=torch.uint8)[:len(payload)].to(dev)
+    n = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes)
+    sizes = torch.cat(sizes).cpu().tolist()
+    mx = max(max(sizes), 1)
     if buf.numel() < mx:
         buf = torch.cat([buf, torch.zeros(mx - buf.numel(), dtype=torch.uint8, device=dev)])
     outs = [torch.empty(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
     dist.all_gather(outs, buf)
-    return [json.loads(bytes(o[:s].cpu().numpy().tobytes()).decode()) for o, s in zip(outs, sizes)]
+    host = torch.stack(outs).cpu().numpy()
+    return [host[r, :sz].tobytes() for r, sz in enumerate(sizes)]
+
+
+def gather_records(records, device=None):
+    """Per-rank result records -> the list of every rank's records, in rank order, on every rank.  Serialised with
+    pickle, as the reference's helper does (lib/utils/comm.py:57-59): JSON-encoding a batch of poses costs more host time
+    than the batch takes on the GPU (8 ms vs 5.5 ms for 8 frames x 8 persons) and JSON is only the FILE format, written
+    once by rank 0 after the run (test.py:147-151)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [records]
+    return [pickle.loads(b) for b in gather_bytes(pickle.dumps(records, protocol=pickle.HIGHEST_PROTOCOL), device)]
+
+
+gather_json = gather_records        # earlier name

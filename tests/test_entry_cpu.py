@@ -78,13 +78,15 @@ _WORKER = r"""
 import os, sys, json
 sys.path.insert(0, sys.argv[1])
 import torch.distributed as dist
-from smap_amd.dist import gather_json, shard_range
+from smap_amd.dist import gather_bytes, gather_records, shard_range
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 st, ed = shard_range(11, world, rank)
 recs = [{"image_path": f"img{i}", "pred_3d": [[float(i), 0.5 * rank]], "root_d": [1.0 / (i + 1)]} for i in range(st, ed)]
-parts = gather_json(recs)
+parts = gather_records(recs)
 flat = [r for p in parts for r in p]
+raw = gather_bytes(b"x" * (3 * rank))            # ragged payloads, an empty one included
+assert raw == [b"x" * (3 * r) for r in range(world)], raw
 assert [r["image_path"] for r in flat] == [f"img{i}" for i in range(11)], flat
 assert flat[7]["root_d"][0] == 1.0 / 8
 if rank == 0:
