@@ -175,6 +175,72 @@ def forward_only(args, dev, rank, world, B):
         dist.destroy_process_group()
 
 
+class _StandInPipeline:
+    """The submit()/flush() protocol of smap_amd.pipeline.PosePipeline without a GPU: records of the batch submitted
+    `depth` calls earlier, made of deterministic numbers."""
+
+    def __init__(self, depth, B, rank):
+        self.depth, self.B, self.rank, self.q, self.k = depth, B, rank, [], 0
+
+    def _records(self, k):
+        rng = np.random.default_rng(1000 * self.rank + k)
+        return [{"pred_2d": rng.normal(0, 100, (3, 15, 4)).astype(np.float32).tolist(),
+                 "pred_3d": rng.normal(0, 100, (3, 15, 4)).tolist(), "root_d": rng.normal(300, 50, 3).tolist(),
+                 "image_path": f"r{self.rank}/b{k}/f{i}", "gt_3d": [], "gt_2d": []} for i in range(self.B)]
+
+    def submit(self):
+        self.q.append(self._records(self.k))
+        self.k += 1
+        return self.q.pop(0) if len(self.q) > self.depth else None
+
+    def flush(self):
+        out = [r for recs in self.q for r in recs]
+        self.q = []
+        return out or None
+
+
+def dry_run(args):
+    """bench.py's distributed control flow on CPU (gloo): same sequence of collectives per rank as the GPU run."""
+    from smap_amd.dist import gather_bytes
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        dist.init_process_group("gloo")
+    pipe = _StandInPipeline(args.depth, args.batch, rank)
+    last = [None]
+
+    def finish(recs):
+        if recs is None:
+            return
+        last[0] = [recs] if world == 1 else gather_bytes(pickle.dumps(recs, protocol=pickle.HIGHEST_PROTOCOL), "cpu")
+
+    for _ in range(args.warmup):
+        finish(pipe.submit())
+    finish(pipe.flush())
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        finish(pipe.submit())
+    finish(pipe.flush())
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    got = last[0] if world == 1 else [pickle.loads(b) for b in last[0]]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU): control flow only", "value": args.batch * world * args.steps / dt,
+                          "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": "stand-in pipeline", "ranks_in_last_gather": len(got),
+                                     "last_paths": [g[-1]["image_path"] for g in got]}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,7 +259,12 @@ def main():
                          "launching its ~208 kernels one by one")
     ap.add_argument("--refine", action="store_true",
                     help="BASELINE configs[4]: also run the RefineNet post-refinement (model/refinenet.py) on every pose")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the same control flow (pipeline protocol, per-step gather, MAX over ranks, one JSON line on "
+                         "rank 0) with a stand-in pipeline and the gloo backend -- what the multi-rank CPU test runs")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

@@ -224,3 +224,20 @@ def test_joint_dataset_croppad_and_loader(tmp_path):
     assert parts == [["f0.npy", "f1.npy"], ["f2.npy", "f3.npy"]]
     b = next(iter(get_test_loader(cfg, 1, 0, "test")))
     assert b[0].shape == (2, 3, 512, 832) and b[1].shape == (2, cfg.DATASET.MAX_PEOPLE, 15, 11) and len(b[3]) == 2
+
+
+def test_bench_control_flow_two_ranks_gloo():
+    """bench.py --dry-run under torch.distributed.run with 2 ranks: every rank issues the same collectives (per-step
+    gather of pickled records, barrier, MAX all-reduce) and rank 0 alone prints the one JSON line."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "5", "--warmup", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["config"]["ranks_in_last_gather"] == 2
+    # the last gather carries the flush of the final batches: depth = 2 -> batches 5 and 6 of each rank (2 warm-up + 5)
+    assert d["config"]["last_paths"] == ["r0/b6/f7", "r1/b6/f7"]
