@@ -121,6 +121,8 @@ enum smap_op_kind {
     SMAP_OP_MAXPOOL = 2,    /* ResNet_top maxpool 3x3 s2 p1 (smap.py:86)                         */
     SMAP_OP_UPADD = 3,      /* out = relu(a + bilinear_align_corners(t)) (smap.py:213-217)       */
     SMAP_OP_HEADSUM = 4,    /* fp32 NCHW out = sum of bilinear-upsampled heads (smap.py:221-229,417-419) */
+    SMAP_OP_STEMPOOL = 5,   /* ResNet_top whole (smap.py:83-86): STEM followed by MAXPOOL in one kernel; H,W = image,
+                               Ho,Wo = pooled size, same weight format as STEM                                  */
 };
 
 typedef struct smap_op {

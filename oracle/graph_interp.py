@@ -10,7 +10,7 @@ TEST INFRASTRUCTURE ONLY.  Two uses:
 import torch
 import torch.nn.functional as F
 
-from smap_amd.engine import OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM
+from smap_amd.engine import OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM, OP_STEMPOOL
 
 
 def _q(x, on):
@@ -26,13 +26,13 @@ def run_graph(g, imgs, quantize, keep=False):
     up = lambda x, size: F.interpolate(x, size=size, mode="bilinear", align_corners=True)
     for op in g.ops:
         p = op.p
-        if op.kind == OP_STEM:
+        if op.kind in (OP_STEM, OP_STEMPOOL):
             w, b = p["w_ref"].float().to(dev), p["b_ref"].float().to(dev)
             x0 = imgs.float()
             if quantize:                                 # the stem kernel rounds image and weights to fp16
                 x0, w = _q(x0, True), _q(w, True)
-            y = F.relu(F.conv2d(x0, w, b, stride=2, padding=3))
-            T[op.out.name] = _q(y, quantize)
+            y = _q(F.relu(F.conv2d(x0, w, b, stride=2, padding=3)), quantize)
+            T[op.out.name] = F.max_pool2d(y, 3, 2, 1) if op.kind == OP_STEMPOOL else y
         elif op.kind == OP_MAXPOOL:
             T[op.out.name] = F.max_pool2d(T[op.inp.name], 3, 2, 1)
         elif op.kind == OP_CONV:

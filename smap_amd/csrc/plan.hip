@@ -117,6 +117,124 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
     }
 }
 
+// ------------------------------------------------------- stem + max-pool --
+// ResNet_top in one kernel (smap.py:83-86): the 7x7 s2 conv + BN + ReLU of stem_kernel, then the 3x3 s2 p1 max-pool
+// straight from LDS.  stem_kernel is bound by its 109 MB (B = 8) output write and maxpool_kernel reads that tensor
+// back; here only the pooled 27 MB leave the CU.  A workgroup owns 8 x 7 pooled pixels = 17 x 15 conv pixels (255 of
+// the 256 MFMA pixel columns; the one-pixel halo is recomputed: +14 % conv work on a store-bound kernel).  Conv pixels
+// outside the image take the value 0 in the LDS tile: every real value is >= 0 after the ReLU, so a 0 never changes a
+// window maximum -- the same result as MaxPool2d's -inf padding.
+constexpr int SP_PY = 8, SP_PX = 7, SP_SY = 2 * SP_PY + 1, SP_SX = 2 * SP_PX + 1;       // pooled tile, conv tile (17 x 15)
+constexpr int SP_PH = (SP_SY - 1) * 2 + 7, SP_PW = 40;                                  // input patch rows (39), padded row
+static_assert(SP_SY * SP_SX <= 256 && (SP_SX - 1) * 2 + 8 <= SP_PW, "stem+pool tile");
+
+__global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict__ img, const _Float16* __restrict__ wk,
+                                                        const float* __restrict__ bias, _Float16* __restrict__ out,
+                                                        int H, int W, int Hs, int Ws, int Ho, int Wo)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 s_w[64 * ST_K];
+    __shared__ __attribute__((aligned(16))) _Float16 s_p[3 * SP_PH * SP_PW];
+    __shared__ __attribute__((aligned(16))) _Float16 s_t[256 * 64];                    // conv tile, [pixel slot][channel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, py0 = blockIdx.y * SP_PY, px0 = blockIdx.x * SP_PX;
+    const int sy0 = py0 * 2 - 1, sx0 = px0 * 2 - 1;                                     // first conv pixel of the tile
+    for (int i = tid; i < 64 * ST_K / 8; i += 256)
+        reinterpret_cast<half8*>(s_w)[i] = reinterpret_cast<const half8*>(wk)[i];
+    const int iy0 = sy0 * 2 - 3, ix0 = sx0 * 2 - 3;
+    for (int i = tid; i < 3 * SP_PH * SP_PW; i += 256) {
+        const int c = i / (SP_PH * SP_PW), r = i - c * SP_PH * SP_PW;
+        const int py = r / SP_PW, px = r - py * SP_PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            v = img[(((size_t)b * 3 + c) * H + iy) * W + ix];
+        s_p[i] = (_Float16)v;
+    }
+    __syncthreads();
+    const int l31 = lane & 31, lhi = lane >> 5;
+    f32x16 acc[2][2];                                          // [channel tile][pixel tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // pixel slot s = wave*64 + t*32 + l31 -> conv pixel (s / 15, s % 15) of the 17 x 15 tile (slot 255 is a spare)
+    int pbase[2], slot[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int sl = wave * 64 + t * 32 + l31;
+        const int sc = sl < SP_SY * SP_SX ? sl : 0;
+        const int py = sc / SP_SX, px = sc - py * SP_SX;
+        slot[t] = sl;
+        pbase[t] = (py * 2) * SP_PW + px * 2;
+    }
+#pragma unroll
+    for (int ks = 0; ks < ST_K / 16; ++ks) {
+        int g = ks * 2 + lhi;
+        const int gg = g < 21 ? g : 20;
+        const int kh = gg / 3, c = gg - kh * 3;
+        const int goff = (c * SP_PH + kh) * SP_PW;
+        half8 wf[2], pf[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            wf[nt] = *reinterpret_cast<const half8*>(s_w + (nt * 32 + l31) * ST_K + g * 8);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned* q = reinterpret_cast<const unsigned*>(s_p + pbase[t] + goff);
+            union { unsigned u[4]; half8 h; } cv;
+            cv.u[0] = q[0]; cv.u[1] = q[1]; cv.u[2] = q[2]; cv.u[3] = q[3];
+            pf[t] = cv.h;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], pf[t], acc[nt][t], 0, 0, 0);
+    }
+    // bias + ReLU -> fp16 conv tile in LDS (zero where the conv pixel lies outside the image)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int sl = slot[t];
+        const int py = sl / SP_SX, px = sl - py * SP_SX;
+        const int sy = sy0 + py, sx = sx0 + px;
+        const bool live = sl < SP_SY * SP_SX && (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = nt * 32 + 8 * q + 4 * lhi;
+                const float4 bv = *reinterpret_cast<const float4*>(bias + n0);
+                half4 h;
+                float v;
+                v = acc[nt][t][4 * q + 0] + bv.x; h[0] = (_Float16)(live && v > 0.f ? v : 0.f);
+                v = acc[nt][t][4 * q + 1] + bv.y; h[1] = (_Float16)(live && v > 0.f ? v : 0.f);
+                v = acc[nt][t][4 * q + 2] + bv.z; h[2] = (_Float16)(live && v > 0.f ? v : 0.f);
+                v = acc[nt][t][4 * q + 3] + bv.w; h[3] = (_Float16)(live && v > 0.f ? v : 0.f);
+                *reinterpret_cast<half4*>(s_t + sl * 64 + n0) = h;
+            }
+    }
+    __syncthreads();
+    // 3x3 s2 max over the conv tile: pooled pixel (py, px) reads conv rows 2py..2py+2, cols 2px..2px+2 of the tile
+    for (int i = tid; i < SP_PY * SP_PX * 8; i += 256) {
+        const int cg = i & 7, pp = i >> 3;
+        const int py = pp / SP_PX, px = pp - py * SP_PX;
+        const int oy = py0 + py, ox = px0 + px;
+        if (oy >= Ho || ox >= Wo) continue;
+        half8 m = *reinterpret_cast<const half8*>(s_t + ((2 * py) * SP_SX + 2 * px) * 64 + cg * 8);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                if (dy == 0 && dx == 0) continue;
+                const half8 v = *reinterpret_cast<const half8*>(s_t + ((2 * py + dy) * SP_SX + 2 * px + dx) * 64 + cg * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        *reinterpret_cast<half8*>(out + (((size_t)b * Ho + oy) * Wo + ox) * 64 + cg * 8) = m;
+    }
+}
+
 // --------------------------------------------------------------- maxpool --
 // NHWC fp16, 3x3 stride 2 pad 1 (padding never wins: only in-range taps are read).
 __global__ void maxpool_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, int B, int H, int W,
@@ -287,6 +405,11 @@ static int validate(const smap_op& o)
             if (o.Cin != 3 || o.Cout != 64 || o.Ho != (o.H + 6 - 7) / 2 + 1 || o.Wo != (o.W + 6 - 7) / 2 + 1)
                 return SMAP_E_ARG;
             return 0;
+        case SMAP_OP_STEMPOOL: {
+            const int hs = (o.H + 6 - 7) / 2 + 1, ws = (o.W + 6 - 7) / 2 + 1;
+            if (o.Cin != 3 || o.Cout != 64 || o.Ho != (hs + 2 - 3) / 2 + 1 || o.Wo != (ws + 2 - 3) / 2 + 1) return SMAP_E_ARG;
+            return 0;
+        }
         case SMAP_OP_MAXPOOL:
             if (o.Cin % 8 || o.Cin != o.Cout || o.Ho != (o.H + 2 - 3) / 2 + 1 || o.Wo != (o.W + 2 - 3) / 2 + 1)
                 return SMAP_E_ARG;
@@ -374,6 +497,17 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                                    reinterpret_cast<const _Float16*>(wb + o.w_off),
                                    reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, o.Ho,
                                    o.Wo);
+                e = hipGetLastError();
+                break;
+            }
+            case SMAP_OP_STEMPOOL: {
+                if (!input) return SMAP_E_ARG;
+                const int hs = (o.H + 6 - 7) / 2 + 1, ws = (o.W + 6 - 7) / 2 + 1;
+                dim3 grid((o.Wo + SP_PX - 1) / SP_PX, (o.Ho + SP_PY - 1) / SP_PY, o.B);
+                hipLaunchKernelGGL(stem_pool_kernel, grid, dim3(256), 0, st, input,
+                                   reinterpret_cast<const _Float16*>(wb + o.w_off),
+                                   reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, hs, ws,
+                                   o.Ho, o.Wo);
                 e = hipGetLastError();
                 break;
             }

@@ -25,7 +25,7 @@ import torch
 
 from . import lib as _L
 
-OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM = range(5)
+OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM, OP_STEMPOOL = range(6)
 import os
 
 # tile id -> (BM, BN); ids 5..9 are the same tiles with deeper LDS-DMA pipelines (csrc/conv.hip)
@@ -240,13 +240,17 @@ class Graph:
         wk[:, :21, :7] = w.permute(0, 2, 1, 3).reshape(64, 21, 7).to(torch.float16)
         wk = wk.reshape(64, 176)
         H2, W2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-        t = self.tensor("top.conv", H2, W2, 64)
-        self.flops += 2 * B * H2 * W2 * 64 * 147
-        self.ops.append(Op(OP_STEM, out=t, p=dict(w_off=self._add_w(wk), bias_off=self._add_w(b.to(torch.float32)),
-                                                  w_ref=w, b_ref=b)))
         H4, W4 = (H2 + 2 - 3) // 2 + 1, (W2 + 2 - 3) // 2 + 1
-        x = self.tensor("top.pool", H4, W4, 64)
-        self.ops.append(Op(OP_MAXPOOL, out=x, inp=t))
+        self.flops += 2 * B * H2 * W2 * 64 * 147
+        stem_p = dict(w_off=self._add_w(wk), bias_off=self._add_w(b.to(torch.float32)), w_ref=w, b_ref=b)
+        if not os.environ.get("SMAP_STEMPOOL"):         # default: conv and max-pool as two kernels (the fused kernel below is
+            t = self.tensor("top.conv", H2, W2, 64)     # bit-identical but no faster inside the two-batch pipeline)
+            self.ops.append(Op(OP_STEM, out=t, p=stem_p))
+            x = self.tensor("top.pool", H4, W4, 64)
+            self.ops.append(Op(OP_MAXPOOL, out=x, inp=t))
+        else:                                           # SMAP_STEMPOOL=1: ResNet_top in one kernel, only the pooled tensor is written
+            x = self.tensor("top.pool", H4, W4, 64)
+            self.ops.append(Op(OP_STEMPOOL, out=x, p=stem_p))
         self.out_h, self.out_w = H4, W4
         skip1 = skip2 = None
         for s in range(self.stage_num):
@@ -401,7 +405,7 @@ class Graph:
                     t = op.aux[0]
                     assert t.C == y.C and t.esize == 2
                     o.aux_off[0], o.aux_h[0], o.aux_w[0] = t.off, t.H, t.W
-            elif op.kind == OP_STEM:
+            elif op.kind in (OP_STEM, OP_STEMPOOL):
                 y = op.out
                 o.H, o.W, o.Cin, o.Ho, o.Wo, o.Cout = self.H, self.W, 3, y.H, y.W, 64
                 o.ksize, o.stride, o.pad, o.relu = 7, 2, 3, 1

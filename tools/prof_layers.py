@@ -16,14 +16,14 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     import torch
     from types import SimpleNamespace as NS
-    from smap_amd.engine import Graph, OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM, TILES
+    from smap_amd.engine import Graph, OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM, OP_STEMPOOL, TILES
     from smap_amd.model.smap import SMAP
     cfg = NS(MODEL=NS(STAGE_NUM=3, UPSAMPLE_CHANNEL_NUM=256), DATASET=NS(KEYPOINT=NS(NUM=15), PAF=NS(NUM=14)),
              OUTPUT_SHAPE=(128, 208), LOSS=NS(OHKM=True, TOPK=8, COARSE_TO_FINE=True))
     torch.manual_seed(0)
     g = Graph(SMAP(cfg).state_dict(), B, 512, 832)
     # kernel-name fragments per op kind (conv ops run conv.hip, conv2.hip, conv3.hip or conv1.hip kernels, by tile id)
-    names = {OP_CONV: ("conv_igemm", "conv3x3_halo", "conv1x1_ws"), OP_STEM: ("stem_kernel",), OP_MAXPOOL: ("maxpool",),
+    names = {OP_CONV: ("conv_igemm", "conv3x3_halo", "conv1x1_ws"), OP_STEM: ("stem_kernel",), OP_STEMPOOL: ("stem_pool_kernel",), OP_MAXPOOL: ("maxpool",),
              OP_UPADD: ("upadd",), OP_HEADSUM: ("headsum",)}       # set SMAP_NO_UPADD_FUSION=1 for pre-fusion traces
     con = sqlite3.connect(db)
     rows = con.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
