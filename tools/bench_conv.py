@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--only", default="")
     ap.add_argument("--tile-override", default="", help="e.g. L2:0,L6:5")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="launch the iterations round-robin on this many streams (own arena each): the difference to one "
+                         "stream is the drain-and-dispatch gap between dependent launches that a second stream can hide")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ov = dict(kv.split(":") for kv in args.tile_override.split(",") if ":" in kv)
@@ -73,18 +76,26 @@ def main():
         if n in ov:
             p[7] = int(ov[n])
         lib, h, arena, blob, flops, byts = build(*p, dev)
-        run = lambda: L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()),
-                                                None, st), "run")
-        for _ in range(3):
+        if args.streams > 1:
+            streams = [torch.cuda.Stream(dev) for _ in range(args.streams)]
+            arenas = [arena] + [arena.clone() for _ in range(args.streams - 1)]
+            def run(i=[0]):
+                k = i[0] % args.streams
+                i[0] += 1
+                L.check(lib.smap_plan_run(h, None, C.c_void_p(arenas[k].data_ptr()), C.c_void_p(blob.data_ptr()), None,
+                                          C.c_void_p(streams[k].cuda_stream)), "run")
+        else:
+            run = lambda: L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()),
+                                                    None, st), "run")
+        for _ in range(3 * args.streams):
             run()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        import time
+        t0 = time.perf_counter()
         for _ in range(args.iters):
             run()
-        e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        us = (time.perf_counter() - t0) * 1e6 / args.iters
         print(f"{n} {tuple(p)} tile={TILES[p[7]]}#{p[7]}: {us:8.1f} us  {flops / us / 1e6:7.1f} TF/s  {byts / us / 1e3:7.0f} GB/s",
               flush=True)
         lib.smap_plan_destroy(h)
