@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Make sure the in-tree HIP library is built and current (a clean checkout has no .so: they are git-ignored).
+    hipcc cross-compiles gfx950 without a GPU; when it is absent the tests that need the library fail loudly."""
+    try:
+        from smap_amd.build import build_lib
+        build_lib(force=False, verbose=False)
+    except Exception as exc:                                   # noqa: BLE001
+        print(f"[conftest] libsmap_hip.so not (re)built: {exc!r}", file=sys.stderr)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
