@@ -16,11 +16,13 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """Make sure the in-tree HIP library is built and current (a clean checkout has no .so: they are git-ignored).
-    hipcc cross-compiles gfx950 without a GPU; when it is absent the tests that need the library fail loudly."""
+    """A clean checkout has no libsmap_hip.so (built artefacts are git-ignored): build it once, in-tree.  An existing
+    library is left alone (snapshots do not always keep mtimes; rebuilding is `python -m smap_amd.build`).  hipcc
+    cross-compiles gfx950 without a GPU; when it is absent the tests that need the library fail loudly."""
     try:
-        from smap_amd.build import build_lib
-        build_lib(force=False, verbose=False)
+        from smap_amd.build import OUT, build_lib
+        if not os.path.exists(OUT):
+            build_lib(force=False, verbose=False)
     except Exception as exc:                                   # noqa: BLE001
         print(f"[conftest] libsmap_hip.so not (re)built: {exc!r}", file=sys.stderr)
 
