@@ -10,6 +10,19 @@ import numpy as np
 import torch
 from torch.utils.data.dataset import Dataset
 
+N_JOINTS = 15
+
+
+def pair_to_vectors(record, root):
+    """One `3d_pairs` record of the per-person flavour (smap_amd/records.py::train_records) -> (inp [75], gt [45]) f64."""
+    pose3 = np.asarray(record["pred_3d"], np.float64)            # [15,4]  X, Y, Z, score
+    pose2 = np.asarray(record["pred_2d"], np.float64)            # [15,4]  x, y, relZ, score
+    truth = np.asarray(record["gt_3d"], np.float64)              # [15,3]
+    feat = np.concatenate([pose2[:, :2] - pose2[root, :2], pose3[:, :3] - pose3[root, :3]], axis=1)   # [15,5]
+    feat[pose3[:, 3] <= 0] = 0.0                                 # undetected joints carry no offset
+    feat[root] = np.concatenate([pose2[root, :2], pose3[root, :3]])
+    return feat.reshape(N_JOINTS * 5), (truth - truth[root]).reshape(N_JOINTS * 3)
+
 
 class P2PDataset(Dataset):
     def __init__(self, stage="train", dataset_path="", root_idx=2):
@@ -21,16 +34,5 @@ class P2PDataset(Dataset):
         return len(self.dataset)
 
     def __getitem__(self, index):
-        pair = self.dataset[index]
-        p3 = np.asarray(pair["pred_3d"], dtype=np.float64)
-        p2 = np.asarray(pair["pred_2d"], dtype=np.float64)
-        g3 = np.asarray(pair["gt_3d"], dtype=np.float64)
-        r = self.root_idx
-        inp = np.zeros((15, 5), np.float64)
-        live = p3[:, 3] > 0
-        live[r] = False
-        inp[live, :2] = p2[live, :2] - p2[r, :2]
-        inp[live, 2:] = p3[live, :3] - p3[r, :3]
-        inp[r, :2], inp[r, 2:] = p2[r, :2], p3[r, :3]
-        gt = g3 - g3[r]
-        return torch.from_numpy(inp.reshape(-1)).float(), torch.from_numpy(gt.reshape(-1)).float()
+        inp, gt = pair_to_vectors(self.dataset[index], self.root_idx)
+        return torch.from_numpy(inp).float(), torch.from_numpy(gt).float()
