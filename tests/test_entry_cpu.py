@@ -85,6 +85,10 @@ st, ed = shard_range(11, world, rank)
 recs = [{"image_path": f"img{i}", "pred_3d": [[float(i), 0.5 * rank]], "root_d": [1.0 / (i + 1)]} for i in range(st, ed)]
 parts = gather_records(recs)
 flat = [r for p in parts for r in p]
+from lib.utils import comm
+assert comm.get_world_size() == world and comm.get_rank() == rank and comm.is_main_process() == (rank == 0)
+comm.synchronize()
+assert comm.all_gather({"r": rank}) == [{"r": r} for r in range(world)]
 raw = gather_bytes(b"x" * (3 * rank))            # ragged payloads, an empty one included
 assert raw == [b"x" * (3 * r) for r in range(world)], raw
 assert [r["image_path"] for r in flat] == [f"img{i}" for i in range(11)], flat
