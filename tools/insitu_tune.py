@@ -40,7 +40,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--gain", type=float, default=0.004)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tile_table_insitu.json"))
+    ap.add_argument("--candidates", default="", help="JSON file [[shape key, [tiles...]], ...] replacing the built-in list")
     args = ap.parse_args()
+    global CANDIDATES
+    if args.candidates:
+        CANDIDATES = [tuple(c) for c in json.load(open(args.candidates))]
     table = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table.json")))
     trial = args.out + ".trial"
     json.dump(table, open(trial, "w"))
