@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     static_assert(LDS_BYTES <= 160 * 1024, "LDS is 160 KiB per CU");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
+    SMAP_TL_BEGIN
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
 #ifdef SMAP_TRACE
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         d[0] = tr_t[0]; d[1] = tr_t[1]; d[2] = tr_t[2]; d[3] = tr_t[3]; d[4] = tr_t[4]; d[5] = tr_t[5]; d[6] = tr_wait; d[7] = hwid;
     }
 #endif
+    SMAP_TL_END(a)
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64>

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     static_assert(NI >= 1 && MI >= 1, "BN >= 32");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
+    SMAP_TL_BEGIN
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
             *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + o) = h;
         }
     }
+    SMAP_TL_END(a)
 }
 
 template <int BN, int TW, int NB>

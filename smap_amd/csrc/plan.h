@@ -22,6 +22,10 @@ struct ConvArgs {
 #ifdef SMAP_TRACE
     long long* dbg;          // diagnostics build only (tools/build_ablate.py --trace): per-workgroup phase stamps
 #endif
+#ifdef SMAP_TIMELINE
+    long long* tl;           // diagnostics build only (tools/build_ablate.py --timeline): [1 + blocks][4] int64 slice of this launch:
+    long long tl_meta[4];    //   row 0 = tl_meta (op index, grid, stream, tile), row 1+b = start, end (s_memrealtime), HW_ID, XCC_ID
+#endif
 };
 
 // ATen's index/weight rule for bilinear align_corners=True (UpSample.h compute_source_index_and_lambda):
@@ -51,3 +55,20 @@ int smap_conv3_tile_dims(int tile, int* bm, int* bn);                       // c
 hipError_t smap_launch_conv3(const ConvArgs& a, int tile, hipStream_t st);
 int smap_conv1_tile_dims(int tile, int* bm, int* bn);                       // conv1.hip (tile ids 40..41, weight-stationary 1x1)
 hipError_t smap_launch_conv1(const ConvArgs& a, int tile, hipStream_t st);
+
+#ifdef SMAP_TIMELINE
+// every workgroup of a conv kernel calls these two (first / last statement): 100 MHz device-wide clock
+#define SMAP_TL_BEGIN const long long tl_t0 = __builtin_amdgcn_s_memrealtime();
+#define SMAP_TL_END(a)                                                                                        \
+    if ((a).tl && threadIdx.x == 0) {                                                                         \
+        unsigned hw_, xcc_;                                                                                   \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                     \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                   \
+        long long* d_ = (a).tl + 4 * (1 + (long long)blockIdx.x);                                             \
+        d_[0] = tl_t0; d_[1] = __builtin_amdgcn_s_memrealtime(); d_[2] = hw_; d_[3] = xcc_;                   \
+        if (blockIdx.x == 0) { (a).tl[0] = (a).tl_meta[0]; (a).tl[1] = (a).tl_meta[1]; (a).tl[2] = (a).tl_meta[2]; (a).tl[3] = (a).tl_meta[3]; } \
+    }
+#else
+#define SMAP_TL_BEGIN
+#define SMAP_TL_END(a)
+#endif

@@ -425,6 +425,18 @@ static int validate(const smap_op& o)
     }
 }
 
+#ifdef SMAP_TIMELINE
+// Diagnostics build (tools/build_ablate.py --timeline): every conv launch gets a slice of a caller-provided buffer
+// (env SMAP_TIMELINE_PTR = device address, SMAP_TIMELINE_CAP = launches it holds) in which its workgroups leave their
+// start / end times on the device-wide 100 MHz clock and the CU they ran on (csrc/plan.h).
+constexpr long long TL_SLICE = 4LL * (1 + 16384);               // int64 per launch: metadata row + up to 16384 workgroups
+static int tl_next = 0;
+static long long* tl_base() { const char* e = getenv("SMAP_TIMELINE_PTR"); return e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 0)) : nullptr; }
+static int tl_cap() { const char* e = getenv("SMAP_TIMELINE_CAP"); return e ? atoi(e) : 0; }
+extern "C" void smap_timeline_reset(void) { tl_next = 0; }
+extern "C" int smap_timeline_count(void) { return tl_next; }
+#endif
+
 extern "C" {
 
 int smap_sizeof_op(void) { return (int)sizeof(smap_op); }
@@ -474,6 +486,13 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                 a.up = A(o.aux_off[0]);
                 a.up_h = o.aux_h[0];
                 a.up_w = o.aux_w[0];
+#ifdef SMAP_TIMELINE
+                a.tl = nullptr;
+                if (tl_base() && tl_next < tl_cap()) {
+                    a.tl = tl_base() + (long long)tl_next++ * TL_SLICE;
+                    a.tl_meta[0] = i; a.tl_meta[1] = 0; a.tl_meta[2] = (long long)(uintptr_t)stream; a.tl_meta[3] = o.tile;
+                }
+#endif
 #ifdef SMAP_TRACE
                 a.dbg = getenv("SMAP_TRACE_PTR") ? reinterpret_cast<long long*>(strtoull(getenv("SMAP_TRACE_PTR"), nullptr, 0)) : nullptr;
 #endif

@@ -9,6 +9,16 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smap_amd import build as B  # noqa: E402
 
+if "--timeline" in sys.argv:    # per-workgroup start/end stamps of every conv launch: libsmap_hip_timeline.so (tools/trace_pipeline.py)
+    objs = []
+    for src, extra in B.SOURCES:
+        op = os.path.join(B.OBJ, "tl_" + src.rsplit(".", 1)[0] + ".o")
+        subprocess.check_call([B._hipcc()] + B.COMMON + extra + ["-DSMAP_TIMELINE=1", "-c", os.path.join(B.CSRC, src), "-o", op])
+        objs.append(op)
+    out = os.path.join(B.OBJ, "libsmap_hip_timeline.so")
+    subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    print(out)
+    sys.exit(0)
 if "--trace" in sys.argv:       # phase-stamp build: libsmap_hip_trace.so (ConvArgs.dbg <- env SMAP_TRACE_PTR)
     objs = []
     for src, extra in B.SOURCES:
