@@ -44,7 +44,9 @@ __device__ __forceinline__ void wait_vm(int n)
     }
 }
 
-template <int BN, int TW, int NB>
+// ONE = the layer has a single 64-channel chunk (Cin = 64: the layer1 3x3s): no second patch buffer, which takes the
+// workgroup from 80 to 52 KB of LDS (three per CU instead of two; residency is what these kernels are short of).
+template <int BN, int TW, int NB, bool ONE>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int tiles_x, int tiles_y)
 {
     constexpr int BM = 128, TH = BM / TW, PW = TW + 2, PH = TH + 2;
@@ -54,7 +56,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     constexpr int A_BYTES = PROWS * ROWB, B_BYTES = BN * ROWB;
     constexpr int D = NB - 1;                                   // weight tiles in flight ahead of the one being multiplied
     static_assert(D >= 1 && D <= 8 && (D - 1) * LB + LA <= 63, "vmcnt is 6 bits");
-    constexpr int PIPE = 2 * A_BYTES + NB * B_BYTES;
+    constexpr int NA = ONE ? 1 : 2;                              // patch buffers
+    constexpr int PIPE = NA * A_BYTES + NB * B_BYTES;
     constexpr int LDS_BYTES = PIPE > BM * BN * 4 ? PIPE : BM * BN * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;           // 2 x 2 waves (wave tile 64 px x BN/2), or 4 x 1 for BN = 32
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
 #pragma unroll
     for (int i = 0; i < LB; ++i) b_off[i] = (unsigned)(((n0 + i * 32 + srow) * a.K + gch * 8) * 2);
     auto issue_b = [&](int buf, unsigned boff) {
-        char* sB = smem + 2 * A_BYTES + buf * B_BYTES;
+        char* sB = smem + NA * A_BYTES + buf * B_BYTES;
         const char* gB = wt + boff;
         if (SMAP_ABLATE & 1) return;
 #pragma unroll
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
                 if (ncc < cchunks) issue_b((it + D) % NB, (unsigned)((ntap * a.Cin + ncc * 64) * 2));
                 if (tap == 0 && !last) issue_a((cc + 1) & 1, cc + 1);
             }
-            const char* sB = smem + 2 * A_BYTES + (it % NB) * B_BYTES;
+            const char* sB = smem + NA * A_BYTES + (it % NB) * B_BYTES;
             const int shift = (tap / 3) * PW + (tap % 3);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -254,8 +257,12 @@ hipError_t launch3(const ConvArgs& a, hipStream_t st)
     constexpr int TH = 128 / TW;
     const int B = a.M / (a.Ho * a.Wo);
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a, tiles_x,
-                       tiles_y);
+    if (a.Cin == 64)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB, true>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a,
+                           tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB, false>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a,
+                           tiles_x, tiles_y);
     return hipGetLastError();
 }
 
