@@ -129,6 +129,7 @@ def forward_only(args, dev, rank, world, B):
     from model.smap import SMAP
     torch.manual_seed(0)
     net = SMAP(make_cfg((128, 208))).eval().to(dev)
+    net.precision = args.precision
     eng = net.engine(B, H, W, dev)
     imgs = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
     out = eng.new_output()
@@ -163,7 +164,7 @@ def forward_only(args, dev, rank, world, B):
             "metric": "frames/sec at 3x512x832 (SMAP backbone forward only)", "value": B * world * args.steps / dt,
             "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"batch={B} x 3x512x832 per GPU, SMAP forward only, no association "
                                    f"(BASELINE configs[1] when batch=1)", "frames_per_step": B * world,
                        "launch": "one HIP graph per forward" if args.graph else "kernel by kernel"},
@@ -259,6 +260,9 @@ def main():
                          "launching its ~208 kernels one by one")
     ap.add_argument("--refine", action="store_true",
                     help="BASELINE configs[4]: also run the RefineNet post-refinement (model/refinenet.py) on every pose")
+    ap.add_argument("--precision", choices=("f16", "x3"), default=os.environ.get("SMAP_PRECISION", "f16"),
+                    help="backbone arithmetic: x3 = fp16 hi/lo pairs + three MFMAs per K step (meets the reference's fp32 "
+                         "results end to end); f16 = fp16 storage (fast mode, ~1e-3 relative error on the maps)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the same control flow (pipeline protocol, per-step gather, MAX over ranks, one JSON line on "
                          "rank 0) with a stand-in pipeline and the gloo backend -- what the multi-rank CPU test runs")
@@ -286,6 +290,7 @@ def main():
     from exps.stage3_root2.config import cfg as run_cfg
     torch.manual_seed(0)
     net = SMAP(make_cfg((128, 208))).eval().to(dev)
+    net.precision = args.precision
     refine_w = None
     if args.refine:
         from model.refinenet import RefineNet
@@ -375,7 +380,7 @@ def main():
             "metric": "frames/sec at 3x512x832 (SMAP backbone + depth-aware association + 3D lifting)",
             "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"batch={B} x 3x512x832 per GPU, full SMAP + depth-aware PAF association "
                                    f"+ lifting{' + RefineNet (configs[4])' if args.refine else ''} "
                                    f"(BASELINE configs[2]; configs[3] when n_gpus=8)",

@@ -1,0 +1,135 @@
+"""End-to-end parity checker: the HIP path (backbone -> association -> lifting) against the reference path restated on the
+CPU in fp32 (oracle/backbone_ref.py -> oracle/smap_oracle.c) ON THE SAME IMAGES AND WEIGHTS.
+
+CHECKER ONLY (imports the oracle): used by tests/test_e2e_parity_gpu.py, __graft_entry__.smoke() and, outside the timed
+region, by bench.py to fill `config.e2e_parity`.  Reference path: exps/stage3_root2/test.py:50-134.
+
+What is compared, per frame (north_star: "peak indices / limb assignments bit-exact, 3D joints within 1e-3 m"):
+  peaks    the NMS candidates of the 15 key-point channels.  A candidate of one path is MATCHED when the other path has a
+           candidate of the same channel within 0.5 heat-map pixel (the 7x7 centroid moves by ~1e-3 px under a 1e-3
+           relative perturbation of the map; a different integer peak is >= 1 px away).  peak_match = matched / max(nA, nB).
+  persons  skeletons are paired through their root joint (same 0.5 px rule).  person_match = paired / max(PA, PB).
+  limbs    for paired skeletons, a joint agrees when it is absent in both or within 0.5 px in both: limb_match.
+  3D       over paired skeletons and joints present in both: |dX,dY,dZ| in cm -> mpjpe_cm (mean Euclidean), max_joint_err_cm,
+           and root_z_max_err_cm.
+"""
+import numpy as np
+import torch
+
+NJ = 15
+TOL_PX = 0.5
+
+
+def reference_path(sd, imgs, cams, root_idx=2, threads=None):
+    """imgs [B,3,H,W] fp32 CPU, cams [B,9] -> list of per-frame dicts (peaks, bodys, p2, p3, rz, hms, det_d, root_d)."""
+    from oracle import oracle_lib as O
+    from oracle.backbone_ref import smap_forward
+    if threads:
+        torch.set_num_threads(threads)
+    outs = []
+    with torch.no_grad():
+        for i in range(imgs.shape[0]):                      # frame by frame: bounded memory, same numbers (eval-mode BN)
+            hms, det_d, root_d = smap_forward(sd, imgs[i:i + 1])
+            hms = hms[0].clone()
+            hms[:NJ] /= 255                                  # test.py:111-112
+            hms[NJ:] /= 127
+            h, d, r = hms.numpy(), det_d[0].numpy(), root_d[0, 0].numpy()
+            bodys, peaks, _ = O.connect(h, r, root_idx, True)
+            p2, p3, rz = O.lift(bodys, d, r, cams[i])
+            outs.append(dict(peaks=peaks, bodys=bodys, p2=p2, p3=p3, rz=rz, hms=h, det_d=d, root_d=r))
+    return outs
+
+
+def hip_path(net, imgs_dev, cams, root_idx=2):
+    """The product path through its public pieces (model.smap.SMAP -> dapalib batch entry points), per-frame numpy."""
+    from smap_amd import dapalib
+    hms, det_d, root_d = net(imgs_dev)
+    hms = hms.clone()
+    dapalib.scale_hms_(hms)
+    bodys, counts, peaks, _ = dapalib.connect_batch(hms, root_d, root_idx, True, return_intermediate=True)
+    p2, p3, rz = dapalib.lift_batch(bodys, counts, det_d, root_d, cams)
+    torch.cuda.synchronize()
+    counts = counts.cpu().numpy()
+    outs = []
+    for i, P in enumerate(counts):
+        P = int(P)
+        outs.append(dict(peaks=peaks[i].cpu().numpy(), bodys=bodys[i, :P].cpu().numpy(), p2=p2[i, :P].cpu().numpy(),
+                         p3=p3[i, :P].cpu().numpy(), rz=rz[i, :P].cpu().numpy(), hms=hms[i].cpu().numpy(),
+                         det_d=det_d[i].cpu().numpy(), root_d=root_d[i, 0].cpu().numpy()))
+    return outs
+
+
+def _pair(a, b, tol=TOL_PX):
+    """Greedy one-to-one pairing of 2-D points a [n,2], b [m,2] within `tol` (Chebyshev): list of (i, j)."""
+    if len(a) == 0 or len(b) == 0:
+        return []
+    d = np.abs(a[:, None, :] - b[None, :, :]).max(-1)
+    pairs, used = [], set()
+    for i in np.argsort(d.min(1)):
+        for j in np.argsort(d[i]):
+            if d[i, j] > tol:
+                break
+            if j not in used:
+                used.add(j)
+                pairs.append((int(i), int(j)))
+                break
+    return pairs
+
+
+def compare(hip, ref, root_idx=2):
+    """hip / ref: lists of per-frame dicts as above -> metrics dict (plain Python floats/ints)."""
+    n_pk = m_pk = 0
+    n_pe = m_pe = 0
+    n_j = m_j = 0
+    errs, rz_errs = [], []
+    worst_frame = None
+    maps = {"hms": 0.0, "det_d": 0.0, "root_d": 0.0}
+    for f, (a, b) in enumerate(zip(hip, ref)):
+        for k in maps:                                                  # backbone: max |d| / max |ref| per output
+            maps[k] = max(maps[k], float(np.abs(a[k] - b[k]).max() / max(np.abs(b[k]).max(), 1e-30)))
+        for c in range(NJ):
+            na, nb = int(a["peaks"][c, 0, 0]), int(b["peaks"][c, 0, 0])
+            n_pk += max(na, nb)
+            m_pk += len(_pair(a["peaks"][c, 1:1 + na, :2], b["peaks"][c, 1:1 + nb, :2]))
+        A, Bo = a["bodys"], b["bodys"]
+        n_pe += max(len(A), len(Bo))
+        ia = [i for i in range(len(A)) if A[i, root_idx, 3] > 0]
+        ib = [i for i in range(len(Bo)) if Bo[i, root_idx, 3] > 0]
+        pr = _pair(A[ia][:, root_idx, :2] if ia else np.zeros((0, 2)), Bo[ib][:, root_idx, :2] if ib else np.zeros((0, 2)))
+        m_pe += len(pr)
+        for i, j in pr:
+            pa, pb = ia[i], ib[j]
+            va, vb = A[pa, :, 3] > 0, Bo[pb, :, 3] > 0
+            close = np.abs(A[pa, :, :2] - Bo[pb, :, :2]).max(-1) <= TOL_PX
+            agree = (~va & ~vb) | (va & vb & close)
+            n_j += NJ
+            m_j += int(agree.sum())
+            both = va & vb & close
+            if both.any():
+                e = np.linalg.norm(a["p3"][pa, both, :3] - b["p3"][pb, both, :3], axis=-1)
+                errs.extend(e.tolist())
+                if worst_frame is None or e.max() > worst_frame[1]:
+                    worst_frame = (f, float(e.max()))
+            rz_errs.append(abs(float(a["rz"][pa]) - float(b["rz"][pb])))
+    errs = np.asarray(errs) if errs else np.zeros((0,))
+    return {
+        "frames": len(hip), "peaks_ref": int(sum(int(b["peaks"][c, 0, 0]) for b in ref for c in range(NJ))),
+        "peak_match": m_pk / n_pk if n_pk else 1.0, "peaks_unmatched": int(n_pk - m_pk),
+        "persons_ref": int(sum(len(b["bodys"]) for b in ref)), "person_match": m_pe / n_pe if n_pe else 1.0,
+        "limb_match": m_j / n_j if n_j else 1.0, "joints_compared": int(errs.size),
+        "mpjpe_cm": float(errs.mean()) if errs.size else 0.0, "max_joint_err_cm": float(errs.max()) if errs.size else 0.0,
+        "p99_joint_err_cm": float(np.percentile(errs, 99)) if errs.size else 0.0,
+        "root_z_max_err_cm": float(max(rz_errs)) if rz_errs else 0.0,
+        "root_z_mean_cm": float(np.mean([r for b in ref for r in b["rz"]])) if any(len(b["rz"]) for b in ref) else 0.0,
+        "map_rel_err_max": maps,
+    }
+
+
+def run(net, sd, imgs, cam=None, threads=None):
+    """One call for tests / smoke / bench: net = model.smap.SMAP on the GPU with weights `sd`; imgs [B,3,H,W] fp32 CPU."""
+    from .workload import PEOPLE_CAM
+    cams = np.tile(np.asarray(PEOPLE_CAM if cam is None else cam, np.float64), (imgs.shape[0], 1))
+    dev = next(net.parameters()).device
+    hip = hip_path(net, imgs.to(dev), cams)
+    ref = reference_path(sd, imgs, cams, threads=threads)
+    return compare(hip, ref), hip, ref

@@ -149,6 +149,15 @@ typedef struct smap_op {
                                        UPADD: aux[0] = low-res t ; HEADSUM: fp32 NHWC head tensors (arena) */
     int32_t aux_h[3], aux_w[3];     /* their spatial sizes                                       */
     int64_t ext_off;                /* HEADSUM: byte offset of the [B,Cout,Ho,Wo] block in the fp32 output buffer */
+    int32_t precision;              /* CONV/STEM/MAXPOOL: 0 = fp16 activations and weights (one rounding per stored value,
+                                       ~1e-3 relative error through the 200-layer graph); 1 = SPLIT precision, the mode
+                                       that reproduces the reference's fp32 arithmetic (smap.py runs fp32 end to end):
+                                       every fp16 tensor is stored as two planes, pixel = [hi(C) | lo(C)] with
+                                       hi = fp16(v), lo = fp16(v - hi) (in_stride_c / out_stride_c are then 2*C and
+                                       res/add/aux tensors have pixel stride 2*Cout8); weights are two consecutive
+                                       matrices hi | lo of (w * 2^s); three MFMAs per K step (hi*hi + hi*lo + lo*hi)
+                                       into fp32.  fp32 head outputs (out_fp32) and HEADSUM are the same in both modes. */
+    float acc_scale;                /* precision 1: 2^-s, applied to the accumulator before the bias             */
 } smap_op;
 
 /* sizeof(smap_op) as compiled: lets a foreign-language binding verify its struct mirror. */
@@ -156,9 +165,9 @@ int smap_sizeof_op(void);
 
 typedef struct smap_plan smap_plan;
 
-/* Copies `ops`; validates geometry.  n_ops <= 4096.  Arena contract: bytes [0,8192) are reserved
+/* Copies `ops`; validates geometry.  n_ops <= 4096.  Arena contract: bytes [0,16384) are reserved
  * (smap_plan_run zeroes them: padding taps of the conv kernels read there), every tensor offset is
- * >= 8192, and conv inputs must end below 4 GiB (32-bit offsets from the arena base). */
+ * >= 16384, and conv inputs must end below 4 GiB (32-bit offsets from the arena base). */
 int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan);
 void smap_plan_destroy(smap_plan* plan);
 /* Runs the whole schedule on `stream`.

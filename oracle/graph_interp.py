@@ -18,8 +18,10 @@ def _q(x, on):
 
 
 def run_graph(g, imgs, quantize, keep=False):
-    """g: Graph built with keep_ref=True.  Returns (hms, det_d, root_d[, dict name->NCHW tensor])."""
+    """g: Graph built with keep_ref=True.  Returns (hms, det_d, root_d[, dict name->NCHW tensor]).
+    quantize=False computes in the dtype of `imgs` (fp32, or fp64 for a tight reference)."""
     dev = imgs.device
+    dt = torch.float32 if quantize or imgs.dtype != torch.float64 else torch.float64
     blob = g.weight_blob()
     T = {}
     outs = {}
@@ -27,8 +29,8 @@ def run_graph(g, imgs, quantize, keep=False):
     for op in g.ops:
         p = op.p
         if op.kind in (OP_STEM, OP_STEMPOOL):
-            w, b = p["w_ref"].float().to(dev), p["b_ref"].float().to(dev)
-            x0 = imgs.float()
+            w, b = p["w_ref"].to(dt).to(dev), p["b_ref"].to(dt).to(dev)
+            x0 = imgs.to(dt)
             if quantize:                                 # the stem kernel rounds image and weights to fp16
                 x0, w = _q(x0, True), _q(w, True)
             y = _q(F.relu(F.conv2d(x0, w, b, stride=2, padding=3)), quantize)
@@ -44,7 +46,7 @@ def run_graph(g, imgs, quantize, keep=False):
                 w = wk[:cout].float().view(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()
                 b = blob[p["bias_off"]:p["bias_off"] + p["cout_pad"] * 4].view(torch.float32)[:cout].clone()
             else:
-                w, b = p["w_ref"].float(), p["b_ref"].float()
+                w, b = p["w_ref"].to(dt), p["b_ref"].to(dt)
             y = F.conv2d(x, w.to(dev), b.to(dev), stride=p["stride"], padding=p["pad"])
             if op.res is not None:
                 y = y + T[op.res.name]

@@ -39,9 +39,17 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 #endif
 // FULL = false: epilogue with bias / residual / ReLU only (most layers: ~45 fewer VGPRs, more workgroups per CU);
 // FULL = true : + fused bilinear add and post-ReLU addends.
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL>
+// X3 = true  : fp32-equivalent arithmetic on the fp16 matrix cores (smap_op.precision = 1).  Every activation and weight
+//              is stored as TWO fp16 planes hi = fp16(v), lo = fp16(v - hi) (22 significant bits; a pixel is [hi(C) | lo(C)],
+//              the weight matrix [cout_pad][K] hi followed by [cout_pad][K] lo, pre-scaled by a power of two so that lo
+//              stays in fp16's normal range) and a K step issues three MFMAs into the same fp32 accumulator:
+//              hi*hi + hi*lo + lo*hi (the dropped lo*lo term is 2^-24 relative).  A K tile stages four LDS images
+//              (A hi, A lo, W hi, W lo); the epilogue re-splits the fp32 result.  3x the MFMA work and 2x the bytes of
+//              the fp16 mode, ~1e-6 relative error instead of ~1e-3: the mode whose output meets the reference's fp32.
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 {
+    constexpr int NPL = X3 ? 2 : 1;                    // fp16 planes per operand
     static_assert(WM * WN == 4, "4 waves");
     static_assert(STAGES >= 2 && STAGES <= 4, "2..4 LDS stages");
     static_assert(BK == 32 || BK == 64, "BK = halves per K chunk");
@@ -53,8 +61,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     constexpr int LA = BM / RPR, LB = BN / RPR;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     static_assert(MI >= 1 && NI >= 1, "tile too small for the wave grid");
-    constexpr int STAGE = (BM + BN) * ROWB;
-    constexpr int LPT = LA + LB;                       // LDS-DMA loads per thread per K tile
+    constexpr int STAGE = NPL * (BM + BN) * ROWB;      // [A planes][B planes]
+    constexpr int LPT = NPL * (LA + LB);               // LDS-DMA loads per thread per K tile
     static_assert((STAGES - 2) * LPT <= 63, "vmcnt is 6 bits");
     constexpr int LDS_BYTES = STAGES * STAGE > BM * BN * 4 ? STAGES * STAGE : BM * BN * 4;   // pipeline | fp32 epilogue tile
     static_assert(LDS_BYTES <= 160 * 1024, "LDS is 160 KiB per CU");
@@ -102,11 +110,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     for (int i = 0; i < LB; ++i)
         b_off[i] = (unsigned)(((n0 + i * RPR + srow) * a.K + gch * 8) * 2);
     auto issue_b = [&](int buf, unsigned boff) {
-        char* sB = smem + buf * STAGE + BM * ROWB;
-        const char* gB = wt + boff;
 #pragma unroll
-        for (int i = 0; i < LB; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
+        for (int pl = 0; pl < NPL; ++pl) {
+            char* sB = smem + buf * STAGE + (NPL * BM + pl * BN) * ROWB;
+            const char* gB = wt + boff + (X3 ? (long long)pl * a.w_lo : 0LL);
+#pragma unroll
+            for (int i = 0; i < LB; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
+        }
     };
     if (!(SMAP_ABLATE & 1)) issue_b(0, 0);
 
@@ -159,11 +170,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     };
     set_tap();
     auto issue_a = [&](int buf) {
-        char* sA = smem + buf * STAGE;
-        const char* gA = arena + (unsigned)(s_cc * ROWB);          // invalid taps: a_cur = 0 -> zero page + s_cc*ROWB
 #pragma unroll
-        for (int i = 0; i < LA; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
+        for (int pl = 0; pl < NPL; ++pl) {
+            char* sA = smem + buf * STAGE + pl * BM * ROWB;
+            // invalid taps: a_cur = 0 -> zero page + s_cc*ROWB (+ the lo-plane offset: the zero page covers both)
+            const char* gA = arena + (unsigned)(s_cc * ROWB + (X3 ? pl * a.in_lo * 2 : 0));
+#pragma unroll
+            for (int i = 0; i < LA; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
+        }
     };
     auto advance = [&]() {
         s_boff += ROWB;
@@ -186,15 +201,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     constexpr int CG = BN / 8;                    // channel groups per row
     constexpr int PASSES = BM * CG / 256;
     static_assert(BM * CG % 256 == 0, "tile/thread mismatch");
-    half8 rres[PASSES];
+    half8 rres[PASSES][NPL];
     if (a.res) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int idx = p * 256 + tid;
             const int row = idx / CG, cg = idx - row * CG;
             const int m = m0 + row, n = n0 + cg * 8;
-            const long long dense = (m < a.M && n < a.Cout8) ? (long long)m * a.Cout8 + n : 0;
-            rres[p] = *reinterpret_cast<const half8*>(a.res + dense);
+            const long long dense = (m < a.M && n < a.Cout8) ? (long long)m * (NPL * a.Cout8) + n : 0;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                rres[p][pl] = *reinterpret_cast<const half8*>(a.res + dense + pl * a.Cout8);
         }
     }
 
@@ -236,22 +253,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #endif
         if (it + STAGES - 1 < n_iter && !(SMAP_ABLATE & 1)) stage(nbuf);
         const char* sA = smem + buf * STAGE;
-        const char* sB = sA + BM * ROWB;
+        const char* sB = sA + NPL * BM * ROWB;
 #pragma unroll
         for (int kk = 0; kk < ((SMAP_ABLATE & 2) ? 0 : BK / 16); ++kk) {
             const int slot = ((kk * 2 + lhi) ^ rswz) * 16;
-            half8 af[MI], bf[NI];
+            half8 af[NPL][MI], bf[NPL][NI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                af[mi] = *reinterpret_cast<const half8*>(sA + (a_row0 + mi * 32) * ROWB + slot);
+            for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                bf[ni] = *reinterpret_cast<const half8*>(sB + (b_row0 + ni * 32) * ROWB + slot);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
+                    af[pl][mi] = *reinterpret_cast<const half8*>(sA + (pl * BM + a_row0 + mi * 32) * ROWB + slot);
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                    bf[pl][ni] = *reinterpret_cast<const half8*>(sB + (pl * BN + b_row0 + ni * 32) * ROWB + slot);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if (X3) {       // small cross terms first, then hi*hi
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[NPL - 1][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][mi], bf[NPL - 1][ni], acc[mi][ni], 0, 0, 0);
+                    }
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
+                }
         }
         buf = buf + 1 == STAGES ? 0 : buf + 1;
         nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
@@ -274,7 +299,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * (BM / WM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                Cs[row * BN + col] = acc[mi][ni][r] + bias;
+                Cs[row * BN + col] = X3 ? acc[mi][ni][r] * a.acc_scale + bias : acc[mi][ni][r] + bias;
             }
     }
     __syncthreads();
@@ -282,7 +307,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     // ---- epilogue 2: 8 consecutive channels of one pixel per thread.  Software-pipelined over the
     //      passes: the global loads of pass p+1 (bilinear taps, post-ReLU addends) are issued before the
     //      arithmetic + store of pass p, so one memory round trip is exposed per tile, not per pass.
-    struct Extra { half8 t00, t01, t10, t11, a1, a2; float ly0, ly1, lx0, lx1; bool ok; long long o; int row, cg; };
+    struct Extra { half8 t00[NPL], t01[NPL], t10[NPL], t11[NPL], a1[NPL], a2[NPL]; float ly0, ly1, lx0, lx1; bool ok; long long o; int row, cg; };
+    constexpr int TS = NPL;                                        // pixel stride multiplier of the dense split tensors
+    auto val = [](const half8 (&h)[NPL], int e) -> float {       // hi (+ lo) -> fp32, exact
+        return X3 ? (float)h[0][e] + (float)h[NPL - 1][e] : (float)h[0][e];
+    };
     auto load_pass = [&](int p) -> Extra {
         Extra x;
         const int idx = p * 256 + tid;
@@ -291,21 +320,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         const int m = m0 + x.row, n = n0 + x.cg * 8;
         x.ok = m < a.M && n < a.Cout8 && !((SMAP_ABLATE & 4) && a.M != 7);
         const int ms = x.ok ? m : 0, ns = x.ok ? n : 0;            // clamped: loads stay in bounds
-        const long long dense = (long long)ms * a.Cout8 + ns;     // res/add tensors are dense [M][Cout8]
+        const long long dense = (long long)ms * (TS * a.Cout8) + ns;     // res/add tensors are dense [M][Cout8] (x planes)
         x.o = (long long)ms * a.out_stride_c + a.out_c_off + ns;
         if (FULL && a.up) {
             const int b = ms / HoWo, rem = ms - b * HoWo;
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
             const Lerp ly = lerp_index(oy, a.up_h, a.Ho), lx = lerp_index(ox, a.up_w, a.Wo);
-            const _Float16* tb = a.up + (long long)b * a.up_h * a.up_w * a.Cout8 + ns;
-            x.t00 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i0) * a.Cout8);
-            x.t01 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i1) * a.Cout8);
-            x.t10 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i0) * a.Cout8);
-            x.t11 = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i1) * a.Cout8);
+            const int us = TS * a.Cout8;
+            const _Float16* tb = a.up + (long long)b * a.up_h * a.up_w * us + ns;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                x.t00[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i0) * us + pl * a.Cout8);
+                x.t01[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i1) * us + pl * a.Cout8);
+                x.t10[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i0) * us + pl * a.Cout8);
+                x.t11[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i1) * us + pl * a.Cout8);
+            }
             x.ly0 = ly.l0; x.ly1 = ly.l1; x.lx0 = lx.l0; x.lx1 = lx.l1;
         }
-        if (FULL && a.add1) x.a1 = *reinterpret_cast<const half8*>(a.add1 + dense);
-        if (FULL && a.add2) x.a2 = *reinterpret_cast<const half8*>(a.add2 + dense);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            if (FULL && a.add1) x.a1[pl] = *reinterpret_cast<const half8*>(a.add1 + dense + pl * a.Cout8);
+            if (FULL && a.add2) x.a2[pl] = *reinterpret_cast<const half8*>(a.add2 + dense + pl * a.Cout8);
+        }
         return x;
     };
     auto finish_pass = [&](int p, const Extra& x) {
@@ -318,14 +354,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         }
         if (a.res) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)rres[p][e];
+            for (int e = 0; e < 8; ++e) v[e] += val(rres[p], e);
         }
         if (FULL && a.up) {        // Upsample_unit: out = relu(u_skip(x) + up_conv(bilinear_up(prev))) (smap.py:213-217); the
                            // 1x1 up_conv was applied at low resolution, this is its bilinear resampling
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                v[e] += x.ly0 * (x.lx0 * (float)x.t00[e] + x.lx1 * (float)x.t01[e]) +
-                        x.ly1 * (x.lx0 * (float)x.t10[e] + x.lx1 * (float)x.t11[e]);
+                v[e] += x.ly0 * (x.lx0 * val(x.t00, e) + x.lx1 * val(x.t01, e)) +
+                        x.ly1 * (x.lx0 * val(x.t10, e) + x.lx1 * val(x.t11, e));
         }
         if (a.relu) {
 #pragma unroll
@@ -333,11 +369,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         }
         if (FULL && a.add1) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)x.a1[e];
+            for (int e = 0; e < 8; ++e) v[e] += val(x.a1, e);
         }
         if (FULL && a.add2) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)x.a2[e];
+            for (int e = 0; e < 8; ++e) v[e] += val(x.a2, e);
         }
         if (!x.ok) return;
         if (a.out_fp32) {
@@ -349,6 +385,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
             *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + x.o) = h;
+            if (X3) {           // lo plane: the part of v that fp16 dropped (v - hi is exact in fp32)
+                half8 l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) l[e] = (_Float16)(v[e] - (float)h[e]);
+                *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + x.o + a.out_lo) = l;
+            }
         }
     };
     TR(4);
@@ -375,10 +417,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64>
 hipError_t launch(const ConvArgs& a, hipStream_t st)
 {
+    if (a.x3) return hipErrorInvalidValue;                 // split-precision ops use the tiles of launch_x3 only
     if (a.up || a.add1 || a.add2)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, true>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, true, false>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, false>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// split-precision (X3) instances: the same tile ids select them when the op says precision = 1
+template <int BM, int BN, int WM, int WN, int STAGES, int BK>
+hipError_t launch_x3(const ConvArgs& a, hipStream_t st)
+{
+    if (a.up || a.add1 || a.add2)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, true, true>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, true>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -405,8 +459,26 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
     }
 }
 
+// tiles that have a split-precision instance (plan.hip::validate asks)
+int smap_conv_tile_has_x3(int tile)
+{
+    return tile == 3 || (tile >= 20 && tile <= 23) || tile == 25 || tile == 27;
+}
+
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
 {
+    if (a.x3) {
+        switch (tile) {                                     // LDS = max(STAGES * 2 * (BM + BN) * row bytes, fp32 epilogue tile)
+            case 3: return launch_x3<128, 32, 4, 1, 2, 64>(a, st);    // 80 KiB (Cout <= 32 heads)
+            case 20: return launch_x3<128, 128, 2, 2, 2, 32>(a, st);  // 64 KiB
+            case 21: return launch_x3<128, 64, 2, 2, 2, 32>(a, st);   // 48 KiB
+            case 22: return launch_x3<64, 64, 2, 2, 2, 32>(a, st);    // 32 KiB
+            case 23: return launch_x3<64, 128, 2, 2, 2, 32>(a, st);   // 48 KiB
+            case 25: return launch_x3<128, 64, 2, 2, 3, 32>(a, st);   // 72 KiB, 2 tiles in flight
+            case 27: return launch_x3<64, 128, 2, 2, 3, 32>(a, st);   // 72 KiB
+            default: return hipErrorInvalidValue;
+        }
+    }
     if (tile >= 10 && tile < 20) return smap_launch_conv2(a, tile, st);
     if (tile >= 30 && tile < 40) return smap_launch_conv3(a, tile, st);
     if (tile >= 40 && tile < 50) return smap_launch_conv1(a, tile, st);

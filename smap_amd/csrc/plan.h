@@ -19,6 +19,12 @@ struct ConvArgs {
     int ksize, stride, pad, relu;
     int out_stride_c, out_c_off, out_fp32;
     int M, K, m_tiles, n_tiles;
+    // split-precision mode (smap_op.precision = 1, conv.hip X3): every fp16 tensor is [pixel][hi(C) | lo(C)]
+    int x3;                  // 0 = fp16 storage, 1 = hi/lo split storage, three MFMAs per K step
+    int in_lo;               // halves from a pixel's hi channel c to its lo channel c (input tensor)
+    int out_lo;              // same for the output tensor (fp16 outputs only)
+    long long w_lo;          // bytes from the hi weight matrix to the lo weight matrix
+    float acc_scale;         // accumulator multiplier undoing the power-of-two weight pre-scale
 #ifdef SMAP_TRACE
     long long* dbg;          // diagnostics build only (tools/build_ablate.py --trace): per-workgroup phase stamps
 #endif
@@ -48,6 +54,7 @@ __device__ __forceinline__ Lerp lerp_index(int dst, int in_size, int out_size)
 }
 
 int smap_conv_tile_dims(int tile, int* bm, int* bn);
+int smap_conv_tile_has_x3(int tile);                                        // conv.hip: tile ids with a split-precision instance
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st);
 int smap_conv2_tile_dims(int tile, int* bm, int* bn);                       // conv2.hip (tile ids >= 10)
 hipError_t smap_launch_conv2(const ConvArgs& a, int tile, hipStream_t st);

@@ -35,15 +35,19 @@ constexpr int ST_K = 176;                                      // 22 granules x 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
+// X3 (smap_op.precision = 1): image and weights as fp16 hi/lo pairs, three MFMAs per K step, output pixel = [hi(64) | lo(64)]
+// (see conv.hip).  The weight blob then holds [64][176] hi followed by [64][176] lo of (w * 2^s); acc_scale = 2^-s.
+template <bool X3>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const _Float16* __restrict__ wk,
                                                    const float* __restrict__ bias, _Float16* __restrict__ out,
-                                                   int H, int W, int Ho, int Wo)
+                                                   int H, int W, int Ho, int Wo, float acc_scale)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 s_w[64 * ST_K];
-    __shared__ __attribute__((aligned(16))) _Float16 s_p[3 * ST_PH * ST_PW];
+    constexpr int NPL = X3 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) _Float16 s_w[NPL * 64 * ST_K];
+    __shared__ __attribute__((aligned(16))) _Float16 s_p[NPL * 3 * ST_PH * ST_PW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, oy0 = blockIdx.y * ST_T, ox0 = blockIdx.x * ST_T;
-    for (int i = tid; i < 64 * ST_K / 8; i += 256)
+    for (int i = tid; i < NPL * 64 * ST_K / 8; i += 256)
         reinterpret_cast<half8*>(s_w)[i] = reinterpret_cast<const half8*>(wk)[i];
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     for (int i = tid; i < 3 * ST_PH * ST_PW; i += 256) {
@@ -53,7 +57,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
         float v = 0.f;
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
             v = img[(((size_t)b * 3 + c) * H + iy) * W + ix];
-        s_p[i] = (_Float16)v;
+        const _Float16 hi = (_Float16)v;
+        s_p[i] = hi;
+        if (X3) s_p[3 * ST_PH * ST_PW + i] = (_Float16)(v - (float)hi);
     }
     __syncthreads();
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -77,42 +83,54 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
         const int gg = g < 21 ? g : 20;                        // granule 21 has zero weights: any in-bounds read
         const int kh = gg / 3, c = gg - kh * 3;
         const int goff = (c * ST_PH + kh) * ST_PW;
-        half8 wf[2], pf[2];
+        half8 wf[NPL][2], pf[NPL][2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            wf[nt] = *reinterpret_cast<const half8*>(s_w + (nt * 32 + l31) * ST_K + g * 8);
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {                          // 8 consecutive columns, 4-byte aligned: 4 x b32
-            const unsigned* q = reinterpret_cast<const unsigned*>(s_p + pbase[t] + goff);
-            union { unsigned u[4]; half8 h; } cv;
-            cv.u[0] = q[0]; cv.u[1] = q[1]; cv.u[2] = q[2]; cv.u[3] = q[3];
-            pf[t] = cv.h;
+            for (int nt = 0; nt < 2; ++nt)
+                wf[pl][nt] = *reinterpret_cast<const half8*>(s_w + pl * 64 * ST_K + (nt * 32 + l31) * ST_K + g * 8);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                      // 8 consecutive columns, 4-byte aligned: 4 x b32
+                const unsigned* q = reinterpret_cast<const unsigned*>(s_p + pl * 3 * ST_PH * ST_PW + pbase[t] + goff);
+                union { unsigned u[4]; half8 h; } cv;
+                cv.u[0] = q[0]; cv.u[1] = q[1]; cv.u[2] = q[2]; cv.u[3] = q[3];
+                pf[pl][t] = cv.h;
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], pf[t], acc[nt][t], 0, 0, 0);
+            for (int t = 0; t < 2; ++t) {
+                if (X3) {
+                    acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[NPL - 1][nt], pf[0][t], acc[nt][t], 0, 0, 0);
+                    acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nt], pf[NPL - 1][t], acc[nt][t], 0, 0, 0);
+                }
+                acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nt], pf[0][t], acc[nt][t], 0, 0, 0);
+            }
     }
     // D[n][pixel]: lane = pixel (col l31), reg r -> channel nt*32 + (r&3) + 8*(r>>2) + 4*lhi
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int oy = oy0 + 4 * wave + 2 * t + (l31 >> 4), ox = ox0 + (l31 & 15);
         if (oy >= Ho || ox >= Wo) continue;
-        _Float16* op = out + (((size_t)b * Ho + oy) * Wo + ox) * 64;
+        _Float16* op = out + (((size_t)b * Ho + oy) * Wo + ox) * (NPL * 64);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n0 = nt * 32 + 8 * q + 4 * lhi;
                 const float4 bv = *reinterpret_cast<const float4*>(bias + n0);
-                half4 h;
-                float v;
-                v = acc[nt][t][4 * q + 0] + bv.x; h[0] = (_Float16)(v > 0.f ? v : 0.f);
-                v = acc[nt][t][4 * q + 1] + bv.y; h[1] = (_Float16)(v > 0.f ? v : 0.f);
-                v = acc[nt][t][4 * q + 2] + bv.z; h[2] = (_Float16)(v > 0.f ? v : 0.f);
-                v = acc[nt][t][4 * q + 3] + bv.w; h[3] = (_Float16)(v > 0.f ? v : 0.f);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                half4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = X3 ? acc[nt][t][4 * q + e] * acc_scale + bb[e] : acc[nt][t][4 * q + e] + bb[e];
+                    v = v > 0.f ? v : 0.f;
+                    h[e] = (_Float16)v;
+                    l[e] = (_Float16)(v - (float)h[e]);
+                }
                 *reinterpret_cast<half4*>(op + n0) = h;
+                if (X3) *reinterpret_cast<half4*>(op + 64 + n0) = l;
             }
     }
 }
@@ -237,9 +255,12 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
 
 // --------------------------------------------------------------- maxpool --
 // NHWC fp16, 3x3 stride 2 pad 1 (padding never wins: only in-range taps are read).
+// X3: pixel = [hi(C) | lo(C)]; the maximum is taken over hi + lo (exact in fp32) and re-split (the same pair comes back).
+template <bool X3>
 __global__ void maxpool_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, int B, int H, int W,
                                int C, int Ho, int Wo)
 {
+    constexpr int NPL = X3 ? 2 : 1;
     const int cg_n = C / 8;
     const long long total = (long long)B * Ho * Wo * cg_n;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -258,15 +279,29 @@ __global__ void maxpool_kernel(const _Float16* __restrict__ in, _Float16* __rest
             for (int dx = 0; dx < 3; ++dx) {
                 const int ix = ox * 2 - 1 + dx;
                 if ((unsigned)ix >= (unsigned)W) continue;
-                const half8 v = *reinterpret_cast<const half8*>(in + (((size_t)b * H + iy) * W + ix) * C + cg * 8);
+                const _Float16* ip = in + (((size_t)b * H + iy) * W + ix) * (NPL * C) + cg * 8;
+                const half8 v = *reinterpret_cast<const half8*>(ip);
+                if (X3) {
+                    const half8 vl = *reinterpret_cast<const half8*>(ip + C);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+                    for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e] + (float)vl[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+                }
             }
         }
         half8 h;
 #pragma unroll
         for (int e = 0; e < 8; ++e) h[e] = (_Float16)m[e];
-        *reinterpret_cast<half8*>(out + (((size_t)b * Ho + oy) * Wo + ox) * C + cg * 8) = h;
+        _Float16* op = out + (((size_t)b * Ho + oy) * Wo + ox) * (NPL * C) + cg * 8;
+        *reinterpret_cast<half8*>(op) = h;
+        if (X3) {
+            half8 l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) l[e] = (_Float16)(m[e] - (float)h[e]);
+            *reinterpret_cast<half8*>(op + C) = l;
+        }
     }
 }
 
@@ -373,16 +408,25 @@ struct smap_plan {
 
 // The first SMAP_ZERO_PAGE bytes of the arena are the conv kernels' "zero page": padding taps and
 // rows past M fetch their 16 bytes there.  smap_plan_run clears it on the stream before the first op.
-constexpr int64_t SMAP_ZERO_PAGE = 8192;   // >= max Cin * 2 bytes + 16: a padding tap reads zero page + chunk*128
+constexpr int64_t SMAP_ZERO_PAGE = 16384;  // >= max Cin * 2 bytes + 16 (+ the lo-plane offset, <= 4096, in split precision):
+                                           // a padding tap reads zero page + chunk*128 (+ lo offset)
 
 static int validate(const smap_op& o)
 {
     if (o.B <= 0 || o.H <= 0 || o.W <= 0 || o.Ho <= 0 || o.Wo <= 0 || o.Cout <= 0) return SMAP_E_ARG;
+    if (o.precision != 0 && o.precision != 1) return SMAP_E_ARG;
+    if (o.precision == 1 && o.kind != SMAP_OP_CONV && o.kind != SMAP_OP_STEM && o.kind != SMAP_OP_MAXPOOL && o.kind != SMAP_OP_HEADSUM)
+        return SMAP_E_ARG;                               // UPADD / STEMPOOL have no split-precision instance
     switch (o.kind) {
         case SMAP_OP_CONV: {
             int bm, bn;
             if (smap_conv_tile_dims(o.tile, &bm, &bn)) return SMAP_E_ARG;
             if (o.Cin % 64 || o.Cin * 2 + 16 > SMAP_ZERO_PAGE || o.cout_pad % bn || o.cout_pad < o.Cout) return SMAP_E_ARG;
+            if (o.precision == 1) {
+                if (!smap_conv_tile_has_x3(o.tile) || o.in_stride_c % 16 || (!o.out_fp32 && o.out_stride_c % 16)) return SMAP_E_ARG;
+                if (o.Cin * 2 + o.in_stride_c + 16 > SMAP_ZERO_PAGE || !(o.acc_scale > 0.f)) return SMAP_E_ARG;
+                if (o.in_c_off + o.Cin > o.in_stride_c / 2) return SMAP_E_ARG;
+            }
             if (o.ksize != 1 && o.ksize != 3) return SMAP_E_ARG;
             if (o.tile >= 40 && o.tile < 50 && (o.ksize != 1 || o.stride != 1 || (o.Cin != 64 && o.Cin != 128 && o.Cin != 256)))
                 return SMAP_E_ARG;                       // weight-stationary kernel: 1x1 stride-1, weights fit the register file
@@ -396,7 +440,7 @@ static int validate(const smap_op& o)
             if (o.in_off < SMAP_ZERO_PAGE || o.out_off < SMAP_ZERO_PAGE || o.w_off < 0 || o.bias_off < 0) return SMAP_E_ARG;
             // conv A-operand addresses are 32-bit byte offsets from the arena base
             if (o.in_off + (int64_t)o.B * o.H * o.W * o.in_stride_c * 2 > ((int64_t)1 << 32)) return SMAP_E_ARG;
-            if ((int64_t)o.cout_pad * o.ksize * o.ksize * o.Cin * 2 > ((int64_t)1 << 32)) return SMAP_E_ARG;
+            if ((int64_t)o.cout_pad * o.ksize * o.ksize * o.Cin * 2 * (1 + o.precision) > ((int64_t)1 << 32)) return SMAP_E_ARG;
             if (o.Ho != (o.H + 2 * o.pad - o.ksize) / o.stride + 1) return SMAP_E_ARG;
             if (o.Wo != (o.W + 2 * o.pad - o.ksize) / o.stride + 1) return SMAP_E_ARG;
             return 0;
@@ -502,6 +546,11 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                 a.out_stride_c = o.out_stride_c; a.out_c_off = o.out_c_off; a.out_fp32 = o.out_fp32;
                 a.M = o.B * o.Ho * o.Wo;
                 a.K = o.ksize * o.ksize * o.Cin;
+                a.x3 = o.precision;
+                a.in_lo = o.in_stride_c / 2;
+                a.out_lo = o.out_stride_c / 2;
+                a.w_lo = (long long)o.cout_pad * a.K * 2;
+                a.acc_scale = o.acc_scale;
                 int bm, bn;
                 smap_conv_tile_dims(o.tile, &bm, &bn);
                 a.m_tiles = (a.M + bm - 1) / bm;
@@ -512,10 +561,16 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
             case SMAP_OP_STEM: {
                 if (!input) return SMAP_E_ARG;
                 dim3 grid((o.Wo + ST_T - 1) / ST_T, (o.Ho + ST_T - 1) / ST_T, o.B);
-                hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, st, input,
-                                   reinterpret_cast<const _Float16*>(wb + o.w_off),
-                                   reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, o.Ho,
-                                   o.Wo);
+                if (o.precision)
+                    hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, st, input,
+                                       reinterpret_cast<const _Float16*>(wb + o.w_off),
+                                       reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, o.Ho,
+                                       o.Wo, o.acc_scale);
+                else
+                    hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, st, input,
+                                       reinterpret_cast<const _Float16*>(wb + o.w_off),
+                                       reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, o.Ho,
+                                       o.Wo, 1.f);
                 e = hipGetLastError();
                 break;
             }
@@ -532,8 +587,12 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
             }
             case SMAP_OP_MAXPOOL: {
                 const long long total = (long long)o.B * o.Ho * o.Wo * (o.Cin / 8);
-                hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, A(o.in_off),
-                                   A(o.out_off), o.B, o.H, o.W, o.Cin, o.Ho, o.Wo);
+                if (o.precision)
+                    hipLaunchKernelGGL(maxpool_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, st, A(o.in_off),
+                                       A(o.out_off), o.B, o.H, o.W, o.Cin, o.Ho, o.Wo);
+                else
+                    hipLaunchKernelGGL(maxpool_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, st, A(o.in_off),
+                                       A(o.out_off), o.B, o.H, o.W, o.Cin, o.Ho, o.Wo);
                 e = hipGetLastError();
                 break;
             }

@@ -16,7 +16,10 @@ floating-point rounding):
   * the three 1x1 head convs of stage-2/up4 share their input and run as one N=768 GEMM;
   * residual add, ReLU and the inter-stage skip adds (smap.py:142-153) run in the
     epilogue of the producing conv.
-Activations are NHWC fp16, accumulation fp32, head outputs fp32.
+Activations are NHWC fp16, accumulation fp32, head outputs fp32 (precision "f16"), or -- precision "x3", the mode
+whose results meet the reference's fp32 arithmetic -- every activation and weight as an fp16 hi/lo PAIR (22 significant
+bits) with three MFMAs per K step (csrc/conv.hip, template X3): ~1e-6 relative error through the whole graph instead of
+~1e-3, at 3x the matrix work and 2x the bytes.
 """
 import ctypes as C
 from dataclasses import dataclass, field
@@ -57,7 +60,37 @@ def _tile_remap():
 LAYERS = (3, 4, 6, 3)            # smap.py:299  resnet-50
 PLANES = (64, 128, 256, 512)
 ALIGN = 256
-ZERO_PAGE = 8192              # csrc/plan.hip SMAP_ZERO_PAGE
+ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
+PRECISIONS = ("f16", "x3")
+X3_TILES = (20, 21, 22, 23)   # BK = 32 tiles of conv.hip that have a split-precision instance (+ tile 3 for Cout <= 32)
+
+
+def split_f16(w, scaled=True):
+    """f64 tensor -> (hi, lo fp16 tensors of w * 2^s, 2^-s): hi = fp16(w 2^s), lo = fp16(w 2^s - hi).  s puts max |w| in
+    [2^13, 2^14) so that the lo parts of all but vanishing weights are normal fp16 numbers."""
+    import math
+    m = float(w.abs().max())
+    s = (13 - math.frexp(m)[1] + 1) if (scaled and m > 0) else 0          # frexp: m = f * 2^e, f in [0.5, 1)
+    ws = w.double() * (2.0 ** s)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.double()).to(torch.float16)
+    assert torch.isfinite(hi).all()
+    return hi, lo, 2.0 ** -s
+
+
+def pick_tile_x3(M, cout):
+    """Split precision: largest BK = 32 tile that still gives >= 512 workgroups, else the one with most workgroups."""
+    if cout <= 32:
+        return 3
+    best, best_blocks = None, -1
+    for t in ((21, 22) if cout <= 64 else (20, 23, 21, 22)):
+        bm, bn = TILES[t]
+        blocks = -(-M // bm) * (-(-cout // bn))
+        if blocks >= 512:
+            return t
+        if blocks > best_blocks:
+            best, best_blocks = t, blocks
+    return best
 
 
 def _rup(x, m):
@@ -86,13 +119,14 @@ class Tensor:
     W: int
     C: int                 # channel stride of a pixel
     esize: int = 2         # bytes per element (2 = fp16, 4 = fp32)
+    planes: int = 1        # 2 = split precision: a pixel is [hi(C) | lo(C)] fp16
     first: int = -1
     last: int = -1
     off: int = -1
 
     @property
     def nbytes(self):
-        return self.B * self.H * self.W * self.C * self.esize
+        return self.B * self.H * self.W * self.C * self.esize * self.planes
 
 
 @dataclass
@@ -162,7 +196,9 @@ DEFAULT_REMAP = {}
 
 
 class Graph:
-    def __init__(self, sd, B, H, W, stage_num=3, chl=256, kpt_paf=43, paf=14, keep_ref=False):
+    def __init__(self, sd, B, H, W, stage_num=3, chl=256, kpt_paf=43, paf=14, keep_ref=False, precision="f16"):
+        assert precision in PRECISIONS, precision
+        self.precision, self.x3 = precision, precision == "x3"
         self.keep_ref = keep_ref
         assert H % 32 == 0 and W % 32 == 0, "input must be a multiple of 32 (5 stride-2 levels)"
         self.sd, self.B, self.H, self.W = sd, B, H, W
@@ -174,7 +210,7 @@ class Graph:
 
     # -- helpers
     def tensor(self, name, H, W, C, esize=2):
-        t = Tensor(name, self.B, H, W, C, esize)
+        t = Tensor(name, self.B, H, W, C, esize, 2 if (self.x3 and esize == 2) else 1)
         self.tensors.append(t)
         return t
 
@@ -200,18 +236,25 @@ class Graph:
         M = self.B * Ho * Wo
         tile = pick_tile(M, cout, f"{self.B},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
         tile = {**DEFAULT_REMAP, **_tile_remap()}.get(tile, tile)
+        if self.x3:
+            tile = pick_tile_x3(M, cout)
+            x3t = os.environ.get("SMAP_X3_TILE", "")         # A/B hook: force one split-precision tile where it fits
+            if x3t and cout > 32 and not (cout <= 64 and TILES[int(x3t)][1] > 64):
+                tile = int(x3t)
         plain3 = ksize == 3 and stride == 1 and res is None and add1 is None and add2 is None and up is None
-        if 30 <= tile < 40 and not plain3:                # the halo-tiled kernel has no fused epilogues (table keyed by shape only)
+        if self.x3:
+            pass
+        elif 30 <= tile < 40 and not plain3:                # the halo-tiled kernel has no fused epilogues (table keyed by shape only)
             tile = pick_tile_heuristic(M, cout)
         ws1 = os.environ.get("SMAP_WS1", "")          # A/B hook: "40" / "41" -> weight-stationary kernel for every eligible 1x1
-        if 40 <= tile < 50 and not (ksize == 1 and stride == 1 and cin in (64, 128, 256)):
+        if not self.x3 and 40 <= tile < 50 and not (ksize == 1 and stride == 1 and cin in (64, 128, 256)):
             tile = pick_tile_heuristic(M, cout)
-        if ws1 and ksize == 1 and stride == 1 and cin in (64, 128, 256) and cout % 256 == 0:
+        if not self.x3 and ws1 and ksize == 1 and stride == 1 and cin in (64, 128, 256) and cout % 256 == 0:
             lim = os.environ.get("SMAP_WS1_MIN_M", "")
             if not lim or M >= int(lim):
                 tile = int(ws1)
         halo = os.environ.get("SMAP_HALO3", "")     # A/B hook: "16" / "32" = pixel-tile width, optional ":64" / ":128" = BN
-        if halo and plain3 and cout > 32:
+        if not self.x3 and halo and plain3 and cout > 32:
             tw, _, hbn = halo.partition(":")
             hbn = int(hbn) if hbn else min(TILES[tile][1], 128 if cout > 64 else 64)
             tile = {(16, 64): 30, (16, 128): 31, (32, 64): 32, (32, 128): 33}[(int(tw), max(hbn, 64))]
@@ -219,8 +262,14 @@ class Graph:
         bn = TILES[tile][1]
         cout_pad = _rup(cout, bn)
         K = ksize * ksize * cin
-        wk = torch.zeros((cout_pad, K), dtype=torch.float16)
-        wk[:cout] = w.permute(0, 2, 3, 1).reshape(cout, K).to(torch.float16)
+        acc_scale = 1.0
+        if self.x3:                     # [cout_pad][K] hi | [cout_pad][K] lo of w * 2^s
+            hi, lo, acc_scale = split_f16(w.permute(0, 2, 3, 1).reshape(cout, K))
+            wk = torch.zeros((2, cout_pad, K), dtype=torch.float16)
+            wk[0, :cout], wk[1, :cout] = hi, lo
+        else:
+            wk = torch.zeros((cout_pad, K), dtype=torch.float16)
+            wk[:cout] = w.permute(0, 2, 3, 1).reshape(cout, K).to(torch.float16)
         bk = torch.zeros((cout_pad,), dtype=torch.float32)
         bk[:cout] = b.to(torch.float32)
         out = self.tensor(name, Ho, Wo, _rup(cout, 8), 4 if out_fp32 else 2)
@@ -228,6 +277,7 @@ class Graph:
         self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, aux=[up] if up is not None else [], p=dict(
             Cin=cin, in_c_off=in_c_off, Cout=cout, ksize=ksize, stride=stride, pad=pad, relu=int(relu),
             cout_pad=cout_pad, tile=tile, out_fp32=int(out_fp32), w_off=self._add_w(wk), bias_off=self._add_w(bk),
+            acc_scale=acc_scale,
             w_ref=w if self.keep_ref else None, b_ref=b if self.keep_ref else None)))
         return out
 
@@ -236,14 +286,21 @@ class Graph:
         B, H, W, sd = self.B, self.H, self.W, self.sd
         # ResNet_top (smap.py:80-92)
         w, b = fold_conv_bn(sd, "top.conv")
-        wk = torch.zeros((64, 22, 8), dtype=torch.float16)          # K = (kh, c, kw 7->8) + one zero granule
-        wk[:, :21, :7] = w.permute(0, 2, 1, 3).reshape(64, 21, 7).to(torch.float16)
-        wk = wk.reshape(64, 176)
+        stem_scale = 1.0
+        if self.x3:
+            hi, lo, stem_scale = split_f16(w.permute(0, 2, 1, 3).reshape(64, 21, 7))
+            wk = torch.zeros((2, 64, 22, 8), dtype=torch.float16)
+            wk[0, :, :21, :7], wk[1, :, :21, :7] = hi, lo
+            wk = wk.reshape(2, 64, 176)
+        else:
+            wk = torch.zeros((64, 22, 8), dtype=torch.float16)      # K = (kh, c, kw 7->8) + one zero granule
+            wk[:, :21, :7] = w.permute(0, 2, 1, 3).reshape(64, 21, 7).to(torch.float16)
+            wk = wk.reshape(64, 176)
         H2, W2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         H4, W4 = (H2 + 2 - 3) // 2 + 1, (W2 + 2 - 3) // 2 + 1
         self.flops += 2 * B * H2 * W2 * 64 * 147
-        stem_p = dict(w_off=self._add_w(wk), bias_off=self._add_w(b.to(torch.float32)), w_ref=w, b_ref=b)
-        if not os.environ.get("SMAP_STEMPOOL"):         # default: conv and max-pool as two kernels (the fused kernel below is
+        stem_p = dict(w_off=self._add_w(wk), bias_off=self._add_w(b.to(torch.float32)), w_ref=w, b_ref=b, acc_scale=stem_scale)
+        if self.x3 or not os.environ.get("SMAP_STEMPOOL"):         # default: conv and max-pool as two kernels (the fused kernel below is
             t = self.tensor("top.conv", H2, W2, 64)     # bit-identical but no faster inside the two-batch pipeline)
             self.ops.append(Op(OP_STEM, out=t, p=stem_p))
             x = self.tensor("top.pool", H4, W4, 64)
@@ -289,7 +346,7 @@ class Graph:
                 out = self.conv(u + ".out", [u + ".u_skip"], xin, relu=True)
             else:
                 tl = self.conv(u + ".up_conv@low", [u + ".up_conv"], out, relu=False)   # commuted with the upsample
-                if os.environ.get("SMAP_NO_UPADD_FUSION"):
+                if os.environ.get("SMAP_NO_UPADD_FUSION") and not self.x3:
                     a = self.conv(u + ".u_skip", [u + ".u_skip"], xin, relu=False)
                     o = self.tensor(u + ".out", a.H, a.W, a.C)
                     self.ops.append(Op(OP_UPADD, out=o, inp=a, aux=[tl], p=dict(relu=1)))
@@ -387,13 +444,15 @@ class Graph:
             for k in range(3):
                 o.aux_off[k] = -1
             o.in_off = o.out_off = o.w_off = o.bias_off = o.ext_off = -1
+            o.precision, o.acc_scale = int(self.x3), 1.0
             p = op.p
             if op.kind == OP_CONV:
                 x, y = op.inp, op.out
-                o.H, o.W, o.Cin, o.in_stride_c, o.in_c_off = x.H, x.W, p["Cin"], x.C, p["in_c_off"]
+                o.H, o.W, o.Cin, o.in_stride_c, o.in_c_off = x.H, x.W, p["Cin"], x.C * x.planes, p["in_c_off"]
                 o.Ho, o.Wo, o.Cout = y.H, y.W, p["Cout"]
                 o.ksize, o.stride, o.pad, o.relu = p["ksize"], p["stride"], p["pad"], p["relu"]
-                o.cout_pad, o.out_stride_c, o.out_c_off = p["cout_pad"], y.C, 0
+                o.cout_pad, o.out_stride_c, o.out_c_off = p["cout_pad"], y.C * y.planes, 0
+                o.acc_scale = p["acc_scale"]
                 o.out_fp32, o.tile = p["out_fp32"], p["tile"]
                 o.in_off, o.out_off, o.w_off, o.bias_off = x.off, y.off, p["w_off"], p["bias_off"]
                 for nm in ("res", "add1", "add2"):
@@ -410,6 +469,7 @@ class Graph:
                 o.H, o.W, o.Cin, o.Ho, o.Wo, o.Cout = self.H, self.W, 3, y.H, y.W, 64
                 o.ksize, o.stride, o.pad, o.relu = 7, 2, 3, 1
                 o.out_off, o.w_off, o.bias_off = y.off, p["w_off"], p["bias_off"]
+                o.acc_scale = p["acc_scale"]
             elif op.kind == OP_MAXPOOL:
                 x, y = op.inp, op.out
                 o.H, o.W, o.Cin, o.Ho, o.Wo, o.Cout = x.H, x.W, x.C, y.H, y.W, y.C
@@ -442,13 +502,15 @@ class Graph:
 class BackboneEngine:
     """Device-resident schedule for one (B, H, W): weights, arena, output buffer, plan."""
 
-    def __init__(self, state_dict, B, H, W, device, stage_num=3, chl=256, kpt_paf=43, paf=14, reuse=True):
+    def __init__(self, state_dict, B, H, W, device, stage_num=3, chl=256, kpt_paf=43, paf=14, reuse=True,
+                 precision="f16"):
         self.lib = _L.load()          # fails loudly when libsmap_hip.so is missing
+        self.precision = precision
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("BackboneEngine needs a ROCm GPU device (no CPU path in smap_amd)")
         sd = {k: v.detach().cpu() for k, v in state_dict.items()}
-        g = Graph(sd, B, H, W, stage_num, chl, kpt_paf, paf)
+        g = Graph(sd, B, H, W, stage_num, chl, kpt_paf, paf, precision=precision)
         g.allocate(reuse=reuse)
         self.graph, self.B, self.H, self.W = g, B, H, W
         self.h, self.w = g.out_h, g.out_w
@@ -543,4 +605,7 @@ class BackboneEngine:
         t = next(t for t in self.graph.tensors if t.name == name)
         dt = torch.float16 if t.esize == 2 else torch.float32
         raw = self.arena[t.off:t.off + t.nbytes].view(dt)
+        if t.planes == 2:              # split precision: hi + lo as fp32
+            raw = raw.view(t.B, t.H, t.W, 2, t.C).float()
+            return raw[..., 0, :] + raw[..., 1, :]
         return raw.view(t.B, t.H, t.W, t.C)

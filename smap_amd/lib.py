@@ -36,6 +36,7 @@ class SmapOp(C.Structure):
         ("res_off", C.c_int64), ("add1_off", C.c_int64), ("add2_off", C.c_int64),
         ("aux_off", C.c_int64 * 3), ("aux_h", C.c_int32 * 3), ("aux_w", C.c_int32 * 3),
         ("ext_off", C.c_int64),
+        ("precision", C.c_int32), ("acc_scale", C.c_float),
     ]
 
 

@@ -8,10 +8,14 @@ checkpoint works because every parameter / buffer carries the reference's key
 There is no PyTorch forward here: `forward` needs eval mode and a ROCm device and raises
 otherwise (training - smap.py:355-401 - is out of scope).
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from ..engine import BackboneEngine, LAYERS, PLANES
+
+DEFAULT_PRECISION = "f16"
 
 
 class ConvBN(nn.Module):
@@ -114,6 +118,10 @@ class SMAP(nn.Module):
             setattr(self, f"stage{i}", _Stage([self.kpt_paf_num, self.paf_num], self.upsample_chl_num,
                                               gen_skip=not last, gen_cross=not last))
         self._engines = {}
+        # arithmetic of the HIP engine (smap_amd/engine.py): "x3" = fp16 hi/lo pairs + three MFMAs per K step, the mode
+        # that reproduces the reference's fp32 forward (3D joints within 1e-3 m end to end); "f16" = plain fp16 storage,
+        # ~2.7x faster, ~1e-3 relative error on the maps (0.3 cm mean joint error at 3 m, tests/test_e2e_parity_gpu.py)
+        self.precision = os.environ.get("SMAP_PRECISION", DEFAULT_PRECISION)
 
     # -- engine cache: one device-resident schedule per (B,H,W,device); dropped whenever the
     #    weights are (re)loaded or moved.  After editing parameters in place call invalidate_engine().
@@ -129,12 +137,13 @@ class SMAP(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def engine(self, B, H, W, device):
-        key = (B, H, W, str(device))
+        key = (B, H, W, str(device), self.precision)
         if key not in self._engines:
             if (H // 4, W // 4) != self.output_shape:
                 raise ValueError(f"input {H}x{W} does not match cfg.OUTPUT_SHAPE {self.output_shape} (stride 4)")
             self._engines[key] = BackboneEngine(self.state_dict(), B, H, W, device, self.stage_num,
-                                                self.upsample_chl_num, self.kpt_paf_num, self.paf_num)
+                                                self.upsample_chl_num, self.kpt_paf_num, self.paf_num,
+                                                precision=self.precision)
         return self._engines[key]
 
     def forward(self, imgs, valids=None, labels=None, rdepth=None):

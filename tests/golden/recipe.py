@@ -1,50 +1,3 @@
-"""Deterministic weight recipe shared by gen_golden.py, the tests and smoke().
-
-Weights are generated BY state_dict KEY (seed = crc32(key)) so that the
-reference (in the authoring container) and this repo (anywhere) regenerate the
-same tensors without shipping any weights.
-"""
-import zlib
-
-import torch
-
-
-def key_seed(key: str) -> int:
-    return zlib.crc32(key.encode()) & 0x7FFFFFFF
-
-
-def recipe_state_dict(sd, bn3_gain=0.3, conv_gain=0.8):
-    """Deterministic weights BY KEY so both sides regenerate them without shipping them.
-
-    conv.weight ~ conv_gain * N(0, 2/fan_in) ; conv.bias ~ N(0, .05) ; bn.weight ~ U(.6,1.4)
-    (x bn3_gain on the last BN of a bottleneck, keeps the residual stream bounded);
-    bn.bias ~ N(0,.1) ; running_mean ~ N(0,.1) ; running_var ~ U(.5,1.5).
-    Linear: weight ~ N(0, 1/fan_in), bias ~ N(0,.05).
-    """
-    out = {}
-    for k, v in sd.items():
-        g = torch.Generator().manual_seed(key_seed(k))
-        if k.endswith("num_batches_tracked"):
-            out[k] = torch.zeros_like(v)
-        elif k.endswith("conv.weight"):
-            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
-            out[k] = torch.randn(v.shape, generator=g) * (conv_gain * (2.0 / fan_in) ** 0.5)
-        elif k.endswith("conv.bias"):
-            out[k] = torch.randn(v.shape, generator=g) * 0.05
-        elif k.endswith("running_mean"):
-            out[k] = torch.randn(v.shape, generator=g) * 0.1
-        elif k.endswith("running_var"):
-            out[k] = torch.rand(v.shape, generator=g) + 0.5
-        elif k.endswith("bn.weight") or (k.endswith(".1.weight") and v.dim() == 1):
-            gain = bn3_gain if ".conv_bn_relu3." in k else 1.0
-            out[k] = (torch.rand(v.shape, generator=g) * 0.8 + 0.6) * gain
-        elif k.endswith("bn.bias") or (k.endswith(".1.bias") and v.dim() == 1):
-            out[k] = torch.randn(v.shape, generator=g) * 0.1
-        elif k.endswith("weight") and v.dim() == 2:
-            out[k] = torch.randn(v.shape, generator=g) * (1.0 / v.shape[1]) ** 0.5
-        elif k.endswith("bias"):
-            out[k] = torch.randn(v.shape, generator=g) * 0.05
-        else:
-            raise KeyError(k)
-        assert out[k].shape == v.shape, k
-    return out
+"""Import-path shim: the weight recipe lives in benchkit/recipe.py (shared with bench.py); the golden generators and the
+tests keep importing `recipe`."""
+from benchkit.recipe import key_seed, recipe_state_dict  # noqa: F401

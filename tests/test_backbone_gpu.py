@@ -17,10 +17,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _split(t):
+    """fp32 tensor [..., C] -> fp16 [..., 2C] = [hi(C) | lo(C)] (the split-precision storage of csrc/conv.hip X3)."""
+    hi = t.to(torch.float16)
+    lo = (t - hi.float()).to(torch.float16)
+    return torch.cat([hi, lo], -1)
+
+
 def _run_single_conv(B, H, W, Cin, Cout, k, stride, tile, relu, use_res, use_adds, out_fp32=False,
-                     in_stride=None, in_off=0, seed=0):
+                     in_stride=None, in_off=0, seed=0, x3=False, x_scale=1.0):
+    """One CONV op through smap_plan_run.  x3: split-precision storage (hi/lo planes) and arithmetic; the operands are
+    then full fp32 values and the reference is the f64 conv of THOSE."""
     from smap_amd import lib as L
-    from smap_amd.engine import TILES
+    from smap_amd.engine import TILES, ZERO_PAGE, split_f16
     lib = L.load()
     g = torch.Generator().manual_seed(seed)
     in_stride = in_stride or Cin
@@ -30,14 +39,21 @@ def _run_single_conv(B, H, W, Cin, Cout, k, stride, tile, relu, use_res, use_add
     cout_pad = (Cout + bn - 1) // bn * bn
     c8 = (Cout + 7) // 8 * 8
     K = k * k * Cin
-    x = (torch.randn(B, H, W, in_stride, generator=g)).half()
-    w = (torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / K) ** 0.5).half()
-    bias = torch.randn(Cout, generator=g)
-    res = torch.randn(B, Ho, Wo, c8, generator=g).half() if use_res else None
-    a1 = torch.randn(B, Ho, Wo, c8, generator=g).half() if use_adds else None
-    a2 = torch.randn(B, Ho, Wo, c8, generator=g).half() if use_adds else None
-    wk = torch.zeros(cout_pad, K, dtype=torch.float16)
-    wk[:Cout] = w.permute(0, 2, 3, 1).reshape(Cout, K)
+    q = (lambda t: t) if x3 else (lambda t: t.half())          # storage rounding of the operands
+    x = q(torch.randn(B, H, W, in_stride, generator=g) * x_scale)
+    w = q(torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / K) ** 0.5)
+    bias = torch.randn(Cout, generator=g) * x_scale
+    res = q(torch.randn(B, Ho, Wo, c8, generator=g) * x_scale) if use_res else None
+    a1 = q(torch.randn(B, Ho, Wo, c8, generator=g) * x_scale) if use_adds else None
+    a2 = q(torch.randn(B, Ho, Wo, c8, generator=g) * x_scale) if use_adds else None
+    acc_scale = 1.0
+    if x3:
+        hi, lo, acc_scale = split_f16(w.permute(0, 2, 3, 1).reshape(Cout, K).double())
+        wk = torch.zeros(2, cout_pad, K, dtype=torch.float16)
+        wk[0, :Cout], wk[1, :Cout] = hi, lo
+    else:
+        wk = torch.zeros(cout_pad, K, dtype=torch.float16)
+        wk[:Cout] = w.permute(0, 2, 3, 1).reshape(Cout, K)
     bk = torch.zeros(cout_pad)
     bk[:Cout] = bias
     # weight blob: [wk | bias]; arena: [x | res | a1 | a2 | out]
@@ -46,22 +62,27 @@ def _run_single_conv(B, H, W, Cin, Cout, k, stride, tile, relu, use_res, use_add
     blob = torch.zeros(w_bytes + al(bk.numel() * 4), dtype=torch.uint8)
     blob[:wk.numel() * 2] = wk.view(torch.uint8).reshape(-1)
     blob[w_bytes:w_bytes + bk.numel() * 4] = bk.view(torch.uint8).reshape(-1)
-    parts, offs, cur = [x, res, a1, a2], [], 8192         # arena[0:8192] = zero page
-    for t in parts:
+    store = _split if x3 else (lambda t: t)
+    parts, offs, cur = [x, res, a1, a2], [], ZERO_PAGE    # arena[0:ZERO_PAGE] = zero page
+    stored = [store(t) if t is not None else None for t in parts]
+    for t in stored:
         offs.append(cur if t is not None else -1)
         cur += al(t.numel() * 2) if t is not None else 0
     out_off = cur
     esz = 4 if out_fp32 else 2
-    arena = torch.zeros(out_off + al(B * Ho * Wo * c8 * esz) + 256, dtype=torch.uint8)
-    for t, o in zip(parts, offs):
+    npl = 2 if (x3 and not out_fp32) else 1
+    arena = torch.zeros(out_off + al(B * Ho * Wo * c8 * esz * npl) + 256, dtype=torch.uint8)
+    for t, o in zip(stored, offs):
         if t is not None:
             arena[o:o + t.numel() * 2] = t.contiguous().view(torch.uint8).reshape(-1)
     op = L.SmapOp()
-    op.kind, op.B, op.H, op.W, op.Cin, op.in_stride_c, op.in_c_off = 0, B, H, W, Cin, in_stride, in_off
+    pl_in = 2 if x3 else 1
+    op.kind, op.B, op.H, op.W, op.Cin, op.in_stride_c, op.in_c_off = 0, B, H, W, Cin, in_stride * pl_in, in_off
     op.Ho, op.Wo, op.Cout, op.ksize, op.stride, op.pad, op.relu = Ho, Wo, Cout, k, stride, pad, int(relu)
-    op.cout_pad, op.out_stride_c, op.out_c_off, op.out_fp32, op.tile = cout_pad, c8, 0, int(out_fp32), tile
+    op.cout_pad, op.out_stride_c, op.out_c_off, op.out_fp32, op.tile = cout_pad, c8 * npl, 0, int(out_fp32), tile
     op.in_off, op.out_off, op.w_off, op.bias_off = offs[0], out_off, 0, w_bytes
     op.res_off, op.add1_off, op.add2_off = offs[1], offs[2], offs[3]
+    op.precision, op.acc_scale = int(x3), acc_scale
     for i in range(3):
         op.aux_off[i] = -1
     op.ext_off = -1
@@ -72,9 +93,13 @@ def _run_single_conv(B, H, W, Cin, Cout, k, stride, tile, relu, use_res, use_add
     L.check(lib.smap_plan_run(h, None, C.c_void_p(arena_d.data_ptr()), C.c_void_p(blob_d.data_ptr()), None, st), "run")
     torch.cuda.synchronize()
     lib.smap_plan_destroy(h)
-    raw = arena_d[out_off:out_off + B * Ho * Wo * c8 * esz].cpu()
-    got = raw.view(torch.float32 if out_fp32 else torch.float16).view(B, Ho, Wo, c8).float()
-    # reference: fp32 conv of the same fp16-rounded operands
+    raw = arena_d[out_off:out_off + B * Ho * Wo * c8 * esz * npl].cpu()
+    if npl == 2:
+        got = raw.view(torch.float16).view(B, Ho, Wo, 2, c8).float()
+        got = got[..., 0, :] + got[..., 1, :]
+    else:
+        got = raw.view(torch.float32 if out_fp32 else torch.float16).view(B, Ho, Wo, c8).float()
+    # reference: f64 conv of the same stored operands
     xin = x[..., in_off:in_off + Cin].float().permute(0, 3, 1, 2)
     y = F.conv2d(xin.double(), w.double(), bias.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
     if use_res:
@@ -161,6 +186,47 @@ def test_single_conv_matches_torch(case):
     assert not got[..., cout:].any()                       # padded channels are written as zeros
 
 
+X3_CASES = [
+    # split precision (smap_op.precision = 1): the tiles that have an X3 instance, every epilogue flavour
+    (2, 16, 24, 64, 256, 1, 1, 20, False, False, False),
+    (3, 10, 14, 192, 320, 3, 1, 20, True, True, True),     # odd sizes, Cout not a tile multiple, full epilogue
+    (2, 16, 24, 256, 64, 3, 1, 21, True, False, False),
+    (1, 16, 26, 64, 64, 3, 2, 22, True, True, False),      # ragged M tile, stride 2
+    (2, 8, 12, 512, 256, 1, 1, 23, True, True, True),
+    (1, 32, 52, 256, 512, 1, 2, 23, False, False, False),  # strided shortcut
+    (2, 8, 12, 2048, 256, 1, 1, 21, True, False, False),   # widest input: zero page must cover the lo plane offset
+    (2, 16, 24, 128, 128, 3, 1, 25, True, False, True),
+    (1, 16, 24, 256, 43, 3, 1, 27, False, False, False),
+    (1, 16, 24, 256, 14, 3, 1, 3, False, False, False),
+    (1, 16, 24, 256, 1, 3, 1, 3, False, False, False),
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES, ids=lambda c: "x3-" + "x".join(map(str, c[:8])))
+def test_single_conv_split_precision(case):
+    """fp16 hi/lo storage + three MFMAs per K step reproduce the fp32 convolution: error at the fp32-roundoff level,
+    100x below what one fp16 rounding of the operands would cost (2.4e-4 relative per value)."""
+    got, ref, cout = _run_single_conv(*case, seed=hash(case) % 1000, x3=True)
+    err = (got[..., :cout] - ref).abs()
+    assert torch.isfinite(got).all()
+    assert err.max().item() < 3e-6 * ref.abs().max().item() + 1e-6, (err.max().item(), ref.abs().max().item())
+    assert not got[..., cout:].any()
+
+
+def test_split_precision_keeps_fp16_subnormal_lo_parts():
+    """Activations around 2^-6: their lo parts (~2^-18) are SUBNORMAL fp16 numbers.  The split scheme relies on the matrix
+    cores taking subnormal fp16 inputs as they are; flushing them would cost 2^-12 relative error on such values."""
+    got, ref, cout = _run_single_conv(2, 16, 24, 256, 256, 1, 1, 20, False, False, False, seed=3, x3=True, x_scale=2.0 ** -6)
+    err = (got[..., :cout] - ref).abs().max().item()
+    assert err < 1e-5 * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+def test_split_precision_fp32_out_and_channel_slice():
+    got, ref, cout = _run_single_conv(1, 16, 24, 256, 43, 3, 1, 21, False, False, False, out_fp32=True,
+                                      in_stride=768, in_off=256, seed=5, x3=True)
+    assert (got[..., :cout] - ref).abs().max().item() < 3e-6 * ref.abs().max().item() + 1e-6
+
+
 def test_single_conv_fp32_out_and_channel_slice():
     got, ref, cout = _run_single_conv(1, 16, 24, 256, 43, 3, 1, 1, False, False, False, out_fp32=True,
                                       in_stride=768, in_off=256, seed=5)
@@ -224,6 +290,38 @@ def test_small_schedule_every_tensor_vs_interpreter(golden_dir, small):
         assert (a - b).abs().max().item() < 5e-3 * b.abs().max().item(), k
         # and against the imported reference model itself
         assert np.abs(a.numpy() - z[k]).max() < 1e-2 * np.abs(z[k]).max(), k
+
+
+@pytest.mark.parametrize("tile", [None, "22", "20"], ids=["heuristic", "all64x64", "all128x128"])
+def test_small_schedule_split_precision_every_tensor(golden_dir, small, monkeypatch, tile):
+    """precision "x3" (fp16 hi/lo pairs, three MFMAs per K step): every tensor of the schedule against the fp32 torch
+    interpretation of the same schedule, and the outputs against the IMPORTED reference model's golden outputs, at the
+    fp32-roundoff level -- SURVEY.md 7 step 4's "<= 1e-4 relative" with two orders of magnitude to spare."""
+    from smap_amd.engine import BackboneEngine, Graph
+    from oracle.graph_interp import run_graph
+    _, sd = small
+    if tile:
+        monkeypatch.setenv("SMAP_X3_TILE", tile)
+    z = np.load(f"{golden_dir}/backbone_small.npz")
+    x = torch.from_numpy(z["x"])
+    eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision="x3")
+    assert all(op.p["tile"] in (3, 20, 21, 22, 23) for op in eng.graph.ops if op.kind == 0)
+    outs = [o.cpu() for o in eng.run(x.to(DEV))]
+    torch.cuda.synchronize()
+    g = Graph(sd, 2, 64, 96, keep_ref=True)
+    with torch.no_grad():
+        *ref, T = run_graph(g, x.double(), quantize=False, keep=True)
+    worst = []
+    for t in eng.graph.tensors:
+        got = eng.read_tensor(t.name).cpu().double().permute(0, 3, 1, 2)
+        want = T[t.name].double()
+        c = want.shape[1]
+        e = (got[:, :c] - want).abs().max().item()
+        worst.append((e / (want.abs().max().item() + 1e-6), t.name))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 2e-5, worst[:5]
+    for a, k in zip(outs, ("hms", "det_d", "root_d")):
+        assert np.abs(a.numpy() - z[k]).max() < 2e-5 * np.abs(z[k]).max(), k
 
 
 @pytest.mark.parametrize("env", [{"SMAP_WS1": "40"}, {"SMAP_WS1": "41", "SMAP_HALO3": "16"},

@@ -1,0 +1,113 @@
+"""End-to-end parity ON THE SAME IMAGES at BASELINE configs[2] (batch 8 x 3x512x832, the benchmarked schedule):
+
+    path A  HIP backbone -> HIP association -> HIP lifting          (model.smap.SMAP + smap_amd.dapalib)
+    path B  fp32 reference forward restated on the CPU -> oracle connect -> oracle lift
+            (oracle/backbone_ref.py + oracle/smap_oracle.c = exps/stage3_root2/test.py:50-134)
+
+north_star: "peak indices / limb assignments bit-exact, 3D joint coordinates within 1e-3 m" (= 0.1 cm in the reference's
+cm units).  Weights are the by-key recipe with calibrated heads (benchkit/workload.py::people_state_dict: ~24 peaks per
+key-point channel, root depth ~3 m), in two flavours: "smooth" maps (coarse heads dominate) and "noise" maps (isolated
+noise maxima: the fragile case for peak identity).
+
+  precision "x3"  (fp16 hi/lo pairs, three MFMAs per K step)  MUST meet the north star -- asserted below;
+  precision "f16" (fp16 storage, the fast mode)               is MEASURED and held to its own documented envelope
+                                                              (it does not meet 0.1 cm at 3 m: ~0.3 cm mean).
+Every run leaves its numbers in gpurun_out/e2e_parity_<precision>_<kind>.json (copied to profiles/ when committed).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_cfg
+from benchkit import parity
+from benchkit.workload import people_state_dict
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+B, H, W = 8, 512, 832
+_REF = {}
+
+
+def _setup(kind):
+    from smap_amd.model.smap import SMAP
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((128, 208))).eval()
+    sd = people_state_dict(net.state_dict(), kind)
+    net.load_state_dict(sd)
+    imgs = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(1234))
+    return net, sd, imgs
+
+
+def _reference(kind, sd, imgs, cams):
+    if kind not in _REF:                      # 8 fp32 CPU forwards: computed once per weight flavour
+        _REF[kind] = parity.reference_path(sd, imgs, cams, threads=min(32, os.cpu_count() or 1))
+    return _REF[kind]
+
+
+def _dump(name, m):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, name), "w") as f:
+        json.dump(m, f, indent=1)
+    print(name, json.dumps(m))
+
+
+@pytest.mark.parametrize("kind", ["smooth", "noise"])
+def test_split_precision_meets_the_north_star_end_to_end(kind):
+    from benchkit.workload import PEOPLE_CAM
+    net, sd, imgs = _setup(kind)
+    net.precision = "x3"
+    net = net.to(DEV)
+    cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (B, 1))
+    hip = parity.hip_path(net, imgs.to(DEV), cams)
+    ref = _reference(kind, sd, imgs, cams)
+    m = parity.compare(hip, ref)
+    m.update(precision="x3", weights=kind, batch=B)
+    _dump(f"e2e_parity_x3_{kind}.json", m)
+    assert m["persons_ref"] >= 8 * B and m["peaks_ref"] >= 100 * B, "the scene must contain people"
+    assert m["peak_match"] == 1.0 and m["peaks_unmatched"] == 0            # same peak sets
+    assert m["person_match"] == 1.0 and m["limb_match"] == 1.0             # same skeletons, same limb assignments
+    assert m["max_joint_err_cm"] <= 0.1 and m["root_z_max_err_cm"] <= 0.1  # north_star: 1e-3 m
+    assert max(m["map_rel_err_max"].values()) < 1e-4
+    # and, stronger than the 0.5 px pairing: the peak lists agree entry by entry to 1e-3 px
+    for a, b in zip(hip, ref):
+        assert np.array_equal(a["peaks"][:, 0, 0], b["peaks"][:, 0, 0])
+        assert np.abs(a["peaks"] - b["peaks"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("kind", ["smooth", "noise"])
+def test_fp16_mode_measured_end_to_end_with_the_shipped_tile_table(kind):
+    """The fast mode on the BENCHMARKED schedule: B = 8 hits smap_amd/tile_table.json (halo tiles 30..39 on their real
+    shapes).  Its output is compared per frame with the fp32 reference; the end-to-end numbers are recorded."""
+    from benchkit.workload import PEOPLE_CAM
+    net, sd, imgs = _setup(kind)
+    net.precision = "f16"
+    net = net.to(DEV)
+    eng = net.engine(B, H, W, torch.device(DEV))
+    tiles = [op.p["tile"] for op in eng.graph.ops if op.kind == 0]
+    assert any(t >= 30 for t in tiles), "B = 8 must run the measured tile table (halo-tiled 3x3 kernels)"
+    cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (B, 1))
+    hip = parity.hip_path(net, imgs.to(DEV), cams)
+    ref = _reference(kind, sd, imgs, cams)
+    m = parity.compare(hip, ref)
+    m.update(precision="f16", weights=kind, batch=B, tiles=sorted(set(tiles)))
+    _dump(f"e2e_parity_f16_{kind}.json", m)
+    assert max(m["map_rel_err_max"].values()) < 1e-2           # fp16 storage tolerance, every frame of the batch
+    assert m["peak_match"] > 0.9 and m["person_match"] > 0.9 and m["limb_match"] > 0.97
+    assert m["mpjpe_cm"] < 1.0 and m["max_joint_err_cm"] < 3.0  # measured envelope (~0.3 / ~0.8 cm at Z ~ 3 m): NOT 0.1 cm
+
+
+def test_fp16_flip_batch_of_16_agrees_with_batch_of_8():
+    """2B = 16 is the flip-TTA batch of the B = 8 pipeline: another tiling of M, same numbers within fp16 tolerance."""
+    net, sd, imgs = _setup("smooth")
+    net.precision = "f16"
+    net = net.to(DEV)
+    x = imgs.to(DEV)
+    a = [t.clone() for t in net(x)]
+    b = net(torch.cat([x, torch.flip(x, [-1])], 0))
+    for u, v in zip(a, b):
+        assert (u - v[:B]).abs().max().item() <= 1e-2 * u.abs().max().item()

@@ -38,7 +38,7 @@ def build(B, H, W, Cin, Cout, k, s, tile, res, dev):
     al = lambda n: (n + 255) // 256 * 256
     c8 = (Cout + 7) // 8 * 8
     x_b, o_b = al(B * H * W * Cin * 2), al(B * Ho * Wo * c8 * 2)
-    arena = (torch.randn((8192 + x_b + 2 * o_b) // 2 + 128, device=dev) * 0.5).half()
+    arena = (torch.randn((16384 + x_b + 2 * o_b) // 2 + 128, device=dev) * 0.5).half()
     w_b = al(cout_pad * K * 2)
     blob = torch.zeros(w_b + al(cout_pad * 4), dtype=torch.uint8, device=dev)
     blob[:cout_pad * K * 2] = (torch.randn(cout_pad * K, device=dev) * K ** -0.5).half().view(torch.uint8)
@@ -46,8 +46,8 @@ def build(B, H, W, Cin, Cout, k, s, tile, res, dev):
     op.kind, op.B, op.H, op.W, op.Cin, op.in_stride_c, op.in_c_off = 0, B, H, W, Cin, Cin, 0
     op.Ho, op.Wo, op.Cout, op.ksize, op.stride, op.pad, op.relu = Ho, Wo, Cout, k, s, pad, 1
     op.cout_pad, op.out_stride_c, op.out_c_off, op.out_fp32, op.tile = cout_pad, c8, 0, 0, tile
-    op.in_off, op.out_off, op.w_off, op.bias_off = 8192, 8192 + x_b + o_b, 0, w_b
-    op.res_off = 8192 + x_b if res else -1
+    op.in_off, op.out_off, op.w_off, op.bias_off = 16384, 16384 + x_b + o_b, 0, w_b
+    op.res_off = 16384 + x_b if res else -1
     op.add1_off = op.add2_off = op.ext_off = -1
     for i in range(3):
         op.aux_off[i] = -1

@@ -21,7 +21,7 @@ def main():
     cfg = NS(MODEL=NS(STAGE_NUM=3, UPSAMPLE_CHANNEL_NUM=256), DATASET=NS(KEYPOINT=NS(NUM=15), PAF=NS(NUM=14)),
              OUTPUT_SHAPE=(128, 208), LOSS=NS(OHKM=True, TOPK=8, COARSE_TO_FINE=True))
     torch.manual_seed(0)
-    g = Graph(SMAP(cfg).state_dict(), B, 512, 832)
+    g = Graph(SMAP(cfg).state_dict(), B, 512, 832, precision=os.environ.get("SMAP_PRECISION", "f16"))
     # kernel-name fragments per op kind (conv ops run conv.hip, conv2.hip, conv3.hip or conv1.hip kernels, by tile id)
     names = {OP_CONV: ("conv_igemm", "conv3x3_halo", "conv1x1_ws"), OP_STEM: ("stem_kernel",), OP_STEMPOOL: ("stem_pool_kernel",), OP_MAXPOOL: ("maxpool",),
              OP_UPADD: ("upadd",), OP_HEADSUM: ("headsum",)}       # set SMAP_NO_UPADD_FUSION=1 for pre-fusion traces
@@ -50,7 +50,7 @@ def main():
             M = B * y.H * y.W
             K = p["ksize"] ** 2 * p["Cin"]
             fl = 2 * M * p["Cout"] * K
-            by = B * x.H * x.W * p["Cin"] * 2 + y.nbytes + p["cout_pad"] * K * 2
+            by = B * x.H * x.W * p["Cin"] * 2 * x.planes + y.nbytes + p["cout_pad"] * K * 2 * (2 if g.x3 else 1)
             by += sum(t.nbytes for t in (op.res, op.add1, op.add2) if t is not None)
             shape = f"M{M} N{p['Cout']} K{K} k{p['ksize']}s{p['stride']}"
             tile = "x".join(map(str, TILES[p["tile"]])) + f"#{p['tile']}"
