@@ -7,6 +7,9 @@ cv2.imread) and the resize is a plain fp32 bilinear with half-pixel centres and 
 (smap_amd.preprocess.resize_bilinear_u8), the sampling rule of cv2.INTER_LINEAR.  uint8 rounding can differ from OpenCV's fixed-point
 path by 1 LSB -- pre-processing is outside the measured hot path.
 `.npy` files holding an HxWx3 uint8 BGR array are accepted as well.
+Record order: the reference lists jpg, then png, then jpeg files in glob (= directory) order, which is not defined; here
+each extension's files are SORTED (one of the orders the reference may produce, and a reproducible one).  Decoding honours
+the EXIF orientation tag like cv2.imread(IMREAD_COLOR) does.
 """
 import glob
 import os.path as osp
@@ -34,8 +37,9 @@ class CustomDataset(Dataset):
     def _read_bgr(path):
         if path.endswith(".npy"):
             return np.load(path)
-        from PIL import Image
-        return np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1].copy()
+        from PIL import Image, ImageOps
+        # cv2.imread(IMREAD_COLOR) (custom_dataset.py:33 upstream) applies the EXIF orientation; PIL does not by itself
+        return np.asarray(ImageOps.exif_transpose(Image.open(path)).convert("RGB"))[:, :, ::-1].copy()
 
     def __getitem__(self, index):
         image_path = self.image_list[index].rstrip()

@@ -19,9 +19,7 @@ OBJ = os.path.join(CSRC, "obj")
 SOURCES = [
     ("assoc.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
-    ("conv2.hip", []),
     ("conv3.hip", []),
-    ("conv1.hip", []),
     ("plan.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),

@@ -442,9 +442,7 @@ hipError_t launch_x3(const ConvArgs& a, hipStream_t st)
 //   0..4 : 2-stage (double-buffered) variants; 5..9 : the same tiles with deeper LDS-DMA pipelines
 int smap_conv_tile_dims(int tile, int* bm, int* bn)
 {
-    if (tile >= 10 && tile < 20) return smap_conv2_tile_dims(tile, bm, bn);
     if (tile >= 30 && tile < 40) return smap_conv3_tile_dims(tile, bm, bn);
-    if (tile >= 40 && tile < 50) return smap_conv1_tile_dims(tile, bm, bn);
     switch (tile) {
         case 20: case 24: *bm = 128; *bn = 128; return 0;      // 20..27: BK = 32 staging (smaller LDS, more workgroups per CU)
         case 21: case 25: *bm = 128; *bn = 64; return 0;
@@ -462,26 +460,30 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
 // tiles that have a split-precision instance (plan.hip::validate asks)
 int smap_conv_tile_has_x3(int tile)
 {
-    return tile == 3 || (tile >= 20 && tile <= 23) || tile == 25 || tile == 27;
+    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27);
 }
 
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
 {
     if (a.x3) {
         switch (tile) {                                     // LDS = max(STAGES * 2 * (BM + BN) * row bytes, fp32 epilogue tile)
+            case 0: return launch_x3<128, 128, 2, 2, 2, 64>(a, st);   // 128 KiB: BK = 64, half the barriers per K
+            case 1: return launch_x3<128, 64, 2, 2, 2, 64>(a, st);    // 96 KiB
+            case 2: return launch_x3<64, 64, 2, 2, 2, 64>(a, st);     // 64 KiB
+            case 4: return launch_x3<64, 128, 2, 2, 2, 64>(a, st);    // 96 KiB
             case 3: return launch_x3<128, 32, 4, 1, 2, 64>(a, st);    // 80 KiB (Cout <= 32 heads)
             case 20: return launch_x3<128, 128, 2, 2, 2, 32>(a, st);  // 64 KiB
             case 21: return launch_x3<128, 64, 2, 2, 2, 32>(a, st);   // 48 KiB
             case 22: return launch_x3<64, 64, 2, 2, 2, 32>(a, st);    // 32 KiB
             case 23: return launch_x3<64, 128, 2, 2, 2, 32>(a, st);   // 48 KiB
+            case 24: return launch_x3<128, 128, 2, 2, 3, 32>(a, st);  // 96 KiB, 2 tiles in flight (fp16 id 24 is 4-stage)
             case 25: return launch_x3<128, 64, 2, 2, 3, 32>(a, st);   // 72 KiB, 2 tiles in flight
+            case 26: return launch_x3<64, 64, 2, 2, 4, 32>(a, st);    // 64 KiB, 3 tiles in flight
             case 27: return launch_x3<64, 128, 2, 2, 3, 32>(a, st);   // 72 KiB
             default: return hipErrorInvalidValue;
         }
     }
-    if (tile >= 10 && tile < 20) return smap_launch_conv2(a, tile, st);
     if (tile >= 30 && tile < 40) return smap_launch_conv3(a, tile, st);
-    if (tile >= 40 && tile < 50) return smap_launch_conv1(a, tile, st);
     switch (tile) {
         case 20: return launch<128, 128, 2, 2, 2, 32>(a, st);   // 64 KiB (fp32 epilogue tile)
         case 21: return launch<128, 64, 2, 2, 2, 32>(a, st);    // 32 KiB

@@ -56,12 +56,8 @@ __device__ __forceinline__ Lerp lerp_index(int dst, int in_size, int out_size)
 int smap_conv_tile_dims(int tile, int* bm, int* bn);
 int smap_conv_tile_has_x3(int tile);                                        // conv.hip: tile ids with a split-precision instance
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st);
-int smap_conv2_tile_dims(int tile, int* bm, int* bn);                       // conv2.hip (tile ids >= 10)
-hipError_t smap_launch_conv2(const ConvArgs& a, int tile, hipStream_t st);
 int smap_conv3_tile_dims(int tile, int* bm, int* bn);                       // conv3.hip (tile ids 30..33, halo-tiled 3x3)
 hipError_t smap_launch_conv3(const ConvArgs& a, int tile, hipStream_t st);
-int smap_conv1_tile_dims(int tile, int* bm, int* bn);                       // conv1.hip (tile ids 40..41, weight-stationary 1x1)
-hipError_t smap_launch_conv1(const ConvArgs& a, int tile, hipStream_t st);
 
 #ifdef SMAP_TIMELINE
 // every workgroup of a conv kernel calls these two (first / last statement): 100 MHz device-wide clock

@@ -428,8 +428,6 @@ static int validate(const smap_op& o)
                 if (o.in_c_off + o.Cin > o.in_stride_c / 2) return SMAP_E_ARG;
             }
             if (o.ksize != 1 && o.ksize != 3) return SMAP_E_ARG;
-            if (o.tile >= 40 && o.tile < 50 && (o.ksize != 1 || o.stride != 1 || (o.Cin != 64 && o.Cin != 128 && o.Cin != 256)))
-                return SMAP_E_ARG;                       // weight-stationary kernel: 1x1 stride-1, weights fit the register file
             if (o.tile >= 30 && o.tile < 40 && (o.ksize != 3 || o.stride != 1 || o.pad != 1 || o.res_off >= 0 || o.add1_off >= 0 ||
                                  o.add2_off >= 0 || o.aux_off[0] >= 0))
                 return SMAP_E_ARG;                       // halo-tiled kernel: plain 3x3 stride-1 convs only

@@ -26,8 +26,8 @@ NJ, NL, MAXP, HMS_C = 15, 14, 127, 43
 JOINT_PAIRS = [0, 1, 0, 2, 0, 9, 9, 10, 10, 11, 0, 3, 3, 4, 4, 5, 2, 12, 12, 13, 13, 14, 2, 6, 6, 7, 7, 8]
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _p(t):
@@ -57,7 +57,8 @@ def scale_hms_(hms):
     batched = hms.dim() == 4
     H, W = _check_hms(hms, batched)
     B = hms.shape[0] if batched else 1
-    _L.check(_L.load().smap_scale_hms(_p(hms), B, H, W, _stream()), "smap_scale_hms")
+    with torch.cuda.device(hms.device):
+        _L.check(_L.load().smap_scale_hms(_p(hms), B, H, W, _stream(hms.device)), "smap_scale_hms")
     return hms
 
 

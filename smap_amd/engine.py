@@ -34,18 +34,15 @@ import os
 # tile id -> (BM, BN); ids 5..9 are the same tiles with deeper LDS-DMA pipelines (csrc/conv.hip)
 TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          5: (128, 128), 6: (128, 64), 7: (64, 64), 8: (128, 32), 9: (64, 128),
-         # 10..18: csrc/conv2.hip (register epilogue; BK = 32 for 10-13,17; BK = 64 for 14-16,18)
-         10: (128, 128), 11: (128, 64), 12: (64, 64), 13: (64, 128), 14: (128, 128), 15: (128, 64), 16: (64, 64),
-         17: (128, 128), 18: (64, 128),
          # 20..27: csrc/conv.hip with BK = 32 staging (LDS-staged epilogue kept)
          20: (128, 128), 21: (128, 64), 22: (64, 64), 23: (64, 128), 24: (128, 128), 25: (128, 64), 26: (64, 64),
          27: (64, 128),
          # 30..39: csrc/conv3.hip halo-tiled 3x3 stride-1 (BM = 128 output pixels as an 8x16 / 4x32 patch)
          30: (128, 64), 31: (128, 128), 32: (128, 64), 33: (128, 128),
          34: (128, 64), 35: (128, 128), 36: (128, 64), 37: (128, 128),     # 34..37: deeper weight pipeline
-         38: (128, 32), 39: (128, 32),                                     # Cout <= 32 heads
-         # 40..41: csrc/conv1.hip weight-stationary persistent 1x1 stride-1 (Cin 64/128/256, 256 channels per workgroup)
-         40: (64, 256), 41: (64, 256)}
+         38: (128, 32), 39: (128, 32)}                                     # Cout <= 32 heads
+# (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
+#  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)
 
 
 def _tile_remap():
@@ -62,7 +59,7 @@ PLANES = (64, 128, 256, 512)
 ALIGN = 256
 ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
 PRECISIONS = ("f16", "x3")
-X3_TILES = (20, 21, 22, 23)   # BK = 32 tiles of conv.hip that have a split-precision instance (+ tile 3 for Cout <= 32)
+X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
 
 
 def split_f16(w, scaled=True):
@@ -78,8 +75,19 @@ def split_f16(w, scaled=True):
     return hi, lo, 2.0 ** -s
 
 
-def pick_tile_x3(M, cout):
-    """Split precision: largest BK = 32 tile that still gives >= 512 workgroups, else the one with most workgroups."""
+_TILE_TABLE_X3 = None
+
+
+def pick_tile_x3(M, cout, key=None):
+    """Split precision: the measured table (tools/autotune.py --precision x3 -> smap_amd/tile_table_x3.json) when the
+    shape is in it, else the largest BK = 32 tile that still gives >= 512 workgroups / the one with most workgroups."""
+    global _TILE_TABLE_X3
+    if _TILE_TABLE_X3 is None:
+        import json
+        path = os.environ.get("SMAP_TILE_TABLE_X3") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table_x3.json")
+        _TILE_TABLE_X3 = json.load(open(path)) if os.path.exists(path) and not os.environ.get("SMAP_NO_TILE_TABLE") else {}
+    if key is not None and key in _TILE_TABLE_X3:
+        return int(_TILE_TABLE_X3[key])
     if cout <= 32:
         return 3
     best, best_blocks = None, -1
@@ -237,7 +245,7 @@ class Graph:
         tile = pick_tile(M, cout, f"{self.B},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
         tile = {**DEFAULT_REMAP, **_tile_remap()}.get(tile, tile)
         if self.x3:
-            tile = pick_tile_x3(M, cout)
+            tile = pick_tile_x3(M, cout, f"{self.B},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
             x3t = os.environ.get("SMAP_X3_TILE", "")         # A/B hook: force one split-precision tile where it fits
             if x3t and cout > 32 and not (cout <= 64 and TILES[int(x3t)][1] > 64):
                 tile = int(x3t)
@@ -246,13 +254,6 @@ class Graph:
             pass
         elif 30 <= tile < 40 and not plain3:                # the halo-tiled kernel has no fused epilogues (table keyed by shape only)
             tile = pick_tile_heuristic(M, cout)
-        ws1 = os.environ.get("SMAP_WS1", "")          # A/B hook: "40" / "41" -> weight-stationary kernel for every eligible 1x1
-        if not self.x3 and 40 <= tile < 50 and not (ksize == 1 and stride == 1 and cin in (64, 128, 256)):
-            tile = pick_tile_heuristic(M, cout)
-        if not self.x3 and ws1 and ksize == 1 and stride == 1 and cin in (64, 128, 256) and cout % 256 == 0:
-            lim = os.environ.get("SMAP_WS1_MIN_M", "")
-            if not lim or M >= int(lim):
-                tile = int(ws1)
         halo = os.environ.get("SMAP_HALO3", "")     # A/B hook: "16" / "32" = pixel-tile width, optional ":64" / ":128" = BN
         if not self.x3 and halo and plain3 and cout > 32:
             tw, _, hbn = halo.partition(":")
@@ -537,11 +538,12 @@ class BackboneEngine:
         e.out = e.new_output()
         e.hms, e.det_d, e.root_d = e.views(e.out)
         e._is_sibling = True
+        e._parent = self               # the shared plan handle lives as long as any executor of it
         return e
 
     def new_output(self):
         """A fresh fp32 output buffer (hms | det_d | root_d); pass it to run(out=...) to double-buffer."""
-        return torch.zeros((self.out_floats,), dtype=torch.float32, device=self.device)
+        return torch.empty((self.out_floats,), dtype=torch.float32, device=self.device)     # HEADSUM writes every element
 
     def views(self, out):
         B, n = self.B, self.B * self.h * self.w

@@ -118,6 +118,7 @@ class SMAP(nn.Module):
             setattr(self, f"stage{i}", _Stage([self.kpt_paf_num, self.paf_num], self.upsample_chl_num,
                                               gen_skip=not last, gen_cross=not last))
         self._engines = {}
+        self.weights_generation = 0
         # arithmetic of the HIP engine (smap_amd/engine.py): "x3" = fp16 hi/lo pairs + three MFMAs per K step, the mode
         # that reproduces the reference's fp32 forward (3D joints within 1e-3 m end to end); "f16" = plain fp16 storage,
         # ~2.7x faster, ~1e-3 relative error on the maps (0.3 cm mean joint error at 3 m, tests/test_e2e_parity_gpu.py)
@@ -127,13 +128,14 @@ class SMAP(nn.Module):
     #    weights are (re)loaded or moved.  After editing parameters in place call invalidate_engine().
     def invalidate_engine(self):
         self._engines = {}
+        self.weights_generation = getattr(self, "weights_generation", 0) + 1     # long-lived users (PosePipeline) check it
 
     def _load_from_state_dict(self, *a, **k):
-        self._engines = {}
+        self.invalidate_engine()
         return super()._load_from_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
-        self._engines = {}
+        self.invalidate_engine()
         return super()._apply(fn, *a, **k)
 
     def engine(self, B, H, W, device):
@@ -157,5 +159,6 @@ class SMAP(nn.Module):
             raise ValueError(f"imgs must be [B,3,H,W], got {tuple(imgs.shape)}")
         B, _, H, W = imgs.shape
         eng = self.engine(B, H, W, imgs.device)
-        hms, det_d, root_d = eng.run(imgs.float())
-        return hms.clone(), det_d.clone(), root_d.clone()
+        # a fresh output buffer per call (caching allocator: no device copy), so the caller owns what it gets back --
+        # the reference returns new tensors too -- while the engine's arena is reused by the next forward
+        return eng.run(imgs.float(), out=eng.new_output())

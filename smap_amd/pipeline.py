@@ -55,6 +55,8 @@ class PosePipeline:
         self.B, self.do_flip = batch, bool(do_flip)
         # flip-TTA (test.py:55-70): frames and their mirror images run as ONE 2B batch
         self.engine = model.engine(2 * batch if do_flip else batch, H, W, self.device)
+        self._model, self._generation = model, model.weights_generation      # a reload / .to() after this point makes the
+                                                                             # pipeline stale: submit() refuses to run on old weights
         kpt = cfg.DATASET.KEYPOINT.NUM
         self.flip_pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
         self.refine = refine_weights
@@ -98,6 +100,8 @@ class PosePipeline:
         (bench only).  annotations (ground-truth modes): B arrays [G_i,15,C] of the KEPT annotations of each
         frame (records.kept_annotations; G_i may be 0 -- the frame is skipped, test.py:81-82).
         Returns the record list of the previous batch or None."""
+        if self._model.weights_generation != self._generation:
+            raise RuntimeError("the model's weights were reloaded or moved after this PosePipeline was built; build a new one")
         gt = None
         if self.record_mode != "run_inference":
             if annotations is None or len(annotations) != len(tags):

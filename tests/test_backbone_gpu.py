@@ -35,7 +35,7 @@ def _run_single_conv(B, H, W, Cin, Cout, k, stride, tile, relu, use_res, use_add
     in_stride = in_stride or Cin
     pad = k // 2
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    bn = TILES[tile][1]
+    bn = TILES.get(tile, (128, 64))[1]                 # unknown ids: the plan must reject them
     cout_pad = (Cout + bn - 1) // bn * bn
     c8 = (Cout + 7) // 8 * 8
     K = k * k * Cin
@@ -133,17 +133,6 @@ CASES = [
     (2, 8, 12, 512, 256, 1, 1, 7, True, True, False),
     (1, 16, 24, 256, 14, 3, 1, 8, False, False, False),
     (1, 32, 52, 256, 512, 1, 2, 9, False, False, False),
-    # second-generation kernel (conv2.hip: BK 32/64, register epilogue), tile ids 10..18
-    (2, 16, 24, 64, 256, 1, 1, 10, False, False, False),
-    (3, 10, 14, 192, 320, 3, 1, 10, True, True, True),
-    (2, 16, 24, 256, 64, 3, 1, 11, True, False, False),
-    (1, 16, 26, 64, 64, 3, 2, 12, True, True, False),
-    (2, 8, 12, 512, 256, 1, 1, 13, True, True, True),
-    (2, 16, 24, 128, 128, 3, 2, 14, True, False, False),
-    (1, 16, 24, 256, 43, 3, 1, 15, False, False, False),
-    (1, 16, 26, 64, 64, 3, 1, 16, True, False, False),
-    (3, 10, 14, 192, 320, 3, 1, 17, True, True, True),
-    (1, 32, 52, 256, 512, 1, 2, 18, False, True, False),
     # conv.hip with BK = 32 staging, tile ids 20..27
     (2, 16, 24, 64, 256, 1, 1, 20, False, True, False),
     (3, 10, 14, 192, 320, 3, 1, 21, True, True, True),
@@ -166,13 +155,6 @@ CASES = [
     (1, 12, 20, 192, 256, 3, 1, 35, True, False, False),
     (1, 16, 36, 64, 64, 3, 1, 36, True, False, False),
     (1, 16, 36, 128, 256, 3, 1, 37, False, False, False),
-    # weight-stationary persistent 1x1 (conv1.hip), tile ids 40..41: K = 64/128/256, ragged M, Cout not a tile multiple
-    (2, 16, 24, 64, 256, 1, 1, 40, False, False, False),
-    (2, 16, 24, 256, 256, 1, 1, 40, True, True, True),
-    (1, 13, 17, 128, 512, 1, 1, 41, True, True, False),
-    (3, 10, 14, 256, 320, 1, 1, 40, True, False, True),
-    (8, 32, 52, 64, 256, 1, 1, 41, True, True, False),
-    (4, 64, 104, 256, 256, 1, 1, 40, True, False, False),      # several tiles per workgroup
 ]
 
 
@@ -199,6 +181,13 @@ X3_CASES = [
     (1, 16, 24, 256, 43, 3, 1, 27, False, False, False),
     (1, 16, 24, 256, 14, 3, 1, 3, False, False, False),
     (1, 16, 24, 256, 1, 3, 1, 3, False, False, False),
+    # BK = 64 and deeper-pipeline instances
+    (3, 10, 14, 192, 320, 3, 1, 0, True, True, True),
+    (2, 16, 24, 256, 64, 3, 1, 1, True, True, False),
+    (1, 16, 26, 64, 64, 3, 2, 2, True, False, False),
+    (2, 8, 12, 512, 256, 1, 1, 4, True, False, True),
+    (2, 16, 24, 64, 256, 1, 1, 24, False, True, False),      # K shorter than the pipeline depth
+    (1, 16, 26, 64, 64, 3, 1, 26, True, False, False),
 ]
 
 
@@ -247,10 +236,12 @@ def test_halo_conv_rejects_fused_epilogues():
         _run_single_conv(1, 16, 24, 64, 64, 3, 1, 30, True, True, False)
     with pytest.raises(SmapError):
         _run_single_conv(1, 16, 24, 64, 64, 1, 1, 30, True, False, False)
-    with pytest.raises(SmapError):                     # weight-stationary kernel: 1x1 stride-1, Cin <= 256 only
-        _run_single_conv(1, 16, 24, 64, 256, 3, 1, 40, True, False, False)
+    with pytest.raises(SmapError):                     # tile ids of kernels that are no longer in the product build
+        _run_single_conv(1, 16, 24, 64, 256, 1, 1, 40, True, False, False)
     with pytest.raises(SmapError):
-        _run_single_conv(1, 16, 24, 512, 256, 1, 1, 40, True, False, False)
+        _run_single_conv(1, 16, 24, 64, 256, 1, 1, 12, True, False, False)
+    with pytest.raises(SmapError):                     # split precision only on the tiles that have an X3 instance
+        _run_single_conv(1, 16, 24, 64, 64, 3, 1, 30, True, False, False, x3=True)
 
 
 @pytest.fixture(scope="module")
@@ -305,7 +296,8 @@ def test_small_schedule_split_precision_every_tensor(golden_dir, small, monkeypa
     z = np.load(f"{golden_dir}/backbone_small.npz")
     x = torch.from_numpy(z["x"])
     eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision="x3")
-    assert all(op.p["tile"] in (3, 20, 21, 22, 23) for op in eng.graph.ops if op.kind == 0)
+    from smap_amd.engine import X3_TILES
+    assert all(op.p["tile"] in X3_TILES + (3,) for op in eng.graph.ops if op.kind == 0)
     outs = [o.cpu() for o in eng.run(x.to(DEV))]
     torch.cuda.synchronize()
     g = Graph(sd, 2, 64, 96, keep_ref=True)
@@ -324,11 +316,10 @@ def test_small_schedule_split_precision_every_tensor(golden_dir, small, monkeypa
         assert np.abs(a.numpy() - z[k]).max() < 2e-5 * np.abs(z[k]).max(), k
 
 
-@pytest.mark.parametrize("env", [{"SMAP_WS1": "40"}, {"SMAP_WS1": "41", "SMAP_HALO3": "16"},
-                                 {"SMAP_HALO3": "32", "SMAP_HALO3_DEEP": "1"}], ids=["ws40", "ws41+halo16", "halo32deep"])
+@pytest.mark.parametrize("env", [{"SMAP_HALO3": "16"}, {"SMAP_HALO3": "32", "SMAP_HALO3_DEEP": "1"}], ids=["halo16", "halo32deep"])
 def test_small_schedule_with_specialised_kernels(golden_dir, small, monkeypatch, env):
-    """The whole schedule with every eligible conv routed to the weight-stationary 1x1 / halo-tiled 3x3 kernels
-    (all their fused epilogues: residual, skip addends, bilinear add, fp32 heads) against the golden outputs."""
+    """The whole schedule with every eligible 3x3 conv routed to the halo-tiled kernel (fp32 heads included) against the
+    golden outputs."""
     from smap_amd.engine import BackboneEngine
     _, sd = small
     z = np.load(f"{golden_dir}/backbone_small.npz")

@@ -4,7 +4,10 @@ same heat-maps.  This is what pins the oracle for nms / paf_score / group:
   * dapalib_ref_nofma (reference sources, -ffp-contract=off) == oracle == HIP, bit for bit;
   * dapalib_ref (default flags, FMA contraction as nvcc/hipcc do by default): identical peak
     sets / counts / limb assignments, float values within 1e-4 px.
-Skipped when oracle/_ref/ was not built (no reference checkout at build time)."""
+A missing oracle/_ref/*.so FAILS these tests (it used to skip): without them the association oracle is unpinned, and
+that must turn the suite red, not quiet.  Build them with `python oracle/build_ref.py` where /root/reference exists
+(__graft_entry__.build() does); the .so files travel with the repo snapshot to the GPU box.
+Scenes: synthetic 0..20-person scenes, pure noise (127-peak cap) AND maps made by the real network."""
 import importlib
 import os
 import sys
@@ -23,16 +26,40 @@ DEV = "cuda:0"
 
 def _load(name):
     if not os.path.exists(os.path.join(REF_DIR, name + ".so")):
-        pytest.skip(f"oracle/_ref/{name}.so not built")
+        pytest.fail(f"oracle/_ref/{name}.so is missing: the association oracle would be unpinned. Run "
+                    f"`python oracle/build_ref.py` in a container that has /root/reference (it travels with the snapshot).")
     if REF_DIR not in sys.path:
         sys.path.insert(0, REF_DIR)
     return importlib.import_module(name)
 
 
+_NET = []
+
+
+def _network_scenes():
+    """Two frames of REAL network output (HIP backbone, calibrated recipe heads: ~24 peaks per key-point channel,
+    PAF channels as the network makes them), scaled as test.py:111-112 does."""
+    if not _NET:
+        from helpers import make_cfg
+        from benchkit.workload import people_state_dict
+        from smap_amd.model.smap import SMAP
+        import dapalib
+        for kind, seed in (("smooth", 1234), ("noise", 77)):
+            torch.manual_seed(0)
+            net = SMAP(make_cfg((128, 208))).eval()
+            net.load_state_dict(people_state_dict(net.state_dict(), kind))
+            x = torch.randn(1, 3, 512, 832, generator=torch.Generator().manual_seed(seed))
+            hms, _, rd = net.to(DEV)(x.to(DEV))
+            dapalib.scale_hms_(hms)
+            _NET.append((hms[0].cpu().numpy().copy(), rd[0, 0].cpu().numpy().copy()))
+            del net
+    return list(_NET)
+
+
 def _scenes():
     sc = [synth_scene(k, seed=300 + k)[:2] for k in (0, 1, 3, 8, 20)]
     sc += [synth_scene(6, seed=9, noise=0.05, drop=0.3)[:2], noise_scene(5), noise_scene(6, amp=0.4)]
-    return sc
+    return sc + _network_scenes()
 
 
 def bits(a):

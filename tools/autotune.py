@@ -25,11 +25,16 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default=os.path.join(ROOT, "smap_amd", "tile_table.json"))
+    ap.add_argument("--precision", choices=("f16", "x3"), default="f16",
+                    help="x3: tune the split-precision instances (-> smap_amd/tile_table_x3.json unless --out is given)")
     ap.add_argument("--halo", type=float, default=0.0, metavar="GAIN",
                     help="only revisit the shapes the specialised kernels cover: keep the tile of the existing table unless "
                          "a halo-tiled 3x3 (csrc/conv3.hip, ids 30..39) or weight-stationary 1x1 (csrc/conv1.hip, ids "
                          "40..41) variant is at least GAIN (e.g. 0.05) faster")
     args = ap.parse_args()
+    x3 = args.precision == "x3"
+    if x3 and args.out == os.path.join(ROOT, "smap_amd", "tile_table.json"):
+        args.out = os.path.join(ROOT, "smap_amd", "tile_table_x3.json")
     from types import SimpleNamespace as NS
     from smap_amd.model.smap import SMAP
     cfg = NS(MODEL=NS(STAGE_NUM=3, UPSAMPLE_CHANNEL_NUM=256), DATASET=NS(KEYPOINT=NS(NUM=15), PAF=NS(NUM=14)),
@@ -55,7 +60,7 @@ def main():
         B, H, W, Cin, Cout, k, s = key
         halo_ok = plain and k == 3 and s == 1
         skey = ",".join(map(str, key))
-        ws_ok = k == 1 and s == 1 and Cin in (64, 128, 256) and Cout % 256 == 0 and not os.environ.get("SMAP_AUTOTUNE_ONLY3")
+        ws_ok = False      # the weight-stationary 1x1 kernel left the product build (tools/experiments/)
         if args.halo and not ((halo_ok or ws_ok) and skey in old):
             continue
         if Cout <= 32:
@@ -65,11 +70,14 @@ def main():
         else:
             cands = [t for t, (bm, bn) in TILES.items() if bn >= 64]
         cands = [t for t in cands if t < 30 or (halo_ok and t < 40)]
+        if x3:
+            from smap_amd.engine import X3_TILES
+            cands = [3] if Cout <= 32 else [t for t in X3_TILES if not (Cout <= 64 and TILES[t][1] > 64)]
         if args.halo:
             cands = [old[skey]] + [t for t in cands if t >= 30] + ([40, 41] if ws_ok else [])
         res = {}
         for t in cands:
-            lib, h, arena, blob, flops, byts = build(B, H, W, Cin, Cout, k, s, t, int(has_res), dev)
+            lib, h, arena, blob, flops, byts = build(B, H, W, Cin, Cout, k, s, t, int(has_res), dev, x3=x3)
             run = lambda: L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()),
                                                     None, st), "run")
             for _ in range(3):
@@ -87,8 +95,9 @@ def main():
         best = min(res, key=res.get)
         if args.halo and res[best] > (1.0 - args.halo) * res[old[skey]]:
             best = old[skey]
-        from smap_amd.engine import pick_tile_heuristic
-        dflt = pick_tile_heuristic(B * ((H + 2 * (k // 2) - k) // s + 1) * ((W + 2 * (k // 2) - k) // s + 1), Cout)
+        from smap_amd.engine import pick_tile_heuristic, pick_tile_x3
+        Mo = B * ((H + 2 * (k // 2) - k) // s + 1) * ((W + 2 * (k // 2) - k) // s + 1)
+        dflt = pick_tile_x3(Mo, Cout) if x3 else pick_tile_heuristic(Mo, Cout)
         table[",".join(map(str, key))] = best
         total_best += res[best] * count
         total_default += res.get(dflt, res[best]) * count

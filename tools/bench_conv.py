@@ -28,8 +28,10 @@ PRESETS = {          # B, H, W, Cin, Cout, k, stride, tile, residual
 }
 
 
-def build(B, H, W, Cin, Cout, k, s, tile, res, dev):
+def build(B, H, W, Cin, Cout, k, s, tile, res, dev, x3=False):
+    """x3: split-precision op (hi/lo planes: strides and weight matrix doubled, smap_op.precision = 1)."""
     lib = L.load()
+    pl = 2 if x3 else 1
     pad = k // 2
     Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
     bn = TILES[tile][1]
@@ -37,15 +39,16 @@ def build(B, H, W, Cin, Cout, k, s, tile, res, dev):
     K = k * k * Cin
     al = lambda n: (n + 255) // 256 * 256
     c8 = (Cout + 7) // 8 * 8
-    x_b, o_b = al(B * H * W * Cin * 2), al(B * Ho * Wo * c8 * 2)
+    x_b, o_b = al(B * H * W * Cin * 2 * pl), al(B * Ho * Wo * c8 * 2 * pl)
     arena = (torch.randn((16384 + x_b + 2 * o_b) // 2 + 128, device=dev) * 0.5).half()
-    w_b = al(cout_pad * K * 2)
+    w_b = al(cout_pad * K * 2 * pl)
     blob = torch.zeros(w_b + al(cout_pad * 4), dtype=torch.uint8, device=dev)
-    blob[:cout_pad * K * 2] = (torch.randn(cout_pad * K, device=dev) * K ** -0.5).half().view(torch.uint8)
+    blob[:cout_pad * K * 2 * pl] = (torch.randn(cout_pad * K * pl, device=dev) * K ** -0.5).half().view(torch.uint8)
     op = L.SmapOp()
-    op.kind, op.B, op.H, op.W, op.Cin, op.in_stride_c, op.in_c_off = 0, B, H, W, Cin, Cin, 0
+    op.kind, op.B, op.H, op.W, op.Cin, op.in_stride_c, op.in_c_off = 0, B, H, W, Cin, Cin * pl, 0
     op.Ho, op.Wo, op.Cout, op.ksize, op.stride, op.pad, op.relu = Ho, Wo, Cout, k, s, pad, 1
-    op.cout_pad, op.out_stride_c, op.out_c_off, op.out_fp32, op.tile = cout_pad, c8, 0, 0, tile
+    op.cout_pad, op.out_stride_c, op.out_c_off, op.out_fp32, op.tile = cout_pad, c8 * pl, 0, 0, tile
+    op.precision, op.acc_scale = int(x3), 1.0
     op.in_off, op.out_off, op.w_off, op.bias_off = 16384, 16384 + x_b + o_b, 0, w_b
     op.res_off = 16384 + x_b if res else -1
     op.add1_off = op.add2_off = op.ext_off = -1
@@ -54,7 +57,7 @@ def build(B, H, W, Cin, Cout, k, s, tile, res, dev):
     h = C.c_void_p()
     L.check(lib.smap_plan_create(C.byref(op), 1, C.byref(h)), "create")
     flops = 2.0 * B * Ho * Wo * Cout * K
-    byts = B * H * W * Cin * 2 + B * Ho * Wo * Cout * 2 * (2 if res else 1) + cout_pad * K * 2
+    byts = (B * H * W * Cin * 2 + B * Ho * Wo * Cout * 2 * (2 if res else 1) + cout_pad * K * 2) * pl
     return lib, h, arena, blob, flops, byts
 
 
@@ -63,6 +66,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--only", default="")
     ap.add_argument("--tile-override", default="", help="e.g. L2:0,L6:5")
+    ap.add_argument("--x3", action="store_true", help="split-precision instances (smap_op.precision = 1)")
     ap.add_argument("--streams", type=int, default=1,
                     help="launch the iterations round-robin on this many streams (own arena each): the difference to one "
                          "stream is the drain-and-dispatch gap between dependent launches that a second stream can hide")
@@ -75,7 +79,7 @@ def main():
         p = list(PRESETS[n])
         if n in ov:
             p[7] = int(ov[n])
-        lib, h, arena, blob, flops, byts = build(*p, dev)
+        lib, h, arena, blob, flops, byts = build(*p, dev, x3=args.x3)
         if args.streams > 1:
             streams = [torch.cuda.Stream(dev) for _ in range(args.streams)]
             arenas = [arena] + [arena.clone() for _ in range(args.streams - 1)]
