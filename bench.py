@@ -5,17 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the whole hot path over one batch of B=8 synthetic frames per GPU
-(BASELINE config 3): SMAP backbone forward (HIP engine) -> /255,/127 scaling -> depth-aware
-association -> 3D lifting -> device-to-host copy of the poses -> result records, run as a
-two-stream pipeline (smap_amd/pipeline.py: the post-processing of batch k overlaps the backbone
-of batch k+1; the pipeline is drained inside the timed region, so K steps = K complete batches); with N>1
-every rank processes its own batch (weak scaling, frames shard with no data-path collective)
-and the step ends with the RCCL all_gather of the per-frame JSON records (config 4).
-Inputs are resident in HBM before the timed region.  Weights are the default random init
-(torch.manual_seed(0)); with them the pelvis heat-map has no peaks, so grouping of the
-network's own output is trivial -- to keep representative association work inside the timed
-region, every step ALSO associates + lifts a resident batch of synthetic 8-person scenes.
+One "step" = one pass of the whole hot path over one batch of B=8 synthetic frames per GPU (BASELINE configs[2]):
+SMAP backbone forward (HIP engine) -> /255,/127 scaling -> depth-aware association -> 3D lifting -> device-to-host
+copy of the poses -> result records, run as a multi-stream pipeline (smap_amd/pipeline.py: the post-processing of batch
+k overlaps later backbones; the pipeline is drained inside the timed region, so K steps = K complete batches).
+With N > 1 every rank processes its own batches (weak scaling, frames shard with no data-path collective) and the run
+ends -- inside the timed region -- with ONE RCCL all_gather of every rank's result records (configs[3]; the reference
+gathers once per run as well: exps/stage3_root2/test.py + lib/utils/comm.py:47-87).
+Inputs are resident in HBM before the timed region.
+
+Arithmetic (--precision): "x3" (default) = fp16 hi/lo pairs with three MFMAs per K step: the mode whose results meet
+the reference's fp32 path end to end (3D joints within 1e-3 m, same peaks and limbs: `config.e2e_parity`, computed in
+this very run against the CPU reference on the same images); "f16" = fp16 storage, ~2x faster, ~0.3 cm mean joint error.
+
+Workload: recipe weights with calibrated heads (benchkit/workload.py: ~24 peaks per key-point channel, ~22 skeletons
+per frame, root depth ~3 m), so the association of the NETWORK's own output is real work; in addition every step
+associates + lifts a resident batch of synthetic scenes whose person count rotates over K in {0, 2, 8, 20}
+(SURVEY.md 8d config 3), timed per K with HIP events on the post-processing stream.
 """
 import argparse
 import gc
@@ -26,9 +32,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
@@ -64,68 +69,64 @@ def usable_cpus(cap=64):
 
 
 _CPU_CHILD = r"""
-import sys, time, os, json, torch
-sys.path.insert(0, sys.argv[1])
-from oracle.backbone_ref import smap_forward
+# Reference path on the host cores (oracle/: fp32 torch-CPU SMAP forward + C association + lifting), frame by frame on
+# the SAME images and weights as the GPU run.  Serves two purposes with one pass: the cpu_baseline timing and the
+# per-frame results the end-to-end parity figures are computed from (benchkit/parity.py).
+import sys, time, os, json, pickle, torch, numpy as np
+root, threads, frames, seed, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+sys.path.insert(0, root)
+from benchkit import parity
+from benchkit.workload import make_cfg, people_state_dict, PEOPLE_CAM
 from smap_amd.model.smap import SMAP
-from helpers import make_cfg
-threads, budget = int(sys.argv[2]), float(sys.argv[3])
 torch.set_num_threads(threads)
 torch.manual_seed(0)
-sd = {k: v.float() for k, v in SMAP(make_cfg((128, 208))).state_dict().items()}
-x = torch.randn(1, 3, 512, 832, generator=torch.Generator().manual_seed(1234))
-with torch.no_grad():
-    t0 = time.time(); smap_forward(sd, x); warm = time.time() - t0
-    t0, n = time.time(), 0
-    while n < 1 or (time.time() - t0 < budget and n < 10):
-        smap_forward(sd, x); n += 1
-    print(json.dumps({"sec_per_frame": (time.time() - t0) / n, "n": n, "warm": warm, "threads": torch.get_num_threads()}))
+sd = people_state_dict(SMAP(make_cfg((128, 208))).state_dict(), "smooth")
+x = torch.randn(8, 3, 512, 832, generator=torch.Generator().manual_seed(seed))[:frames]
+cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (frames, 1))
+parity.reference_path(sd, x[:1], cams[:1])                     # warm-up (oneDNN primitive cache, page faults)
+t0 = time.time()
+ref = parity.reference_path(sd, x, cams)
+dt = (time.time() - t0) / frames
+# association + lifting alone: single thread (the reference's own path: its OpenMP pragmas are commented out,
+# association.cpp:79,100) and frame-parallel over the cores
+from oracle import oracle_lib as O
+from concurrent.futures import ThreadPoolExecutor
+def assoc(r):
+    b, _, _ = O.connect(r["hms"], r["root_d"], 2, True)
+    O.lift(b, r["det_d"], r["root_d"], cams[0])
+t0 = time.time()
+for r in ref: assoc(r)
+t_as1 = (time.time() - t0) / frames
+with ThreadPoolExecutor(min(threads, frames)) as ex:
+    t0 = time.time(); list(ex.map(assoc, ref * 4)); t_asn = (time.time() - t0) / (4 * frames)
+pickle.dump({"ref": ref, "sec_per_frame": dt, "assoc_1thread_ms": t_as1 * 1e3, "assoc_all_cores_ms": t_asn * 1e3,
+             "threads": torch.get_num_threads(), "frames": frames}, open(out, "wb"))
 """
 
 
-def cpu_baseline(scenes, budget_s=12.0):
-    """Reference CPU path restated (oracle/): torch-CPU backbone (oracle/backbone_ref.py) + C
-    association + lifting (oracle/smap_oracle.c), on a bounded sample of the same workload.
-    The backbone runs in a child process under a hard timeout so that a mis-sized OpenMP team on
-    the box's host CPU cannot stall the bench."""
+def cpu_reference(frames, seed):
+    """Runs _CPU_CHILD under a hard timeout (a mis-sized OpenMP team on the box's host CPU must not stall the bench).
+    Returns its result dict or {"error": ...}."""
     import subprocess
-    from oracle import oracle_lib as O
+    import tempfile
     threads = usable_cpus(32)
-    bb = None
+    out = os.path.join(tempfile.mkdtemp(prefix="smap_bench_"), "ref.pkl")
     try:
-        r = subprocess.run([sys.executable, "-c", _CPU_CHILD, ROOT, str(threads), str(budget_s)],
-                           capture_output=True, text=True, timeout=150, cwd=ROOT,
-                           env={**os.environ, "PYTHONPATH": os.pathsep.join([ROOT, os.path.join(ROOT, "tests"),
-                                                                             os.path.join(ROOT, "tests", "golden")])})
-        bb = json.loads(r.stdout.strip().splitlines()[-1])
+        r = subprocess.run([sys.executable, "-c", _CPU_CHILD, ROOT, str(threads), str(frames), str(seed), out],
+                           capture_output=True, text=True, timeout=240, cwd=ROOT)
+        if r.returncode != 0:
+            return {"error": r.stderr[-300:]}
+        res = pickle.load(open(out, "rb"))
+        res["cores"] = threads
+        return res
     except Exception as e:          # timeout / parse error: report it, never hang the bench
-        bb = {"error": repr(e)[:200]}
-    cam = np.array([1.0, 832, 512, 832, 512, 832, 832, 416, 256], np.float64)
-    det = np.zeros((14, 128, 208), np.float32)
-    t0, m = time.time(), 0
-    for _ in range(3):
-        for hms, rd in scenes[:8]:
-            bodys, _, _ = O.connect(hms, rd)
-            O.lift(bodys, det, rd, cam)
-            m += 1
-    t_as = (time.time() - t0) / max(m, 1)
-    out = {"unit": "frames/sec", "cores": threads, "kind": "port", "assoc_ms": t_as * 1e3}
-    if "sec_per_frame" in bb:
-        out["value"] = 1.0 / (bb["sec_per_frame"] + t_as)
-        out["backbone_ms"] = bb["sec_per_frame"] * 1e3
-        out["sample"] = (f"{bb['n']} x backbone fwd of 1x3x{H}x{W} (oracle/backbone_ref.py, torch CPU fp32, "
-                         f"{bb['threads']} threads) + {m} x association+lift of a synthetic 8-person frame "
-                         f"(oracle/smap_oracle.c, 1 thread)")
-    else:
-        out["value"] = None
-        out["sample"] = f"backbone child failed: {bb.get('error')}"
-    return out
+        return {"error": repr(e)[:200]}
 
 
 def forward_only(args, dev, rank, world, B):
     """BASELINE configs[1]: SMAP forward only (HIP conv engine), inputs resident, K forwards back to back on one
     stream, timed with HIP events around the K schedules and with the host clock around barrier + synchronize."""
-    from helpers import make_cfg
+    from benchkit.workload import make_cfg
     from model.smap import SMAP
     torch.manual_seed(0)
     net = SMAP(make_cfg((128, 208))).eval().to(dev)
@@ -201,32 +202,28 @@ class _StandInPipeline:
 
 
 def dry_run(args):
-    """bench.py's distributed control flow on CPU (gloo): same sequence of collectives per rank as the GPU run."""
+    """bench.py's distributed control flow on CPU (gloo): same sequence of collectives per rank as the GPU run -- records
+    collected over the timed steps, ONE gather at the end of the run, barrier, MAX all-reduce, one JSON line on rank 0."""
     from smap_amd.dist import gather_bytes
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     if world > 1:
         dist.init_process_group("gloo")
     pipe = _StandInPipeline(args.depth, args.batch, rank)
-    last = [None]
-
-    def finish(recs):
-        if recs is None:
-            return
-        last[0] = [recs] if world == 1 else gather_bytes(pickle.dumps(recs, protocol=pickle.HIGHEST_PROTOCOL), "cpu")
-
     for _ in range(args.warmup):
-        finish(pipe.submit())
-    finish(pipe.flush())
+        pipe.submit()
+    pipe.flush()
+    collected = []
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        finish(pipe.submit())
-    finish(pipe.flush())
+        collected.extend(pipe.submit() or [])
+    collected.extend(pipe.flush() or [])
+    got = [collected]
     if world > 1:
+        got = [pickle.loads(b) for b in gather_bytes(pickle.dumps(collected, protocol=pickle.HIGHEST_PROTOCOL), "cpu")]
         dist.barrier()
     dt = time.perf_counter() - t0
-    got = last[0] if world == 1 else [pickle.loads(b) for b in last[0]]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -236,19 +233,39 @@ def dry_run(args):
                           "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "synthetic",
-                          "config": {"workload": "stand-in pipeline", "ranks_in_last_gather": len(got),
+                          "config": {"workload": "stand-in pipeline", "ranks_in_gather": len(got),
+                                     "records_per_rank": [len(g) for g in got],
+                                     "first_paths": [g[0]["image_path"] for g in got],
                                      "last_paths": [g[-1]["image_path"] for g in got]}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
+def pin_host_threads(local, world):
+    """One process per GPU on a shared host: give each rank its own slice of the allowed CPUs and a matching thread
+    count, so that eight submit threads + their OpenMP/MKL pools do not fight over the same cores."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        if world > 1 and len(cpus) >= 2 * world:
+            per = len(cpus) // world
+            os.sched_setaffinity(0, cpus[local * per:(local + 1) * per])
+            cpus = cpus[local * per:(local + 1) * per]
+        n = max(1, min(len(cpus), 16))
+    except (AttributeError, OSError):
+        n = 4
+    os.environ.setdefault("OMP_NUM_THREADS", str(n))
+    torch.set_num_threads(n)
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the CPU reference pass (no cpu_baseline, no config.e2e_parity): kernel experiments only")
     ap.add_argument("--depth", type=int, default=2,
                     help="backbones in flight per GPU (2 = two streams/arenas: batch k+1 fills the CUs that batch k's "
                          "low-resolution layers leave idle)")
@@ -260,11 +277,11 @@ def main():
                          "launching its ~208 kernels one by one")
     ap.add_argument("--refine", action="store_true",
                     help="BASELINE configs[4]: also run the RefineNet post-refinement (model/refinenet.py) on every pose")
-    ap.add_argument("--precision", choices=("f16", "x3"), default=os.environ.get("SMAP_PRECISION", "f16"),
+    ap.add_argument("--precision", choices=("f16", "x3"), default=os.environ.get("SMAP_PRECISION", "x3"),
                     help="backbone arithmetic: x3 = fp16 hi/lo pairs + three MFMAs per K step (meets the reference's fp32 "
                          "results end to end); f16 = fp16 storage (fast mode, ~1e-3 relative error on the maps)")
     ap.add_argument("--dry-run", action="store_true",
-                    help="no GPU: the same control flow (pipeline protocol, per-step gather, MAX over ranks, one JSON line on "
+                    help="no GPU: the same control flow (pipeline protocol, end-of-run gather, MAX over ranks, one JSON line on "
                          "rank 0) with a stand-in pipeline and the gloo backend -- what the multi-rank CPU test runs")
     args = ap.parse_args()
     if args.dry_run:
@@ -273,13 +290,13 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    host_threads = pin_host_threads(local, world)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm; one process per GPU
 
-    import dapalib
-    from helpers import make_cfg, synth_scene
+    from benchkit.workload import PEOPLE_CAM, make_cfg, people_state_dict, synth_scene
     from model.smap import SMAP
     from smap_amd.dist import gather_bytes
 
@@ -289,52 +306,63 @@ def main():
     from smap_amd.pipeline import PosePipeline
     from exps.stage3_root2.config import cfg as run_cfg
     torch.manual_seed(0)
-    net = SMAP(make_cfg((128, 208))).eval().to(dev)
+    net = SMAP(make_cfg((128, 208))).eval()
+    net.load_state_dict(people_state_dict(net.state_dict(), "smooth"))
+    net = net.to(dev)
     net.precision = args.precision
     refine_w = None
     if args.refine:
         from model.refinenet import RefineNet
         torch.manual_seed(1)
         refine_w = RefineNet().eval().folded(dev)
+    SEED = 1234                      # frame 0 of this batch is the frame the heads were calibrated on; every rank
+    imgs_cpu = torch.randn(8, 3, H, W, generator=torch.Generator().manual_seed(SEED))   # runs the same 8 frames
+    imgs_cpu = imgs_cpu[:B] if B <= 8 else imgs_cpu.repeat((B + 7) // 8, 1, 1, 1)[:B]
+    imgs = imgs_cpu.to(dev)
+    cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (B, 1))
+
+    # ---- end-to-end parity of THIS configuration (outside the timed region; rank 0, N = 1 reports it).  The CPU child
+    #      computes the reference path while the GPU side is being set up.
+    parity_out, cpu_ref, hip_frames = None, None, None
+    want_ref = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if want_ref:
+        import concurrent.futures as cf
+        nref = min(B, 8)
+        ref_future = cf.ThreadPoolExecutor(1).submit(cpu_reference, nref, SEED)
+        from benchkit import parity
+        hip_frames = parity.hip_path(net, imgs[:nref] if B == nref else imgs, cams)[:nref] if B >= nref else None
+
     pipe = PosePipeline(net, run_cfg, B, H, W, dev, refine_weights=refine_w, n_extra=1, depth=args.depth)
-    imgs = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
-    scenes = [synth_scene(8, seed=1000 * rank + i)[:2] for i in range(B)]
-    s_hms = torch.from_numpy(np.stack([s[0] for s in scenes])).to(dev)
-    s_rd = torch.from_numpy(np.stack([s[1] for s in scenes])).to(dev)
-    cams = np.tile(np.array([1.0, 832, 512, 832, 512, 832, 832, 416, 256], np.float64), (B, 1))
+    KS = (0, 2, 8, 20)               # synthetic scenes, person count rotating over the steps
+    synth = {}
+    for K in KS:
+        sc = [synth_scene(K, seed=1000 * rank + 10 * K + i)[:2] for i in range(B)]
+        synth[K] = (torch.from_numpy(np.stack([s_[0] for s_ in sc])).to(dev), torch.from_numpy(np.stack([s_[1] for s_ in sc])).to(dev))
     tags = [f"r{rank}/f{i}" for i in range(B)]
-    last = [None]
+    collected = []                   # this rank's records of the timed steps (gathered once, at the end of the run)
 
-    def finish(recs):
-        """Records of a completed batch -> (RCCL) all_gather of every rank's serialised records to every rank, on the comm
-        stream (BASELINE configs[3]).  Serialisation is pickle, like the reference's gather helper (lib/utils/comm.py:
-        57-59); the gathered payloads stay bytes -- decoding 8 ranks' records on every rank every step is not part of
-        the path (rank 0 writes the JSON file once, after the run: test.py:147-151).  Nothing to do at N = 1."""
-        if recs is None:
-            return
-        if world == 1:
-            last[0] = recs
-            return
-        payload = pickle.dumps(recs, protocol=pickle.HIGHEST_PROTOCOL)
-        with torch.cuda.stream(pipe.s_comm):
-            last[0] = gather_bytes(payload, dev)
-
-    host = {"submit": 0.0, "finish": 0.0}
+    host = {"submit": 0.0}
+    step_no = [0]
 
     def step(timed):
-        # backbone(k) on one stream; association+lift+D2H of batch k on another; records of batch k-1 on the host
+        # backbone(k) on one stream; association+lift+D2H of batch k on another; records of earlier batches on the host
+        K = KS[step_no[0] % len(KS)]
+        step_no[0] += 1
         t0 = time.perf_counter()
-        recs = pipe.submit(imgs, cams, tags, extra=[("synth", s_hms, s_rd, None)], time_backbone=timed)
-        t1 = time.perf_counter()
-        finish(recs)
+        recs = pipe.submit(imgs, cams, tags, extra=[(f"synthK{K}", synth[K][0], synth[K][1], None)], time_backbone=timed)
         if timed:
-            host["submit"] += t1 - t0
-            host["finish"] += time.perf_counter() - t1
-            host.setdefault("steps", []).append((t1 - t0) * 1e3)
+            dt = time.perf_counter() - t0
+            host["submit"] += dt
+            host.setdefault("steps", []).append(dt * 1e3)
+            if recs:
+                collected.extend(recs)
 
+    if want_ref:
+        cpu_ref = ref_future.result()         # the CPU pass ran beside the GPU set-up; it is over before anything is timed
     for _ in range(args.warmup):
         step(False)
-    finish(pipe.flush())
+    pipe.flush()
+    step_no[0] = 0
     # The set-up leaves ~2 M long-lived Python objects behind (state dict, folded weights, op lists); a full cyclic-GC
     # pass over them costs ~35 ms and lands on some step or other of the timed loop depending on K and W.  Freeze them
     # into the permanent generation: collections during the loop then only look at what the loop itself allocates.
@@ -343,25 +371,39 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     t_loop = time.perf_counter() - t0
-    finish(pipe.flush())                      # the K-th batch is complete inside the timed region
+    tail = pipe.flush()                       # the K-th batch is complete inside the timed region
+    if tail:
+        collected.extend(tail)
     t_flush = time.perf_counter() - t0
-    if world > 1:
+    gathered = None
+    if world > 1:                             # ONE gather per run: every rank's records to every rank (RCCL, comm stream)
+        payload = pickle.dumps(collected, protocol=pickle.HIGHEST_PROTOCOL)
+        with torch.cuda.stream(pipe.s_comm):
+            gathered = gather_bytes(payload, dev)
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
     bb_ms = [e0.elapsed_time(e1) for e0, e1 in pipe.bb_events]
     # idle time of a backbone stream between two consecutive schedules (batch k-depth's end -> batch k's start)
     ev = pipe.bb_events
     gap_ms = [ev[k - args.depth][1].elapsed_time(ev[k][0]) for k in range(args.depth, len(ev))]
-    last = [last[0]] if world == 1 else [pickle.loads(b) for b in last[0]]
+    post_us = {}
+    for tag, p0, p1 in pipe.post_events:
+        post_us.setdefault(tag, []).append(p0.elapsed_time(p1) * 1e3)
+    per_rank_host = [cpu_ms_per_step]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        hc = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(hc, torch.tensor([cpu_ms_per_step], dtype=torch.float64, device=dev))
+        per_rank_host = [float(h.item()) for h in hc]
     if rank == 0:
         frames = B * world * args.steps
         fps = frames / dt
@@ -370,39 +412,62 @@ def main():
             achieved = ALG_GFLOP_PER_FRAME * B * args.steps / dt / 1e3
         else:
             achieved = ALG_GFLOP_PER_FRAME * B / bb / 1e3        # TFLOP/s over the whole backbone schedule
+        x3 = args.precision == "x3"
         traffic, traffic_src = None, None                        # HBM bytes per batch from committed PMC passes
-        tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "hbm_traffic_x3.json" if x3 else "hbm_traffic.json")
         if os.path.exists(tj) and B == 8:
             t = json.load(open(tj))
             traffic = t["hbm_read_bytes_per_batch"] + t["hbm_write_bytes_per_batch"]
             traffic_src = t["source"]
+        n_rec = len(collected) if gathered is None else sum(len(pickle.loads(b)) for b in gathered)
         out = {
             "metric": "frames/sec at 3x512x832 (SMAP backbone + depth-aware association + 3D lifting)",
             "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16x3" if x3 else "f16", "data": "synthetic",
             "config": {"workload": f"batch={B} x 3x512x832 per GPU, full SMAP + depth-aware PAF association "
                                    f"+ lifting{' + RefineNet (configs[4])' if args.refine else ''} "
                                    f"(BASELINE configs[2]; configs[3] when n_gpus=8)",
-                       "frames_per_step": B * world, "persons_in_last_step": sum(len(r) for r in last),
-                       "arithmetic": "backbone fp16 storage / fp32 MFMA accumulate, heads fp32; association fp32 (+f64 "
-                                     "where the reference is); lifting f64",
-                       "pipeline": f"post-processing of batch k overlaps later backbones; {args.depth} backbone(s) in flight",
-                       "host_ms_per_step": {k: v / args.steps * 1e3 for k, v in host.items() if k != "steps"},
+                       "frames_per_step": B * world, "records_in_run": n_rec,
+                       "arithmetic": ("backbone: fp16 hi/lo pairs (22 significant bits), three fp16 MFMAs per K step, fp32 "
+                                      "accumulate = the reference's fp32 results to ~3e-6 relative" if x3 else
+                                      "backbone: fp16 storage / fp32 MFMA accumulate (~2e-3 relative on the maps)") +
+                                     "; heads fp32; association fp32 (+f64 where the reference is); lifting f64",
+                       "weights": "by-key recipe, stage-2 heads calibrated to ~24 peaks per key-point channel (benchkit/workload.py)",
+                       "pipeline": f"post-processing of batch k overlaps later backbones; {args.depth} backbone(s) in flight; "
+                                   f"one end-of-run gather of the records",
+                       "association_lift_us_per_batch": {k: float(np.median(v)) for k, v in sorted(post_us.items())},
+                       "host_ms_per_step": {"submit_wall": host["submit"] / args.steps * 1e3, "process_cpu_per_rank": per_rank_host,
+                                            "threads": host_threads},
                        "host_submit_ms_quantiles": [float(np.percentile(host["steps"], q)) for q in (0, 10, 50, 90, 100)],
-                       "host_submit_slowest_step": int(np.argmax(host["steps"])),
                        "host_timeline_ms": {"submit_loop_done": t_loop * 1e3, "flush_done": t_flush * 1e3, "total": dt * 1e3}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "conv_igemm_kernel (all backbone launches; HIP events: per-schedule span below, "
-                                   "rate = algorithmic FLOPs of the timed region / its duration when depth > 1)",
+                         "kernel": "conv_igemm_kernel / conv3x3_halo_kernel (all backbone launches; HIP events: per-schedule span "
+                                   "below, rate = algorithmic FLOPs of the timed region / its duration when depth > 1)",
+                         "mfma_flops_executed_per_algorithmic_flop": 3 if x3 else 1,
+                         "mfma_pipe_frac": (3 if x3 else 1) * achieved / PEAK_F16_TFLOPS,
                          "backbone_ms_per_batch": bb * 1e3,
                          "backbone_stream_idle_ms_between_batches": float(np.mean(gap_ms)) if gap_ms else None,
-                         "first_backbone_start_to_last_end_ms": ev[0][0].elapsed_time(max(ev[-1][1], ev[-2][1], key=lambda e: ev[0][0].elapsed_time(e))) if len(ev) > 1 else None,
                          "algorithmic_gflop_per_frame": ALG_GFLOP_PER_FRAME},
         }
-        if not args.no_cpu_baseline and world == 1:              # reported at N = 1 only (the other ranks would idle)
-            out["cpu_baseline"] = cpu_baseline(scenes)
+        if want_ref:
+            if "error" in cpu_ref:
+                out["cpu_baseline"] = {"value": None, "unit": "frames/sec", "cores": cpu_ref.get("cores"), "kind": "port",
+                                       "sample": "reference child failed: " + cpu_ref["error"]}
+            else:
+                from benchkit import parity
+                m = parity.compare(hip_frames, cpu_ref["ref"])
+                out["config"]["e2e_parity"] = m
+                out["config"]["e2e_mpjpe_cm"], out["config"]["peak_match"] = m["mpjpe_cm"], m["peak_match"]
+                out["cpu_baseline"] = {
+                    "value": 1.0 / cpu_ref["sec_per_frame"], "unit": "frames/sec", "cores": cpu_ref["cores"], "kind": "port",
+                    "backbone_plus_assoc_ms_per_frame": cpu_ref["sec_per_frame"] * 1e3,
+                    "assoc_lift_ms_per_frame_1thread": cpu_ref["assoc_1thread_ms"],
+                    "assoc_lift_ms_per_frame_all_cores_frame_parallel": cpu_ref["assoc_all_cores_ms"],
+                    "sample": f"{cpu_ref['frames']} frames of the same batch: oracle/backbone_ref.py (torch CPU fp32, "
+                              f"{cpu_ref['threads']} threads) + oracle/smap_oracle.c association + lifting (1 thread, as the "
+                              f"reference) per frame; association also frame-parallel over the cores"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

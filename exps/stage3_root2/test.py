@@ -22,6 +22,7 @@ import json
 import logging
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 from torch.utils.data import DataLoader, Subset
@@ -100,7 +101,15 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
             annotations = [kept_annotations(m.numpy(), cfg.DATASET.ROOT_IDX) for m in meta_data]
             cams = [annotation_camera(a, s) if len(a) else [1.0] * 9 for a, s in zip(annotations, scales)]
         imgs = imgs.to(device, non_blocking=True).float().contiguous()
-        if pipe is None or pipe.B != len(imgs):                  # (last) batch of a different size
+        img_path = list(img_path)
+        if pipe is not None and len(imgs) < pipe.B:              # ragged last batch: pad with copies of its last frame and
+            pad = pipe.B - len(imgs)                             # drop their records (tag None) -- no second engine / arena
+            imgs = torch.cat([imgs, imgs[-1:].expand(pad, -1, -1, -1)], 0).contiguous()
+            cams = np.concatenate([np.asarray(cams, np.float64), np.repeat(np.asarray(cams, np.float64)[-1:], pad, 0)], 0)
+            img_path = img_path + [None] * pad
+            if annotations is not None:
+                annotations = list(annotations) + [annotations[-1]] * pad
+        if pipe is None or pipe.B != len(imgs):
             if pipe is not None:
                 drain(pipe.flush())
             pipe = PosePipeline(model, cfg, len(imgs), imgs.shape[-2], imgs.shape[-1], device, refine_w,

@@ -70,6 +70,7 @@ class PosePipeline:
         self.slots = [_Slot(self.engine, self.device, n_extra, batch) for _ in range(self.nslots)]
         self.k = 0
         self.bb_events = []              # (start, end) HIP events of timed backbone runs
+        self.post_events = []            # (tag, start, end) HIP events of timed association+lifting passes (time_backbone=True)
 
     # -- device side -------------------------------------------------------------------------
     def _post(self, slot, idx, hms, det_d, root_d, cams, scale, gt=None):
@@ -142,9 +143,17 @@ class PosePipeline:
             slot.ev_bb.record()
         with torch.cuda.stream(self.s_post):
             self.s_post.wait_event(slot.ev_bb)
-            self._post(slot, 0, slot.hms, slot.det_d, slot.root_d, cams_d, scale=True, gt=gt)
+            def timed_post(tag, *a, **k):
+                if not time_backbone:
+                    return self._post(*a, **k)
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record()
+                self._post(*a, **k)
+                p1.record()
+                self.post_events.append((tag, p0, p1))
+            timed_post("network", slot, 0, slot.hms, slot.det_d, slot.root_d, cams_d, scale=True, gt=gt)
             for j, (tag, hms, rd, dd) in enumerate(extra):
-                self._post(slot, 1 + j, hms, slot.det_d if dd is None else dd, rd, cams_d, scale=False)
+                timed_post(tag, slot, 1 + j, hms, slot.det_d if dd is None else dd, rd, cams_d, scale=False)
             slot.ev_post.record()
         slot.meta = (list(tags), [t for t, *_ in extra], annotations)
         slot.busy = True
@@ -177,7 +186,7 @@ class PosePipeline:
             p3, rz = h["p3"].numpy(), h["rz"].numpy()
             for i, P in enumerate(counts):
                 P = int(P)
-                if P == 0:
+                if P == 0 or tags[i] is None:                                   # tag None = padding frame of a ragged last batch
                     continue                                                    # test.py:81-82,131-132
                 name = tags[i] if idx == 0 else f"{extra_tags[idx - 1]}/{tags[i]}"
                 if gt_mode and self.record_mode == "generate_train":            # test.py:142-143

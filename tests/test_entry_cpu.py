@@ -231,8 +231,8 @@ def test_joint_dataset_croppad_and_loader(tmp_path):
 
 
 def test_bench_control_flow_two_ranks_gloo():
-    """bench.py --dry-run under torch.distributed.run with 2 ranks: every rank issues the same collectives (per-step
-    gather of pickled records, barrier, MAX all-reduce) and rank 0 alone prints the one JSON line."""
+    """bench.py --dry-run under torch.distributed.run with 2 ranks: every rank issues the same collectives (ONE end-of-run
+    gather of the pickled records of all timed steps, barrier, MAX all-reduce) and rank 0 alone prints the one JSON line."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
@@ -242,6 +242,7 @@ def test_bench_control_flow_two_ranks_gloo():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["config"]["ranks_in_last_gather"] == 2
-    # the last gather carries the flush of the final batches: depth = 2 -> batches 5 and 6 of each rank (2 warm-up + 5)
-    assert d["config"]["last_paths"] == ["r0/b6/f7", "r1/b6/f7"]
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["config"]["ranks_in_gather"] == 2
+    # the gather carries every record of the 5 timed batches of each rank (8 frames each; batches 2..6 after 2 warm-ups)
+    assert d["config"]["records_per_rank"] == [40, 40]
+    assert d["config"]["first_paths"] == ["r0/b2/f0", "r1/b2/f0"] and d["config"]["last_paths"] == ["r0/b6/f7", "r1/b6/f7"]
