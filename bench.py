@@ -277,6 +277,9 @@ def main():
                          "launching its ~208 kernels one by one")
     ap.add_argument("--refine", action="store_true",
                     help="BASELINE configs[4]: also run the RefineNet post-refinement (model/refinenet.py) on every pose")
+    ap.add_argument("--flip", action="store_true",
+                    help="flip-TTA (test.py:55-70, the reference's shipped --do_flip 1): every frame also runs mirrored, inside "
+                         "the same schedule (2B-frame batch; stem reads the mirror by index, head sum merges)")
     ap.add_argument("--precision", choices=("f16", "x3"), default=os.environ.get("SMAP_PRECISION", "x3"),
                     help="backbone arithmetic: x3 = fp16 hi/lo pairs + three MFMAs per K step (meets the reference's fp32 "
                          "results end to end); f16 = fp16 storage (fast mode, ~1e-3 relative error on the maps)")
@@ -332,7 +335,8 @@ def main():
         from benchkit import parity
         hip_frames = parity.hip_path(net, imgs[:nref] if B == nref else imgs, cams)[:nref] if B >= nref else None
 
-    pipe = PosePipeline(net, run_cfg, B, H, W, dev, refine_weights=refine_w, n_extra=1, depth=args.depth)
+    pipe = PosePipeline(net, run_cfg, B, H, W, dev, refine_weights=refine_w, n_extra=1, depth=args.depth, numpy_records=True,
+                        do_flip=args.flip)
     KS = (0, 2, 8, 20)               # synthetic scenes, person count rotating over the steps
     synth = {}
     for K in KS:
@@ -426,7 +430,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16x3" if x3 else "f16", "data": "synthetic",
             "config": {"workload": f"batch={B} x 3x512x832 per GPU, full SMAP + depth-aware PAF association "
-                                   f"+ lifting{' + RefineNet (configs[4])' if args.refine else ''} "
+                                   f"+ lifting{' + RefineNet (configs[4])' if args.refine else ''}{' + flip-TTA' if args.flip else ''} "
                                    f"(BASELINE configs[2]; configs[3] when n_gpus=8)",
                        "frames_per_step": B * world, "records_in_run": n_rec,
                        "arithmetic": ("backbone: fp16 hi/lo pairs (22 significant bits), three fp16 MFMAs per K step, fp32 "

@@ -34,7 +34,7 @@ from smap_amd.dist import gather_records, shard_range
 from exps.stage3_root2.config import cfg
 from smap_amd.pipeline import PosePipeline
 from exps.stage3_root2.test_util import default_cams
-from smap_amd.records import annotation_camera, kept_annotations
+from smap_amd.records import annotation_camera, kept_annotations, to_jsonable
 
 
 def get_logger(name, log_dir, filename):
@@ -113,7 +113,7 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
             if pipe is not None:
                 drain(pipe.flush())
             pipe = PosePipeline(model, cfg, len(imgs), imgs.shape[-2], imgs.shape[-1], device, refine_w,
-                                do_flip=bool(cfg.DO_FLIP), record_mode=cfg.TEST_MODE,
+                                do_flip=bool(cfg.DO_FLIP), record_mode=cfg.TEST_MODE, numpy_records=True,
                                 depth=int(os.environ.get("SMAP_PIPELINE_DEPTH", 2)))   # two backbones in flight (+19 %)
         with torch.no_grad():
             drain(pipe.submit(imgs, cams, list(img_path), annotations=annotations))
@@ -126,6 +126,7 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
         dir_name = os.path.split(os.path.split(os.path.realpath(__file__))[0])[1]
         name = os.path.join(output_dir, "{}_{}_{}_{}.json".format(dir_name, cfg.TEST_MODE, cfg.DATA_MODE,
                                                                   cfg.JSON_SUFFIX_NAME))
+        result["3d_pairs"] = to_jsonable(result["3d_pairs"])          # ndarray -> nested lists, once, at the end of the run
         with open(name, "w") as f:
             json.dump(result, f)
         logger.info("Pairs writed to {}".format(name))
@@ -144,6 +145,9 @@ def main():
     parser.add_argument("--do_flip", type=float, default=0, help="Set to 1 if do flip when test")
     parser.add_argument("--dataset_path", type=str, default="", help='Image dir path of "run_inference" test mode')
     parser.add_argument("--json_name", type=str, default="", help="Add a suffix to the result json.")
+    parser.add_argument("--precision", type=str, default="", choices=["", "x3", "f16"],
+                        help="(addition) backbone arithmetic: x3 (default) = fp16 hi/lo pairs, three MFMAs per K step -- "
+                             "reproduces the reference's fp32 forward; f16 = fp16 storage, ~2x faster, ~1e-3 relative error")
     parser.add_argument("--device_preprocess", type=int, default=0,
                         help="(addition) 1: resize/pad/normalise on the GPU (smap_preprocess) instead of in the dataset")
     args = parser.parse_args()
@@ -165,6 +169,8 @@ def main():
     model = SMAP(cfg, run_efficient=cfg.RUN_EFFICIENT)
     device = torch.device(cfg.MODEL.DEVICE, local)
     model.to(device)
+    if args.precision:
+        model.precision = args.precision
 
     if args.test_mode != "run_inference":
         from lib.utils.dataloader import get_test_loader

@@ -158,6 +158,14 @@ typedef struct smap_op {
                                        matrices hi | lo of (w * 2^s); three MFMAs per K step (hi*hi + hi*lo + lo*hi)
                                        into fp32.  fp32 head outputs (out_fp32) and HEADSUM are the same in both modes. */
     float acc_scale;                /* precision 1: 2^-s, applied to the accumulator before the bias             */
+    int32_t flip_from;              /* flip-TTA inside the schedule (test.py:55-70), 0 = off.  STEM: frames b >= flip_from
+                                       are computed from the x-MIRRORED image of input frame b - flip_from (the input
+                                       holds flip_from frames, the schedule runs B = 2 * flip_from).  HEADSUM: B is the
+                                       number of OUTPUT frames; when flip_from > 0 the summed maps of frame b + flip_from
+                                       are merged into frame b: out[b,c,y,x] = v[b,c,y,x] + s_c * v[b+flip_from, pair[c], y,
+                                       W-1-x], s_c = -1 on PAF-x channels (c >= in_c_off, (c - in_c_off) even), then
+                                       channels >= in_c_off are halved; pair = int32[Cout] at w_off in the weight blob. */
+    int32_t reserved_;
 } smap_op;
 
 /* sizeof(smap_op) as compiled: lets a foreign-language binding verify its struct mirror. */

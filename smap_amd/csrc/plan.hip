@@ -40,7 +40,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 template <bool X3>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const _Float16* __restrict__ wk,
                                                    const float* __restrict__ bias, _Float16* __restrict__ out,
-                                                   int H, int W, int Ho, int Wo, float acc_scale)
+                                                   int H, int W, int Ho, int Wo, float acc_scale, int flip_from)
 {
     constexpr int NPL = X3 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) _Float16 s_w[NPL * 64 * ST_K];
@@ -50,13 +50,16 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
     for (int i = tid; i < NPL * 64 * ST_K / 8; i += 256)
         reinterpret_cast<half8*>(s_w)[i] = reinterpret_cast<const half8*>(wk)[i];
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    // flip-TTA: frames >= flip_from are the x-mirrored images of frames 0.. (the mirror lives in this index, not in memory)
+    const bool mirror = flip_from > 0 && b >= flip_from;
+    const int bsrc = mirror ? b - flip_from : b;
     for (int i = tid; i < 3 * ST_PH * ST_PW; i += 256) {
         const int c = i / (ST_PH * ST_PW), r = i - c * ST_PH * ST_PW;
         const int py = r / ST_PW, px = r - py * ST_PW;
         const int iy = iy0 + py, ix = ix0 + px;
         float v = 0.f;
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            v = img[(((size_t)b * 3 + c) * H + iy) * W + ix];
+            v = img[(((size_t)bsrc * 3 + c) * H + iy) * W + (mirror ? W - 1 - ix : ix)];
         const _Float16 hi = (_Float16)v;
         s_p[i] = hi;
         if (X3) s_p[3 * ST_PH * ST_PW + i] = (_Float16)(v - (float)hi);
@@ -347,50 +350,81 @@ __global__ void upadd_kernel(const _Float16* __restrict__ a, const _Float16* __r
 struct HeadSrc { const float* p[3]; int h[3], w[3]; int n; };
 constexpr int HS_PX = 32;
 
-__global__ __launch_bounds__(256) void headsum_kernel(HeadSrc s, float* __restrict__ out, int Ho, int Wo, int C,
-                                                      int Cs)
+// ((s0 + up(s1)) + up(s2)) for four consecutive channels of pixel (b, y, x): the value the reference's
+// `res4 + res3 + res2` (smap.py:417) has there.  A source at the output resolution is its own bilinear image.
+__device__ __forceinline__ float4 head_value4(const HeadSrc& s, const Lerp* ly, int b, int y, int x, int c, int Ho, int Wo, int Cs)
 {
-    __shared__ float tile[48 * (HS_PX + 1)];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < s.n; ++k) {
+        const float* base = s.p[k] + (size_t)b * s.h[k] * s.w[k] * Cs + c;
+        float4 up;
+        if (s.h[k] == Ho && s.w[k] == Wo) {
+            up = *reinterpret_cast<const float4*>(base + ((size_t)y * Wo + x) * Cs);
+        } else {
+            const Lerp lx = lerp_index(x, s.w[k], Wo);
+            const float4 v00 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i0 * s.w[k] + lx.i0) * Cs);
+            const float4 v01 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i0 * s.w[k] + lx.i1) * Cs);
+            const float4 v10 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i1 * s.w[k] + lx.i0) * Cs);
+            const float4 v11 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i1 * s.w[k] + lx.i1) * Cs);
+            up.x = ly[k].l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly[k].l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
+            up.y = ly[k].l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly[k].l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
+            up.z = ly[k].l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly[k].l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
+            up.w = ly[k].l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly[k].l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+        }
+        if (k == 0) v = up;
+        else { v.x += up.x; v.y += up.y; v.z += up.z; v.w += up.w; }
+    }
+    return v;
+}
+
+// fp32 NHWC heads (channel stride Cs) -> fp32 NCHW [B,C,Ho,Wo] = ((s0 + up(s1)) + up(s2)).
+// One 32-pixel row segment per workgroup; LDS transposes pixel-major -> channel-major so
+// that both the NHWC reads and the NCHW writes are coalesced.
+// FLIP (smap_op.flip_from > 0): the flip-TTA merge of test.py:55-70 in the same pass -- the workgroup also evaluates the
+// maps of the mirrored frame b + flip_from at the mirrored pixels W-1-x and writes
+//     out[b,c] = v[b,c] + s_c * v_mirror[pair[c]]   (s_c = -1 on PAF-x channels), halved for c >= n_kpt,
+// the same fp32 operations, in the same order, as the reference's channel loop (and as smap_flip_merge).
+template <bool FLIP>
+__global__ __launch_bounds__(256) void headsum_kernel(HeadSrc s, float* __restrict__ out, int Ho, int Wo, int C,
+                                                      int Cs, int flip_from, const int* __restrict__ pair, int n_kpt)
+{
+    __shared__ float tile[(FLIP ? 2 : 1) * 48 * (HS_PX + 1)];
+    float* tile2 = tile + 48 * (HS_PX + 1);
     const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * HS_PX, tid = threadIdx.x;
     Lerp ly[3];
     for (int k = 0; k < s.n; ++k) ly[k] = lerp_index(y, s.h[k], Ho);
-    // four channels per thread (16-byte loads; Cs is a multiple of 8); a source at the output resolution is its own
-    // bilinear image (weights 1, 0: identity), so it costs one load instead of four
+    // four channels per thread (16-byte loads; Cs is a multiple of 8)
     const int G = Cs >> 2;
     for (int idx = tid; idx < HS_PX * G; idx += 256) {
         const int px = idx / G, c = (idx - px * G) * 4;
         const int x = x0 + px;
         if (x >= Wo || c >= C) continue;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < s.n; ++k) {
-            const float* base = s.p[k] + (size_t)b * s.h[k] * s.w[k] * Cs + c;
-            float4 up;
-            if (s.h[k] == Ho && s.w[k] == Wo) {
-                up = *reinterpret_cast<const float4*>(base + ((size_t)y * Wo + x) * Cs);
-            } else {
-                const Lerp lx = lerp_index(x, s.w[k], Wo);
-                const float4 v00 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i0 * s.w[k] + lx.i0) * Cs);
-                const float4 v01 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i0 * s.w[k] + lx.i1) * Cs);
-                const float4 v10 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i1 * s.w[k] + lx.i0) * Cs);
-                const float4 v11 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i1 * s.w[k] + lx.i1) * Cs);
-                up.x = ly[k].l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly[k].l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
-                up.y = ly[k].l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly[k].l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
-                up.z = ly[k].l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly[k].l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
-                up.w = ly[k].l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly[k].l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
-            }
-            if (k == 0) v = up;
-            else { v.x += up.x; v.y += up.y; v.z += up.z; v.w += up.w; }
-        }
+        const float4 v = head_value4(s, ly, b, y, x, c, Ho, Wo, Cs);
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (c + e < C) tile[(c + e) * (HS_PX + 1) + px] = vv[e];
+        if (FLIP) {
+            const float4 m = head_value4(s, ly, b + flip_from, y, Wo - 1 - x, c, Ho, Wo, Cs);
+            const float mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < C) tile2[(c + e) * (HS_PX + 1) + px] = mm[e];
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < C * HS_PX; idx += 256) {
         const int c = idx / HS_PX, px = idx - c * HS_PX;
         const int x = x0 + px;
-        if (x < Wo) out[(((size_t)b * C + c) * Ho + y) * Wo + x] = tile[c * (HS_PX + 1) + px];
+        if (x >= Wo) continue;
+        float v = tile[c * (HS_PX + 1) + px];
+        if (FLIP) {
+            const float f = tile2[pair[c] * (HS_PX + 1) + px];
+            const bool neg = c >= n_kpt && ((c - n_kpt) & 1) == 0;
+            v = v + (neg ? f * -1.f : f);
+            if (c >= n_kpt) v = v * 0.5f;
+        }
+        out[(((size_t)b * C + c) * Ho + y) * Wo + x] = v;
     }
 }
 
@@ -446,6 +480,7 @@ static int validate(const smap_op& o)
         case SMAP_OP_STEM:
             if (o.Cin != 3 || o.Cout != 64 || o.Ho != (o.H + 6 - 7) / 2 + 1 || o.Wo != (o.W + 6 - 7) / 2 + 1)
                 return SMAP_E_ARG;
+            if (o.flip_from < 0 || (o.flip_from > 0 && o.B != 2 * o.flip_from)) return SMAP_E_ARG;
             return 0;
         case SMAP_OP_STEMPOOL: {
             const int hs = (o.H + 6 - 7) / 2 + 1, ws = (o.W + 6 - 7) / 2 + 1;
@@ -461,6 +496,7 @@ static int validate(const smap_op& o)
             return 0;
         case SMAP_OP_HEADSUM:
             if (o.n_aux < 1 || o.n_aux > 3 || o.Cout > 48 || o.Cin < o.Cout || o.ext_off < 0) return SMAP_E_ARG;
+            if (o.flip_from < 0 || (o.flip_from > 0 && (o.w_off < 0 || o.in_c_off < 0 || o.in_c_off > o.Cout))) return SMAP_E_ARG;
             return 0;
         default:
             return SMAP_E_ARG;
@@ -563,12 +599,12 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                     hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, st, input,
                                        reinterpret_cast<const _Float16*>(wb + o.w_off),
                                        reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, o.Ho,
-                                       o.Wo, o.acc_scale);
+                                       o.Wo, o.acc_scale, o.flip_from);
                 else
                     hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, st, input,
                                        reinterpret_cast<const _Float16*>(wb + o.w_off),
                                        reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, o.Ho,
-                                       o.Wo, 1.f);
+                                       o.Wo, 1.f, o.flip_from);
                 e = hipGetLastError();
                 break;
             }
@@ -612,9 +648,13 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                     s.w[k] = o.aux_w[k];
                 }
                 dim3 grid((o.Wo + HS_PX - 1) / HS_PX, o.Ho, o.B);
-                hipLaunchKernelGGL(headsum_kernel, grid, dim3(256), 0, st, s,
-                                   reinterpret_cast<float*>(reinterpret_cast<char*>(out) + o.ext_off), o.Ho, o.Wo,
-                                   o.Cout, o.Cin);
+                float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + o.ext_off);
+                if (o.flip_from > 0)
+                    hipLaunchKernelGGL(headsum_kernel<true>, grid, dim3(256), 0, st, s, dst, o.Ho, o.Wo, o.Cout, o.Cin,
+                                       o.flip_from, reinterpret_cast<const int*>(wb + o.w_off), o.in_c_off);
+                else
+                    hipLaunchKernelGGL(headsum_kernel<false>, grid, dim3(256), 0, st, s, dst, o.Ho, o.Wo, o.Cout, o.Cin,
+                                       0, nullptr, 0);
                 e = hipGetLastError();
                 break;
             }

@@ -204,10 +204,20 @@ DEFAULT_REMAP = {}
 
 
 class Graph:
-    def __init__(self, sd, B, H, W, stage_num=3, chl=256, kpt_paf=43, paf=14, keep_ref=False, precision="f16"):
+    def __init__(self, sd, B, H, W, stage_num=3, chl=256, kpt_paf=43, paf=14, keep_ref=False, precision="f16",
+                 flip_pair=None):
+        """flip_pair (43 ints: KEYPOINT.FLIP_ORDER + [15 + c for c in PAF.FLIP_CHANNEL]) switches the flip-TTA of
+        test.py:55-70 on INSIDE the schedule: B input frames run as a 2B batch whose second half the stem reads mirrored,
+        and the head sum merges the mirrored maps back (no flipped copy of the images, no separate merge pass); the
+        depth heads, which the reference takes from the un-mirrored pass only, run on the first B frames."""
         assert precision in PRECISIONS, precision
         self.precision, self.x3 = precision, precision == "x3"
         self.keep_ref = keep_ref
+        self.flip_pair = list(flip_pair) if flip_pair is not None else None
+        self.frames = B                       # frames of the input / output
+        if self.flip_pair is not None:
+            assert len(self.flip_pair) == kpt_paf
+            B = 2 * B                         # frames of every activation tensor
         assert H % 32 == 0 and W % 32 == 0, "input must be a multiple of 32 (5 stride-2 levels)"
         self.sd, self.B, self.H, self.W = sd, B, H, W
         self.ops, self.tensors = [], []
@@ -231,8 +241,9 @@ class Graph:
         return off
 
     def conv(self, name, prefixes, x, ksize=1, stride=1, relu=True, res=None, add1=None, add2=None,
-             in_c_off=0, cin=None, out_fp32=False, up=None):
-        """One conv launch; `prefixes` (list) are concatenated along Cout (shared input)."""
+             in_c_off=0, cin=None, out_fp32=False, up=None, frames=None):
+        """One conv launch; `prefixes` (list) are concatenated along Cout (shared input).  frames: run on the first
+        `frames` frames of the batch only (flip-TTA: heads whose mirrored half nobody reads)."""
         ws, bs = zip(*[fold_conv_bn(self.sd, p) for p in prefixes])
         w, b = torch.cat(ws, 0), torch.cat(bs, 0)
         cout, cin_w = w.shape[0], w.shape[1]
@@ -241,11 +252,12 @@ class Graph:
         pad = ksize // 2
         Ho = (x.H + 2 * pad - ksize) // stride + 1
         Wo = (x.W + 2 * pad - ksize) // stride + 1
-        M = self.B * Ho * Wo
-        tile = pick_tile(M, cout, f"{self.B},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
+        nfr = self.B if frames is None else frames
+        M = nfr * Ho * Wo
+        tile = pick_tile(M, cout, f"{nfr},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
         tile = {**DEFAULT_REMAP, **_tile_remap()}.get(tile, tile)
         if self.x3:
-            tile = pick_tile_x3(M, cout, f"{self.B},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
+            tile = pick_tile_x3(M, cout, f"{nfr},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
             x3t = os.environ.get("SMAP_X3_TILE", "")         # A/B hook: force one split-precision tile where it fits
             if x3t and cout > 32 and not (cout <= 64 and TILES[int(x3t)][1] > 64):
                 tile = int(x3t)
@@ -278,7 +290,7 @@ class Graph:
         self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, aux=[up] if up is not None else [], p=dict(
             Cin=cin, in_c_off=in_c_off, Cout=cout, ksize=ksize, stride=stride, pad=pad, relu=int(relu),
             cout_pad=cout_pad, tile=tile, out_fp32=int(out_fp32), w_off=self._add_w(wk), bias_off=self._add_w(bk),
-            acc_scale=acc_scale,
+            acc_scale=acc_scale, frames=nfr,
             w_ref=w if self.keep_ref else None, b_ref=b if self.keep_ref else None)))
         return out
 
@@ -301,7 +313,7 @@ class Graph:
         H4, W4 = (H2 + 2 - 3) // 2 + 1, (W2 + 2 - 3) // 2 + 1
         self.flops += 2 * B * H2 * W2 * 64 * 147
         stem_p = dict(w_off=self._add_w(wk), bias_off=self._add_w(b.to(torch.float32)), w_ref=w, b_ref=b, acc_scale=stem_scale)
-        if self.x3 or not os.environ.get("SMAP_STEMPOOL"):         # default: conv and max-pool as two kernels (the fused kernel below is
+        if self.x3 or self.flip_pair is not None or not os.environ.get("SMAP_STEMPOOL"):         # default: conv and max-pool as two kernels (the fused kernel below is
             t = self.tensor("top.conv", H2, W2, 64)     # bit-identical but no faster inside the two-batch pipeline)
             self.ops.append(Op(OP_STEM, out=t, p=stem_p))
             x = self.tensor("top.pool", H4, W4, 64)
@@ -368,22 +380,26 @@ class Graph:
                     head_t["res4"] = self.conv(u + ".res", [u + ".res_conv2"], m, 3, relu=False, in_c_off=0,
                                                cin=c, out_fp32=True)
                     head_t["res_d"] = self.conv(u + ".res_d", [u + ".res_d_conv2"], m, 3, relu=False, in_c_off=c,
-                                                cin=c, out_fp32=True)
+                                                cin=c, out_fp32=True, frames=self.frames)
                     head_t["res_rd"] = self.conv(u + ".res_rd", [u + ".res_rd_conv2"], m, 3, relu=False,
-                                                 in_c_off=2 * c, cin=c, out_fp32=True)
+                                                 in_c_off=2 * c, cin=c, out_fp32=True, frames=self.frames)
                 elif ind >= 1:
                     m = self.conv(u + ".res1", [u + ".res_conv1"], out, relu=True)
                     head_t[f"res{ind + 1}"] = self.conv(u + ".res", [u + ".res_conv2"], m, 3, relu=False,
                                                         out_fp32=True)
         if heads:
-            B, h, w = self.B, self.out_h, self.out_w
+            B, h, w = self.frames, self.out_h, self.out_w
             n_hms, n_d = self.kpt_paf, self.paf
+            flip_p = {}
+            if self.flip_pair is not None:         # pair table of the in-schedule flip-TTA merge lives in the weight blob
+                flip_p = dict(flip_from=self.frames, n_kpt=n_hms - 2 * n_d,
+                              w_off=self._add_w(torch.tensor(self.flip_pair, dtype=torch.int32)))
             self.out_layout = dict(hms=(0, n_hms), det_d=(B * n_hms * h * w * 4, n_d),
                                    root_d=(B * (n_hms + n_d) * h * w * 4, 1))
             self.out_bytes = B * (n_hms + n_d + 1) * h * w * 4
             # outputs_2d = res4 + res3 + res2 (smap.py:417)
             self.ops.append(Op(OP_HEADSUM, aux=[head_t["res4"], head_t["res3"], head_t["res2"]],
-                               p=dict(Cout=n_hms, ext_off=self.out_layout["hms"][0])))
+                               p=dict(Cout=n_hms, ext_off=self.out_layout["hms"][0], **flip_p)))
             self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_d"]], p=dict(Cout=n_d, ext_off=self.out_layout["det_d"][0])))
             self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_rd"]], p=dict(Cout=1, ext_off=self.out_layout["root_d"][0])))
         return cross, (s1 if gen_skip else None), (s2 if gen_skip else None)
@@ -449,6 +465,7 @@ class Graph:
             p = op.p
             if op.kind == OP_CONV:
                 x, y = op.inp, op.out
+                o.B = p["frames"]
                 o.H, o.W, o.Cin, o.in_stride_c, o.in_c_off = x.H, x.W, p["Cin"], x.C * x.planes, p["in_c_off"]
                 o.Ho, o.Wo, o.Cout = y.H, y.W, p["Cout"]
                 o.ksize, o.stride, o.pad, o.relu = p["ksize"], p["stride"], p["pad"], p["relu"]
@@ -471,6 +488,7 @@ class Graph:
                 o.ksize, o.stride, o.pad, o.relu = 7, 2, 3, 1
                 o.out_off, o.w_off, o.bias_off = y.off, p["w_off"], p["bias_off"]
                 o.acc_scale = p["acc_scale"]
+                o.flip_from = self.frames if self.flip_pair is not None else 0
             elif op.kind == OP_MAXPOOL:
                 x, y = op.inp, op.out
                 o.H, o.W, o.Cin, o.Ho, o.Wo, o.Cout = x.H, x.W, x.C, y.H, y.W, y.C
@@ -490,6 +508,9 @@ class Graph:
                 for k, t in enumerate(op.aux):
                     o.aux_off[k], o.aux_h[k], o.aux_w[k] = t.off, t.H, t.W
                 o.ext_off = p["ext_off"]
+                o.B = self.frames                          # output frames (flip-TTA: the mirrored half is merged in)
+                if p.get("flip_from"):
+                    o.flip_from, o.in_c_off, o.w_off = p["flip_from"], p["n_kpt"], p["w_off"]
         return arr
 
     def weight_blob(self):
@@ -504,14 +525,14 @@ class BackboneEngine:
     """Device-resident schedule for one (B, H, W): weights, arena, output buffer, plan."""
 
     def __init__(self, state_dict, B, H, W, device, stage_num=3, chl=256, kpt_paf=43, paf=14, reuse=True,
-                 precision="f16"):
+                 precision="f16", flip_pair=None):
         self.lib = _L.load()          # fails loudly when libsmap_hip.so is missing
         self.precision = precision
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("BackboneEngine needs a ROCm GPU device (no CPU path in smap_amd)")
         sd = {k: v.detach().cpu() for k, v in state_dict.items()}
-        g = Graph(sd, B, H, W, stage_num, chl, kpt_paf, paf, precision=precision)
+        g = Graph(sd, B, H, W, stage_num, chl, kpt_paf, paf, precision=precision, flip_pair=flip_pair)
         g.allocate(reuse=reuse)
         self.graph, self.B, self.H, self.W = g, B, H, W
         self.h, self.w = g.out_h, g.out_w

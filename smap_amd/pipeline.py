@@ -28,9 +28,7 @@ MAXG = 64                       # annotations per frame the registration kernel 
 class _Slot:
     def __init__(self, engine, device, n_extra, B):
         self.out = engine.new_output()
-        hms, det_d, root_d = engine.views(self.out)         # engine batch is 2B with flip-TTA: [frames ; mirrored]
-        self.hms, self.det_d, self.root_d = hms[:B], det_d[:B], root_d[:B]
-        self.hms_flip = hms[B:] if engine.B == 2 * B else None
+        self.hms, self.det_d, self.root_d = engine.views(self.out)   # B frames, also with flip-TTA (merged in the schedule)
         mk = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         self.host = [dict(p2=mk((B, MAXP, NJ, 4), torch.float32), p3=mk((B, MAXP, NJ, 4), torch.float64),
                           rz=mk((B, MAXP), torch.float64), counts=mk((B,), torch.int32))
@@ -44,21 +42,23 @@ class _Slot:
 
 class PosePipeline:
     def __init__(self, model, cfg, batch, H, W, device, refine_weights=None, n_extra=0, do_flip=False, depth=1,
-                 record_mode="run_inference"):
+                 record_mode="run_inference", numpy_records=False):
         """record_mode: test.py's -t: "run_inference" (no ground truth), "generate_result" (one record per frame
         with the annotations attached) or "generate_train" (one record per matched person); the last two need
         `annotations=` in submit()."""
         assert record_mode in ("run_inference", "generate_result", "generate_train")
         self.record_mode = record_mode
+        self.as_lists = not numpy_records      # numpy_records: records carry ndarray copies (records.to_jsonable at the end)
         self.device = torch.device(device)
         self.cfg = cfg
         self.B, self.do_flip = batch, bool(do_flip)
-        # flip-TTA (test.py:55-70): frames and their mirror images run as ONE 2B batch
-        self.engine = model.engine(2 * batch if do_flip else batch, H, W, self.device)
-        self._model, self._generation = model, model.weights_generation      # a reload / .to() after this point makes the
-                                                                             # pipeline stale: submit() refuses to run on old weights
+        # flip-TTA (test.py:55-70): frames and their mirror images run as ONE 2B batch inside the engine's schedule -- the
+        # stem reads the mirrored image by index, the head sum merges the mirrored maps (no ATen cat/flip, no merge pass)
         kpt = cfg.DATASET.KEYPOINT.NUM
         self.flip_pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
+        self.engine = model.engine(batch, H, W, self.device, flip_pair=self.flip_pair if do_flip else None)
+        self._model, self._generation = model, model.weights_generation      # a reload / .to() after this point makes the
+                                                                             # pipeline stale: submit() refuses to run on old weights
         self.refine = refine_weights
         self.depth = max(1, int(depth))
         self.engines = [self.engine] + [self.engine.sibling() for _ in range(self.depth - 1)]
@@ -132,11 +132,7 @@ class PosePipeline:
             if time_backbone:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if self.do_flip:
-                eng.run(torch.cat([imgs, torch.flip(imgs, [-1])], 0), out=slot.out)
-                dapalib.flip_merge_(slot.hms, slot.hms_flip, self.flip_pair)
-            else:
-                eng.run(imgs, out=slot.out)
+            eng.run(imgs, out=slot.out)
             if time_backbone:
                 e1.record()
                 self.bb_events.append((e0, e1))
@@ -191,9 +187,9 @@ class PosePipeline:
                 name = tags[i] if idx == 0 else f"{extra_tags[idx - 1]}/{tags[i]}"
                 if gt_mode and self.record_mode == "generate_train":            # test.py:142-143
                     recs.extend(train_records(p2[i, :P], p3[i, :P], rz[i, :P], np.asarray(annotations[i]),
-                                              self.cfg.DATASET.ROOT_IDX))
+                                              self.cfg.DATASET.ROOT_IDX, as_lists=self.as_lists))
                 else:
                     recs.append(frame_record(p2[i, :P], p3[i, :P], rz[i, :P], name,
-                                             np.asarray(annotations[i]) if gt_mode else None))
+                                             np.asarray(annotations[i]) if gt_mode else None, as_lists=self.as_lists))
         slot.busy = False
         return recs

@@ -8,24 +8,40 @@ Two writers exist in the reference and both are kept:
 import numpy as np
 
 
-def frame_record(pred_2d, pred_3d, root_d, image_path, gt_bodys=None):
-    rec = {"pred_2d": np.asarray(pred_2d).tolist(), "pred_3d": np.asarray(pred_3d).tolist(),
-           "root_d": np.asarray(root_d).tolist(), "image_path": image_path}
+def _lists(a):
+    return np.asarray(a).tolist()
+
+
+def _arrays(a):
+    return np.array(a)                 # a private copy: the pipeline's pinned result buffers are reused
+
+
+def frame_record(pred_2d, pred_3d, root_d, image_path, gt_bodys=None, as_lists=True):
+    """as_lists=False keeps the numbers as numpy arrays (copies): the inference loop then does no per-element Python
+    work; `to_jsonable` turns such records into the reference's nested lists when the file is written."""
+    cv = _lists if as_lists else _arrays
+    rec = {"pred_2d": cv(pred_2d), "pred_3d": cv(pred_3d), "root_d": cv(root_d), "image_path": image_path}
     if gt_bodys is not None:
-        rec["gt_3d"] = gt_bodys[:, :, 4:].tolist()
-        rec["gt_2d"] = gt_bodys[:, :, :4].tolist()
+        rec["gt_3d"] = cv(gt_bodys[:, :, 4:])
+        rec["gt_2d"] = cv(gt_bodys[:, :, :4])
     else:
         rec["gt_3d"], rec["gt_2d"] = [], []
     return rec
 
 
-def train_records(pred_2d, pred_3d, root_d, gt_bodys, root_n=2):
+def train_records(pred_2d, pred_3d, root_d, gt_bodys, root_n=2, as_lists=True):
+    cv = _lists if as_lists else _arrays
     out = []
     for i, body in enumerate(pred_3d):
         if body[root_n][3] != 0:
-            out.append({"pred_3d": np.asarray(body).tolist(), "pred_2d": np.asarray(pred_2d[i]).tolist(),
-                        "gt_3d": gt_bodys[i][:, 4:7].tolist(), "root_d": float(root_d[i])})
+            out.append({"pred_3d": cv(body), "pred_2d": cv(pred_2d[i]), "gt_3d": cv(gt_bodys[i][:, 4:7]),
+                        "root_d": float(root_d[i])})
     return out
+
+
+def to_jsonable(records):
+    """Records built with as_lists=False -> the nested-list form json.dump writes (same numbers: ndarray.tolist())."""
+    return [{k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in r.items()} for r in records]
 
 
 def kept_annotations(annotation, root_idx=2):

@@ -333,6 +333,32 @@ def test_small_schedule_with_specialised_kernels(golden_dir, small, monkeypatch,
         assert np.abs(a.numpy() - z[k]).max() < 1e-2 * np.abs(z[k]).max(), k
 
 
+@pytest.mark.parametrize("precision", ["f16", "x3"])
+def test_flip_tta_inside_the_schedule_is_bit_exact(small, precision):
+    """Engine built with flip_pair: the stem reads the mirrored image by index, the head sum merges the mirrored maps
+    (test.py:55-70).  Must equal, bit for bit, two separate forwards (frames, torch.flip(frames)) merged by the reference's
+    channel loop; det_d / root_d are those of the un-mirrored pass."""
+    from exps.stage3_root2.config import cfg
+    from exps.stage3_root2.test_util import merge_flip
+    net, sd = small
+    net = net.to(DEV)
+    net.precision = precision
+    kpt = cfg.DATASET.KEYPOINT.NUM
+    pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
+    x = torch.randn(3, 3, 64, 96, generator=torch.Generator().manual_seed(21)).to(DEV)
+    h, d, rd = net(x)
+    hf, _, _ = net(torch.flip(x, [-1]))
+    want = merge_flip(h.clone(), hf, cfg)
+    eng = net.engine(3, 64, 96, torch.device(DEV), flip_pair=pair)
+    assert eng.graph.B == 6 and eng.B == 3
+    got_h, got_d, got_rd = eng.run(x)
+    torch.cuda.synchronize()
+    assert got_h.shape == want.shape and torch.equal(got_h, want)
+    assert torch.equal(got_d, d) and torch.equal(got_rd, rd)
+    assert (want - h).abs().max().item() > 1e-3            # the merge did something
+    net.precision = "f16"
+
+
 def test_smap_module_forward_and_reload(golden_dir, small):
     from model.smap import SMAP
     net, sd = small
