@@ -46,17 +46,21 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 //              hi*hi + hi*lo + lo*hi (the dropped lo*lo term is 2^-24 relative).  A K tile stages four LDS images
 //              (A hi, A lo, W hi, W lo); the epilogue re-splits the fp32 result.  3x the MFMA work and 2x the bytes of
 //              the fp16 mode, ~1e-6 relative error instead of ~1e-3: the mode whose output meets the reference's fp32.
+// WM x WN = 4 or 8 waves.  Eight waves (two per SIMD from ONE workgroup) are for the low-resolution layers whose grids
+// do not fill the chip: a lone wave issues an MFMA only every ~80 cycles, two waves per SIMD reach the pipe rate
+// (tools/ubench/mfma_clock.hip), and with <= 256 workgroups of 4 waves there is no second wave on the SIMD.
 template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a)
 {
     constexpr int NPL = X3 ? 2 : 1;                    // fp16 planes per operand
-    static_assert(WM * WN == 4, "4 waves");
+    constexpr int NW = WM * WN, NT = NW * 64;          // waves, threads
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(STAGES >= 2 && STAGES <= 4, "2..4 LDS stages");
     static_assert(BK == 32 || BK == 64, "BK = halves per K chunk");
     constexpr int ROWB = BK * 2;                       // bytes per LDS row
     constexpr int SPR = ROWB / 16;                     // 16-byte slots per row (8 / 4)
     constexpr int RPW = 64 / SPR;                      // rows one wave-wide LDS-DMA instruction covers (8 / 16)
-    constexpr int RPR = 4 * RPW;                       // rows per round of the 4 waves (32 / 64)
+    constexpr int RPR = NW * RPW;                      // rows per round of all waves (32 / 64 with 4 waves)
     static_assert(BM % RPR == 0 && BN % RPR == 0, "tile must be a multiple of the DMA round");
     constexpr int LA = BM / RPR, LB = BN / RPR;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
@@ -199,13 +203,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     //      requested before the K loop so that its HBM latency hides under the whole main loop
     //      (a pass-by-pass load in the epilogue exposes one full memory round trip per pass).
     constexpr int CG = BN / 8;                    // channel groups per row
-    constexpr int PASSES = BM * CG / 256;
-    static_assert(BM * CG % 256 == 0, "tile/thread mismatch");
+    constexpr int PASSES = BM * CG / NT;
+    static_assert(BM * CG % NT == 0, "tile/thread mismatch");
     half8 rres[PASSES][NPL];
     if (a.res) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int idx = p * 256 + tid;
+            const int idx = p * NT + tid;
             const int row = idx / CG, cg = idx - row * CG;
             const int m = m0 + row, n = n0 + cg * 8;
             const long long dense = (m < a.M && n < a.Cout8) ? (long long)m * (NPL * a.Cout8) + n : 0;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     };
     auto load_pass = [&](int p) -> Extra {
         Extra x;
-        const int idx = p * 256 + tid;
+        const int idx = p * NT + tid;
         x.row = idx / CG;
         x.cg = idx - x.row * CG;
         const int m = m0 + x.row, n = n0 + x.cg * 8;
@@ -419,9 +423,9 @@ hipError_t launch(const ConvArgs& a, hipStream_t st)
 {
     if (a.x3) return hipErrorInvalidValue;                 // split-precision ops use the tiles of launch_x3 only
     if (a.up || a.add1 || a.add2)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, true, false>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, true, false>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, false>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, false>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
     return hipGetLastError();
 }
 
@@ -430,9 +434,9 @@ template <int BM, int BN, int WM, int WN, int STAGES, int BK>
 hipError_t launch_x3(const ConvArgs& a, hipStream_t st)
 {
     if (a.up || a.add1 || a.add2)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, true, true>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, true, true>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, true>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, true>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
     return hipGetLastError();
 }
 
@@ -448,6 +452,9 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
         case 21: case 25: *bm = 128; *bn = 64; return 0;
         case 22: case 26: *bm = 64; *bn = 64; return 0;
         case 23: case 27: *bm = 64; *bn = 128; return 0;
+        case 50: case 51: case 52: *bm = 128; *bn = 128; return 0;   // 50..54: eight-wave workgroups
+        case 53: *bm = 256; *bn = 128; return 0;
+        case 54: *bm = 128; *bn = 256; return 0;
         case 0: case 5: *bm = 128; *bn = 128; return 0;
         case 1: case 6: *bm = 128; *bn = 64; return 0;
         case 2: case 7: *bm = 64; *bn = 64; return 0;
@@ -460,7 +467,7 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
 // tiles that have a split-precision instance (plan.hip::validate asks)
 int smap_conv_tile_has_x3(int tile)
 {
-    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27);
+    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 50 && tile <= 54);
 }
 
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
@@ -480,6 +487,11 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
             case 25: return launch_x3<128, 64, 2, 2, 3, 32>(a, st);   // 72 KiB, 2 tiles in flight
             case 26: return launch_x3<64, 64, 2, 2, 4, 32>(a, st);    // 64 KiB, 3 tiles in flight
             case 27: return launch_x3<64, 128, 2, 2, 3, 32>(a, st);   // 72 KiB
+            case 50: return launch_x3<128, 128, 2, 4, 2, 32>(a, st);  // 64 KiB, 8 waves of 64x32
+            case 51: return launch_x3<128, 128, 4, 2, 2, 32>(a, st);  // 64 KiB, 8 waves of 32x64
+            case 52: return launch_x3<128, 128, 2, 4, 2, 64>(a, st);  // 128 KiB, BK = 64
+            case 53: return launch_x3<256, 128, 4, 2, 2, 32>(a, st);  // 96 KiB, 8 waves of 64x64
+            case 54: return launch_x3<128, 256, 2, 4, 2, 32>(a, st);  // 96 KiB, 8 waves of 64x64
             default: return hipErrorInvalidValue;
         }
     }
@@ -503,6 +515,11 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
         case 7: return launch<64, 64, 2, 2, 4>(a, st);      //  64 KiB, 2 blocks/CU
         case 8: return launch<128, 32, 4, 1, 3>(a, st);     //  60 KiB, 2 blocks/CU
         case 9: return launch<64, 128, 2, 2, 3>(a, st);     //  72 KiB, 2 blocks/CU
+        case 50: return launch<128, 128, 2, 4, 2, 32>(a, st);   // eight-wave workgroups (fp16: 64 KiB = the fp32 epilogue tile)
+        case 51: return launch<128, 128, 4, 2, 2, 32>(a, st);
+        case 52: return launch<128, 128, 2, 4, 2, 64>(a, st);
+        case 53: return launch<256, 128, 4, 2, 2, 32>(a, st);   // 128 KiB (fp32 epilogue tile)
+        case 54: return launch<128, 256, 2, 4, 2, 32>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -40,7 +40,9 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          # 30..39: csrc/conv3.hip halo-tiled 3x3 stride-1 (BM = 128 output pixels as an 8x16 / 4x32 patch)
          30: (128, 64), 31: (128, 128), 32: (128, 64), 33: (128, 128),
          34: (128, 64), 35: (128, 128), 36: (128, 64), 37: (128, 128),     # 34..37: deeper weight pipeline
-         38: (128, 32), 39: (128, 32)}                                     # Cout <= 32 heads
+         38: (128, 32), 39: (128, 32),                                     # Cout <= 32 heads
+         # 50..54: csrc/conv.hip with EIGHT waves per workgroup (two per SIMD from one workgroup: the low-resolution layers)
+         50: (128, 128), 51: (128, 128), 52: (128, 128), 53: (256, 128), 54: (128, 256)}
 # (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
 #  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)
 
@@ -59,7 +61,7 @@ PLANES = (64, 128, 256, 512)
 ALIGN = 256
 ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
 PRECISIONS = ("f16", "x3")
-X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
+X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
 
 
 def split_f16(w, scaled=True):

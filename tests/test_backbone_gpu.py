@@ -142,6 +142,13 @@ CASES = [
     (2, 16, 24, 256, 64, 3, 1, 25, True, False, False),
     (1, 16, 24, 256, 43, 3, 1, 26, False, False, False),
     (1, 32, 52, 256, 512, 1, 2, 27, False, True, False),
+    # eight-wave workgroups (tile ids 50..54)
+    (3, 10, 14, 192, 320, 3, 1, 50, True, True, True),
+    (2, 16, 24, 256, 256, 1, 1, 51, True, True, False),
+    (2, 16, 24, 128, 128, 3, 2, 52, True, False, False),
+    (1, 32, 52, 256, 512, 1, 2, 53, False, True, True),
+    (2, 16, 24, 64, 256, 1, 1, 54, True, False, False),
+    (1, 16, 26, 64, 320, 3, 1, 54, True, True, True),
     # halo-tiled 3x3 stride-1 kernel (conv3.hip), tile ids 30..33: ragged pixel tiles in both directions
     (2, 16, 24, 64, 64, 3, 1, 30, True, False, False),
     (3, 10, 14, 192, 320, 3, 1, 31, True, False, False),
@@ -188,6 +195,12 @@ X3_CASES = [
     (2, 8, 12, 512, 256, 1, 1, 4, True, False, True),
     (2, 16, 24, 64, 256, 1, 1, 24, False, True, False),      # K shorter than the pipeline depth
     (1, 16, 26, 64, 64, 3, 1, 26, True, False, False),
+    # eight-wave workgroups
+    (3, 10, 14, 192, 320, 3, 1, 50, True, True, True),
+    (2, 16, 24, 256, 256, 1, 1, 51, True, True, False),
+    (2, 16, 24, 128, 128, 3, 2, 52, True, False, False),
+    (1, 32, 52, 256, 512, 1, 2, 53, False, True, True),
+    (1, 16, 26, 64, 320, 3, 1, 54, True, True, True),
 ]
 
 
