@@ -467,12 +467,13 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
 // tiles that have a split-precision instance (plan.hip::validate asks)
 int smap_conv_tile_has_x3(int tile)
 {
-    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 50 && tile <= 54);
+    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 54);
 }
 
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
 {
     if (a.x3) {
+        if (tile >= 30 && tile < 40) return smap_launch_conv3(a, tile, st);     // halo-tiled 3x3, split-precision instance
         switch (tile) {                                     // LDS = max(STAGES * 2 * (BM + BN) * row bytes, fp32 epilogue tile)
             case 0: return launch_x3<128, 128, 2, 2, 2, 64>(a, st);   // 128 KiB: BK = 64, half the barriers per K
             case 1: return launch_x3<128, 64, 2, 2, 2, 64>(a, st);    // 96 KiB

@@ -16,6 +16,11 @@
 //   pipeline  : iteration = (cc, tap); NB-1 weight tiles and, from tap 0 of a chunk, the next patch are
 //               in flight while the current tap is multiplied (counted vmcnt + raw s_barrier)
 //   epilogue  : fp32 LDS tile -> bias, ReLU -> 16-byte NHWC stores (fp16, or fp32 for the heads)
+//
+// X3 (smap_op.precision = 1, see conv.hip): a chunk is 32 channels and an LDS row holds [hi(32) | lo(32)] of them --
+// the same 128 bytes, the same swizzle, the same LDS footprint; the eight 16-byte slots of a row are logical granules
+// 0..3 of the hi plane and 0..3 of the lo plane, fetched from the two planes of the pixel / the two weight matrices.
+// A tap iteration then covers 32 channels with 2 K steps of three MFMAs (hi*hi + hi*lo + lo*hi).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "smap_hip.h"
@@ -46,9 +51,12 @@ __device__ __forceinline__ void wait_vm(int n)
 
 // ONE = the layer has a single 64-channel chunk (Cin = 64: the layer1 3x3s): no second patch buffer, which takes the
 // workgroup from 80 to 52 KB of LDS (three per CU instead of two; residency is what these kernels are short of).
-template <int BN, int TW, int NB, bool ONE>
+template <int BN, int TW, int NB, bool ONE, bool X3>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int tiles_x, int tiles_y)
 {
+    constexpr int CH = X3 ? 32 : 64;                            // channels per chunk
+    constexpr int NPL = X3 ? 2 : 1;
+    static_assert(!(ONE && X3), "split precision: Cin = 64 is two chunks");
     constexpr int BM = 128, TH = BM / TW, PW = TW + 2, PH = TH + 2;
     constexpr int PROWS = ((PH * PW + 31) / 32) * 32;          // patch rows rounded to a DMA round (32 rows)
     constexpr int LA = PROWS / 32, LB = BN / 32;
@@ -85,13 +93,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     // ---- staging offsets (uniform base + 32-bit lane offset; 0 = zero page of the arena)
     const int lrow = lane >> 3, lslot = lane & 7;
     const int srow = wave * 8 + lrow;
-    const int gch = lslot ^ ((srow >> 1) & 7);                  // (prow>>1)&7 == (srow>>1)&7: rounds are 32 rows
+    const int gl = lslot ^ ((srow >> 1) & 7);                   // (prow>>1)&7 == (srow>>1)&7: rounds are 32 rows
+    const int gch = X3 ? (gl & 3) : gl;                         // channel granule inside the chunk ...
+    const int gpl = X3 ? (gl >> 2) : 0;                         // ... of plane 0 (hi) / 1 (lo)
     const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
     const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
 
     unsigned b_off[LB];
 #pragma unroll
-    for (int i = 0; i < LB; ++i) b_off[i] = (unsigned)(((n0 + i * 32 + srow) * a.K + gch * 8) * 2);
+    for (int i = 0; i < LB; ++i)
+        b_off[i] = (unsigned)(((n0 + i * 32 + srow) * a.K + gch * 8) * 2 + (X3 ? (long long)gpl * a.w_lo : 0LL));
     auto issue_b = [&](int buf, unsigned boff) {
         char* sB = smem + NA * A_BYTES + buf * B_BYTES;
         const char* gB = wt + boff;
@@ -110,13 +121,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
         a_off[i] = 0;
         if (prow < PH * PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
-            const long long e = ((long long)(b * a.H + iy) * a.W + ix) * a.in_stride_c + a.in_c_off + gch * 8;
+            const long long e = ((long long)(b * a.H + iy) * a.W + ix) * a.in_stride_c + a.in_c_off + gch * 8 +
+                                (X3 ? gpl * a.in_lo : 0);
             a_off[i] = (unsigned)(a.in_off + e * 2);
         }
     }
     auto issue_a = [&](int buf, int cc) {
         char* sA = smem + buf * A_BYTES;
-        const char* gA = arena + (unsigned)(cc * ROWB);         // invalid pixels: zero page + cc*128
+        const char* gA = arena + (unsigned)(cc * CH * 2);       // invalid pixels: zero page + chunk offset
         if (SMAP_ABLATE & 1) return;
 #pragma unroll
         for (int i = 0; i < LA; ++i)
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     //      cc & 1).  Weight tiles it+1 .. it+D-1 and, during taps 1..D, the next patch stay in flight across the
     //      barrier (counted vmcnt: loads retire in issue order).  Issue order per iteration: B(it+D), then at
     //      tap 0 A(cc+1) -- so A(cc+1) is younger than B(it) exactly while tap <= D.
-    const int cchunks = a.Cin / 64;
+    const int cchunks = a.Cin / CH;
     const int n_iter = cchunks * 9;
 #pragma unroll
     for (int d = 1; d < D; ++d) issue_b(d, (unsigned)(d * a.Cin * 2));      // taps 1..D-1 of chunk 0 (D <= 9)
@@ -169,32 +181,39 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
             {
                 const int nt = tap + D;                                     // tap index of iteration it+D
                 const int ncc = cc + nt / 9, ntap = nt % 9;
-                if (ncc < cchunks) issue_b((it + D) % NB, (unsigned)((ntap * a.Cin + ncc * 64) * 2));
+                if (ncc < cchunks) issue_b((it + D) % NB, (unsigned)((ntap * a.Cin + ncc * CH) * 2));
                 if (tap == 0 && !last) issue_a((cc + 1) & 1, cc + 1);
             }
             const char* sB = smem + NA * A_BYTES + (it % NB) * B_BYTES;
             const int shift = (tap / 3) * PW + (tap % 3);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < CH / 16; ++kk) {
                 const int g = kk * 2 + lhi;
-                half8 af[MI], bf[NI];
+                half8 af[NPL][MI], bf[NPL][NI];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int prow = prow0[mi] + shift;
-                    if (SMAP_ABLATE & 16) { for (int e = 0; e < 8; ++e) af[mi][e] = (_Float16)(float)(lane + kk); continue; }
-                    af[mi] = *reinterpret_cast<const half8*>(sA + prow * ROWB + ((g ^ ((prow >> 1) & 7)) << 4));
-                }
+                for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    if (SMAP_ABLATE & 16) { for (int e = 0; e < 8; ++e) bf[ni][e] = (_Float16)(float)(tap + kk); continue; }
-                    bf[ni] = *reinterpret_cast<const half8*>(sB + (b_row0 + ni * 32) * ROWB + ((g ^ bswz) << 4));
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int prow = prow0[mi] + shift;
+                        if (SMAP_ABLATE & 16) { for (int e = 0; e < 8; ++e) af[pl][mi][e] = (_Float16)(float)(lane + kk); continue; }
+                        af[pl][mi] = *reinterpret_cast<const half8*>(sA + prow * ROWB + (((g + 4 * pl) ^ ((prow >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        if (SMAP_ABLATE & 16) { for (int e = 0; e < 8; ++e) bf[pl][ni][e] = (_Float16)(float)(tap + kk); continue; }
+                        bf[pl][ni] = *reinterpret_cast<const half8*>(sB + (b_row0 + ni * 32) * ROWB + (((g + 4 * pl) ^ bswz) << 4));
+                    }
                 }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
-                        if (SMAP_ABLATE & 2) { acc[mi][ni][kk] += (float)af[mi][0] + (float)bf[ni][1]; continue; }
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                        if (SMAP_ABLATE & 2) { acc[mi][ni][kk] += (float)af[0][mi][0] + (float)bf[0][ni][1]; continue; }
+                        if (X3) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[NPL - 1][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][mi], bf[NPL - 1][ni], acc[mi][ni], 0, 0, 0);
+                        }
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
                     }
             }
         }
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * (MI * 32) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                Cs[row * BN + col] = acc[mi][ni][r] + bias;
+                Cs[row * BN + col] = X3 ? acc[mi][ni][r] * a.acc_scale + bias : acc[mi][ni][r] + bias;
             }
     }
     __syncthreads();
@@ -246,6 +265,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
             *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + o) = h;
+            if (X3) {
+                half8 l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) l[e] = (_Float16)(v[e] - (float)h[e]);
+                *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + o + a.out_lo) = l;
+            }
         }
     }
     SMAP_TL_END(a)
@@ -257,11 +282,14 @@ hipError_t launch3(const ConvArgs& a, hipStream_t st)
     constexpr int TH = 128 / TW;
     const int B = a.M / (a.Ho * a.Wo);
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
-    if (a.Cin == 64)
-        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB, true>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a,
+    if (a.x3)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB, false, true>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a,
+                           tiles_x, tiles_y);
+    else if (a.Cin == 64)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB, true, false>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a,
                            tiles_x, tiles_y);
     else
-        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB, false>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a,
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB, false, false>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a,
                            tiles_x, tiles_y);
     return hipGetLastError();
 }

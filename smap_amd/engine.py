@@ -264,12 +264,14 @@ class Graph:
             if x3t and cout > 32 and not (cout <= 64 and TILES[int(x3t)][1] > 64):
                 tile = int(x3t)
         plain3 = ksize == 3 and stride == 1 and res is None and add1 is None and add2 is None and up is None
-        if self.x3:
+        if 30 <= tile < 40 and not plain3 and self.x3:
+            tile = pick_tile_x3(M, cout)
+        elif self.x3:
             pass
         elif 30 <= tile < 40 and not plain3:                # the halo-tiled kernel has no fused epilogues (table keyed by shape only)
             tile = pick_tile_heuristic(M, cout)
         halo = os.environ.get("SMAP_HALO3", "")     # A/B hook: "16" / "32" = pixel-tile width, optional ":64" / ":128" = BN
-        if not self.x3 and halo and plain3 and cout > 32:
+        if halo and plain3 and cout > 32:
             tw, _, hbn = halo.partition(":")
             hbn = int(hbn) if hbn else min(TILES[tile][1], 128 if cout > 64 else 64)
             tile = {(16, 64): 30, (16, 128): 31, (32, 64): 32, (32, 128): 33}[(int(tw), max(hbn, 64))]

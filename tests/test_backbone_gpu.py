@@ -201,6 +201,17 @@ X3_CASES = [
     (2, 16, 24, 128, 128, 3, 2, 52, True, False, False),
     (1, 32, 52, 256, 512, 1, 2, 53, False, True, True),
     (1, 16, 26, 64, 320, 3, 1, 54, True, True, True),
+    # halo-tiled 3x3 (conv3.hip) in split precision: 32-channel chunks, rows = [hi32 | lo32]
+    (2, 16, 24, 64, 64, 3, 1, 30, True, False, False),
+    (3, 10, 14, 192, 320, 3, 1, 31, True, False, False),
+    (1, 16, 26, 128, 64, 3, 1, 32, True, False, False),
+    (2, 13, 52, 256, 256, 3, 1, 33, False, False, False),
+    (2, 16, 24, 128, 128, 3, 1, 34, True, False, False),
+    (1, 12, 20, 192, 256, 3, 1, 35, True, False, False),
+    (1, 16, 36, 64, 64, 3, 1, 36, True, False, False),
+    (1, 16, 36, 128, 256, 3, 1, 37, False, False, False),
+    (1, 16, 24, 256, 14, 3, 1, 38, False, False, False),
+    (2, 10, 40, 128, 1, 3, 1, 39, False, False, False),
 ]
 
 
@@ -229,6 +240,14 @@ def test_split_precision_fp32_out_and_channel_slice():
     assert (got[..., :cout] - ref).abs().max().item() < 3e-6 * ref.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("tile", [30, 36, 38])
+def test_halo_conv_split_precision_fp32_out_and_channel_slice(tile):
+    cout = 14 if tile == 38 else 43
+    got, ref, cout = _run_single_conv(1, 16, 24, 256, cout, 3, 1, tile, False, False, False, out_fp32=True,
+                                      in_stride=768, in_off=512, seed=7, x3=True)
+    assert (got[..., :cout] - ref).abs().max().item() < 3e-6 * ref.abs().max().item() + 1e-6
+
+
 def test_single_conv_fp32_out_and_channel_slice():
     got, ref, cout = _run_single_conv(1, 16, 24, 256, 43, 3, 1, 1, False, False, False, out_fp32=True,
                                       in_stride=768, in_off=256, seed=5)
@@ -254,7 +273,9 @@ def test_halo_conv_rejects_fused_epilogues():
     with pytest.raises(SmapError):
         _run_single_conv(1, 16, 24, 64, 256, 1, 1, 12, True, False, False)
     with pytest.raises(SmapError):                     # split precision only on the tiles that have an X3 instance
-        _run_single_conv(1, 16, 24, 64, 64, 3, 1, 30, True, False, False, x3=True)
+        _run_single_conv(1, 16, 24, 64, 64, 3, 1, 5, True, False, False, x3=True)
+    with pytest.raises(SmapError):                     # halo kernel in split precision: still plain 3x3 only
+        _run_single_conv(1, 16, 24, 64, 64, 3, 1, 30, True, True, False, x3=True)
 
 
 @pytest.fixture(scope="module")
@@ -310,7 +331,7 @@ def test_small_schedule_split_precision_every_tensor(golden_dir, small, monkeypa
     x = torch.from_numpy(z["x"])
     eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision="x3")
     from smap_amd.engine import X3_TILES
-    assert all(op.p["tile"] in X3_TILES + (3,) for op in eng.graph.ops if op.kind == 0)
+    assert all(op.p["tile"] in X3_TILES + (3,) + tuple(range(30, 40)) for op in eng.graph.ops if op.kind == 0)
     outs = [o.cpu() for o in eng.run(x.to(DEV))]
     torch.cuda.synchronize()
     g = Graph(sd, 2, 64, 96, keep_ref=True)
@@ -325,6 +346,21 @@ def test_small_schedule_split_precision_every_tensor(golden_dir, small, monkeypa
         worst.append((e / (want.abs().max().item() + 1e-6), t.name))
     worst.sort(reverse=True)
     assert worst[0][0] < 2e-5, worst[:5]
+    for a, k in zip(outs, ("hms", "det_d", "root_d")):
+        assert np.abs(a.numpy() - z[k]).max() < 2e-5 * np.abs(z[k]).max(), k
+
+
+@pytest.mark.parametrize("env", [{"SMAP_HALO3": "16"}, {"SMAP_HALO3": "32", "SMAP_HALO3_DEEP": "1"}], ids=["halo16", "halo32deep"])
+def test_small_schedule_split_precision_with_halo_kernel(golden_dir, small, monkeypatch, env):
+    """precision "x3" with every plain 3x3 conv on the halo-tiled kernel's split-precision instances."""
+    from smap_amd.engine import BackboneEngine
+    _, sd = small
+    z = np.load(f"{golden_dir}/backbone_small.npz")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision="x3")
+    assert any(30 <= op.p["tile"] < 40 for op in eng.graph.ops if op.kind == 0)
+    outs = [o.cpu() for o in eng.run(torch.from_numpy(z["x"]).to(DEV))]
     for a, k in zip(outs, ("hms", "det_d", "root_d")):
         assert np.abs(a.numpy() - z[k]).max() < 2e-5 * np.abs(z[k]).max(), k
 

@@ -73,6 +73,8 @@ def main():
         if x3:
             from smap_amd.engine import X3_TILES
             cands = [3] if Cout <= 32 else [t for t in X3_TILES if not (Cout <= 64 and TILES[t][1] > 64)]
+            if halo_ok:      # halo-tiled 3x3 kernel has split-precision instances too
+                cands += [38, 39] if Cout <= 32 else [t for t in range(30, 38) if not (Cout <= 64 and TILES[t][1] > 64)]
         if args.halo:
             cands = [old[skey]] + [t for t in cands if t >= 30] + ([40, 41] if ws_ok else [])
         res = {}
