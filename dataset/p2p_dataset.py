@@ -1,6 +1,10 @@
 """Reader of the RefineNet training pairs that `test.py -t generate_train` writes (reference:
 dataset/p2p_dataset.py:9-40) -- the consumer side of that file format.
 
+TOOLING, not part of the inference hot path (SURVEY.md section 2 lists RefineNet training as out of scope): it exists so that the
+`generate_train` record format (smap_amd/records.py::train_records) has a reader that pins it (tests/golden/p2p.npz); nothing
+under smap_amd/ or exps/ imports it.
+
 Item i: (inp [75] fp32, gt [45] fp32).  `inp` is 15 x (2D offset from the root, 3D offset from the root) with the
 root row holding the absolute root (2D position, 3D position); joints whose predicted score is not positive
 stay zero.  `gt` is the ground-truth 3D offset from the root for every joint (root row zero)."""

@@ -1,0 +1,161 @@
+"""CPU tests of the host logic added in round 2: split-precision weight packing and schedule emission, the in-schedule
+flip-TTA op list, tile tables, lazy result records, the end-to-end parity checker on synthetic inputs."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_cfg
+from recipe import recipe_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def small_sd():
+    from smap_amd.model.smap import SMAP
+    torch.manual_seed(0)
+    return recipe_state_dict(SMAP(make_cfg((16, 24))).state_dict())
+
+
+def test_split_f16_reconstructs_to_22_bits():
+    from smap_amd.engine import split_f16
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(64, 576, generator=g, dtype=torch.float64) * 0.03
+    w[0, 0], w[0, 1] = 0.0, 1e-7                                   # vanishing weights survive too
+    hi, lo, inv = split_f16(w)
+    assert hi.dtype == lo.dtype == torch.float16 and torch.isfinite(hi).all() and torch.isfinite(lo).all()
+    s = 1.0 / inv
+    assert 2 ** 13 <= w.abs().max().item() * s < 2 ** 14 and float(np.log2(s)).is_integer()
+    back = (hi.double() + lo.double()) * inv
+    assert ((back - w).abs() <= w.abs() * 2.0 ** -21 + 2.0 ** -24 * inv).all()
+    # plain fp16 is three orders of magnitude coarser on the same data
+    assert (w.half().double() - w).abs().max() > 100 * (back - w).abs().max()
+    z = split_f16(torch.zeros(4, 8, dtype=torch.float64))
+    assert z[2] == 1.0 and not z[0].any() and not z[1].any()
+
+
+def test_x3_graph_emits_split_strides_and_weights(small_sd):
+    from smap_amd.engine import Graph, OP_CONV, OP_HEADSUM, OP_MAXPOOL, OP_STEM, X3_TILES, ZERO_PAGE
+    g16 = Graph(small_sd, 2, 64, 96)
+    g = Graph(small_sd, 2, 64, 96, precision="x3")
+    g.allocate()
+    ops = g.emit()
+    assert len(g.ops) == len(g16.ops) and g.flops == g16.flops
+    assert g.weight_blob().numel() > 1.9 * g16.weight_blob().numel()
+    for op, o in zip(g.ops, ops):
+        assert o.precision == 1
+        if op.kind == OP_CONV:
+            x, y = op.inp, op.out
+            assert x.planes == 2 and o.in_stride_c == 2 * x.C and o.in_c_off + o.Cin <= x.C
+            assert o.tile in X3_TILES + (3,) + tuple(range(30, 40)) and o.acc_scale > 0
+            assert (y.planes, o.out_stride_c) == ((1, y.C) if o.out_fp32 else (2, 2 * y.C))
+            assert o.in_off >= ZERO_PAGE and o.Cin * 2 + o.in_stride_c + 16 <= ZERO_PAGE
+            for t in (op.res, op.add1, op.add2):
+                assert t is None or t.planes == 2
+        elif op.kind == OP_STEM:
+            assert o.acc_scale > 0 and op.out.planes == 2
+        elif op.kind == OP_MAXPOOL:
+            assert op.inp.planes == op.out.planes == 2
+        elif op.kind == OP_HEADSUM:
+            assert all(t.esize == 4 and t.planes == 1 for t in op.aux)
+    # arena: split tensors take twice the bytes
+    g16.allocate()
+    assert g.arena_bytes > 1.8 * g16.arena_bytes
+
+
+def test_flip_graph_runs_two_B_frames_and_merges_in_the_head_sum(small_sd):
+    from smap_amd.engine import Graph, OP_CONV, OP_HEADSUM, OP_STEM
+    pair = list(range(43))[::-1]
+    g = Graph(small_sd, 3, 64, 96, flip_pair=pair)
+    g.allocate()
+    ops = g.emit()
+    assert g.B == 6 and g.frames == 3 and g.out_bytes == 3 * 58 * 16 * 24 * 4
+    kinds = [op.kind for op in g.ops]
+    stem = ops[kinds.index(OP_STEM)]
+    assert stem.B == 6 and stem.flip_from == 3
+    heads = [o for o in ops if o.kind == OP_HEADSUM]
+    assert [h.B for h in heads] == [3, 3, 3] and [h.flip_from for h in heads] == [3, 0, 0]
+    assert heads[0].in_c_off == 15 and heads[0].w_off >= 0
+    blob = g.weight_blob()
+    tab = blob[heads[0].w_off:heads[0].w_off + 43 * 4].view(torch.int32).tolist()
+    assert tab == pair
+    convs = {op.out.name: o for op, o in zip(g.ops, ops) if op.kind == OP_CONV}
+    depth = [n for n in convs if n.endswith(".res_d") or n.endswith(".res_rd")]
+    assert len(depth) == 2 and all(convs[n].B == 3 for n in depth)          # mirrored half of the depth heads: never read
+    assert all(o.B == 6 for n, o in convs.items() if n not in depth)
+    with pytest.raises(AssertionError):
+        Graph(small_sd, 3, 64, 96, flip_pair=[0, 1, 2])
+
+
+def test_tile_tables_name_existing_tiles():
+    from smap_amd.engine import TILES, X3_TILES
+    t16 = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table.json")))
+    tx3 = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table_x3.json")))
+    assert t16 and all(int(v) in TILES for v in t16.values())
+    assert tx3 and all(int(v) in X3_TILES + (3,) + tuple(range(30, 40)) for v in tx3.values())
+    for key, v in tx3.items():
+        B, H, W, cin, cout, k, s = map(int, key.split(","))
+        assert B == 8 and (int(v) < 30 or int(v) >= 40 or (k == 3 and s == 1))       # halo tiles: plain 3x3 stride 1 only
+        assert cout > 32 or int(v) in (3, 38, 39)
+
+
+def test_lazy_records_equal_eager_records():
+    from smap_amd.records import frame_record, to_jsonable, train_records
+    rng = np.random.default_rng(0)
+    p2, p3, rz = rng.normal(size=(3, 15, 4)).astype(np.float32), rng.normal(size=(3, 15, 4)), rng.normal(size=3)
+    gt = rng.normal(size=(3, 15, 11))
+    for g in (None, gt):
+        eager = frame_record(p2, p3, rz, "a.jpg", g)
+        lazy = frame_record(p2, p3, rz, "a.jpg", g, as_lists=False)
+        p2_before = p2.copy()
+        assert isinstance(lazy["pred_2d"], np.ndarray) and lazy["pred_2d"] is not p2
+        assert to_jsonable([lazy]) == [eager] and json.dumps(to_jsonable([lazy])) == json.dumps([eager])
+        assert np.array_equal(p2, p2_before)
+    assert to_jsonable(train_records(p2, p3, rz, gt, as_lists=False)) == train_records(p2, p3, rz, gt)
+
+
+def test_parity_compare_counts_what_it_says():
+    from benchkit import parity
+
+    def frame(shift=0.0, drop_person=False, z_err=0.0):
+        peaks = np.zeros((15, 128, 3), np.float32)
+        for c in range(15):
+            peaks[c, 0, 0] = 4
+            peaks[c, 1:5, :2] = np.array([[10, 10], [50, 20], [90, 60], [150, 100]]) + c + shift
+            peaks[c, 1:5, 2] = 0.9
+        bodys = np.zeros((2, 15, 4), np.float32)
+        bodys[:, :, :2] = np.arange(60).reshape(2, 15, 2) + shift
+        bodys[:, :, 3] = 1.0
+        p3 = np.zeros((2, 15, 4))
+        p3[:, :, :3] = np.arange(90).reshape(2, 15, 3) + z_err
+        p3[:, :, 3] = 1.0
+        n = 1 if drop_person else 2
+        maps = {k: np.ones((2, 4, 4), np.float32) for k in ("hms", "det_d", "root_d")}
+        return dict(peaks=peaks, bodys=bodys[:n], p2=bodys[:n] * 4, p3=p3[:n], rz=np.array([300.0, 310.0])[:n] + z_err, **maps)
+
+    same = parity.compare([frame()], [frame()])
+    assert same["peak_match"] == same["person_match"] == same["limb_match"] == 1.0 and same["max_joint_err_cm"] == 0.0
+    assert same["peaks_ref"] == 60 and same["persons_ref"] == 2 and same["joints_compared"] == 30
+    sub = parity.compare([frame(shift=0.2, z_err=0.05)], [frame()])           # sub-pixel shift: still the same peaks
+    assert sub["peak_match"] == 1.0 and sub["limb_match"] == 1.0
+    assert abs(sub["max_joint_err_cm"] - 0.05 * 3 ** 0.5) < 1e-9 and abs(sub["root_z_max_err_cm"] - 0.05) < 1e-9
+    moved = parity.compare([frame(shift=1.0)], [frame()])                     # one pixel away: different peaks
+    assert moved["peak_match"] < 0.5 and moved["person_match"] == 0.0
+    lost = parity.compare([frame(drop_person=True)], [frame()])
+    assert lost["person_match"] == 0.5 and lost["peak_match"] == 1.0
+
+
+def test_people_weights_are_calibrated_data_not_weights():
+    from benchkit.workload import HEAD_KINDS, people_state_dict
+    cal = json.load(open(os.path.join(ROOT, "benchkit", "head_calibration.json")))
+    assert set(cal) == set(HEAD_KINDS) and all(len(cal[k]["kpt_bias"]) == 15 for k in cal)
+    from smap_amd.model.smap import SMAP
+    torch.manual_seed(0)
+    base = SMAP(make_cfg((16, 24))).state_dict()
+    a, b = recipe_state_dict(base), people_state_dict(base, "smooth")
+    changed = sorted(k for k in a if not torch.equal(a[k], b[k]))
+    assert changed == ["stage2.upsample.up4.res_conv2.bn.bias", "stage2.upsample.up4.res_conv2.bn.weight",
+                       "stage2.upsample.up4.res_rd_conv2.bn.bias", "stage2.upsample.up4.res_rd_conv2.bn.weight"]

@@ -26,10 +26,13 @@ CANDIDATES = [      # shape key -> alternative conv.hip tiles to try
 ]
 
 
+PRECISION = "f16"
+
+
 def bench(table_path, steps, warmup):
-    env = dict(os.environ, SMAP_TILE_TABLE=table_path)
+    env = dict(os.environ, **{"SMAP_TILE_TABLE_X3" if PRECISION == "x3" else "SMAP_TILE_TABLE": table_path})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup),
-                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300)
+                        "--no-cpu-baseline", "--precision", PRECISION], capture_output=True, text=True, env=env, timeout=300)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return json.loads(line[-1])["value"] if line else 0.0
 
@@ -41,11 +44,13 @@ def main():
     ap.add_argument("--gain", type=float, default=0.004)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tile_table_insitu.json"))
     ap.add_argument("--candidates", default="", help="JSON file [[shape key, [tiles...]], ...] replacing the built-in list")
+    ap.add_argument("--precision", choices=("f16", "x3"), default="f16", help="x3: search smap_amd/tile_table_x3.json")
     args = ap.parse_args()
-    global CANDIDATES
+    global CANDIDATES, PRECISION
+    PRECISION = args.precision
     if args.candidates:
         CANDIDATES = [tuple(c) for c in json.load(open(args.candidates))]
-    table = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table.json")))
+    table = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table_x3.json" if PRECISION == "x3" else "tile_table.json")))
     trial = args.out + ".trial"
     json.dump(table, open(trial, "w"))
     best = max(bench(trial, args.steps, args.warmup) for _ in range(2))
