@@ -20,8 +20,10 @@ NJ = 15
 TOL_PX = 0.5
 
 
-def reference_path(sd, imgs, cams, root_idx=2, threads=None):
-    """imgs [B,3,H,W] fp32 CPU, cams [B,9] -> list of per-frame dicts (peaks, bodys, p2, p3, rz, hms, det_d, root_d)."""
+def reference_path(sd, imgs, cams, root_idx=2, threads=None, refine=None):
+    """imgs [B,3,H,W] fp32 CPU, cams [B,9] -> list of per-frame dicts (peaks, bodys, p2, p3, rz, hms, det_d, root_d).
+    refine = (W[5] [out,in], b[5]) BN-folded RefineNet weights (numpy): p3 becomes the refined pose (BASELINE configs[4],
+    test_util.py:102-131)."""
     from oracle import oracle_lib as O
     from oracle.backbone_ref import smap_forward
     if threads:
@@ -36,18 +38,23 @@ def reference_path(sd, imgs, cams, root_idx=2, threads=None):
             h, d, r = hms.numpy(), det_d[0].numpy(), root_d[0, 0].numpy()
             bodys, peaks, _ = O.connect(h, r, root_idx, True)
             p2, p3, rz = O.lift(bodys, d, r, cams[i])
+            if refine is not None and len(bodys):
+                p3 = O.refine(p2, p3, refine[0], refine[1])
             outs.append(dict(peaks=peaks, bodys=bodys, p2=p2, p3=p3, rz=rz, hms=h, det_d=d, root_d=r))
     return outs
 
 
-def hip_path(net, imgs_dev, cams, root_idx=2):
-    """The product path through its public pieces (model.smap.SMAP -> dapalib batch entry points), per-frame numpy."""
+def hip_path(net, imgs_dev, cams, root_idx=2, refine=None):
+    """The product path through its public pieces (model.smap.SMAP -> dapalib batch entry points), per-frame numpy.
+    refine = RefineNet.folded(device) -> the refined pose replaces p3."""
     from smap_amd import dapalib
     hms, det_d, root_d = net(imgs_dev)
     hms = hms.clone()
     dapalib.scale_hms_(hms)
     bodys, counts, peaks, _ = dapalib.connect_batch(hms, root_d, root_idx, True, return_intermediate=True)
     p2, p3, rz = dapalib.lift_batch(bodys, counts, det_d, root_d, cams)
+    if refine is not None:
+        p3 = dapalib.refine_batch(p2, p3, counts, *refine)
     torch.cuda.synchronize()
     counts = counts.cpu().numpy()
     outs = []

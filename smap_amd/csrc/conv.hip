@@ -452,6 +452,7 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
         case 21: case 25: *bm = 128; *bn = 64; return 0;
         case 22: case 26: *bm = 64; *bn = 64; return 0;
         case 23: case 27: *bm = 64; *bn = 128; return 0;
+        case 55: case 56: case 57: *bm = 128; *bn = 128; return 0;   // 55..57: deep pipelines (3 K tiles in flight)
         case 50: case 51: case 52: *bm = 128; *bn = 128; return 0;   // 50..54: eight-wave workgroups
         case 53: *bm = 256; *bn = 128; return 0;
         case 54: *bm = 128; *bn = 256; return 0;
@@ -467,7 +468,7 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
 // tiles that have a split-precision instance (plan.hip::validate asks)
 int smap_conv_tile_has_x3(int tile)
 {
-    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 54);
+    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 57);
 }
 
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
@@ -493,6 +494,9 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
             case 52: return launch_x3<128, 128, 2, 4, 2, 64>(a, st);  // 128 KiB, BK = 64
             case 53: return launch_x3<256, 128, 4, 2, 2, 32>(a, st);  // 96 KiB, 8 waves of 64x64
             case 54: return launch_x3<128, 256, 2, 4, 2, 32>(a, st);  // 96 KiB, 8 waves of 64x64
+            case 55: return launch_x3<128, 128, 2, 4, 4, 32>(a, st);  // 128 KiB: 8 waves, 3 K tiles (96 KiB) in flight
+            case 56: return launch_x3<128, 128, 4, 2, 4, 32>(a, st);
+            case 57: return launch_x3<128, 128, 2, 2, 4, 32>(a, st);  // 128 KiB: 4 waves, 3 K tiles in flight
             default: return hipErrorInvalidValue;
         }
     }
@@ -521,6 +525,9 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
         case 52: return launch<128, 128, 2, 4, 2, 64>(a, st);
         case 53: return launch<256, 128, 4, 2, 2, 32>(a, st);   // 128 KiB (fp32 epilogue tile)
         case 54: return launch<128, 256, 2, 4, 2, 32>(a, st);
+        case 55: return launch<128, 128, 2, 4, 4, 32>(a, st);   // 64 KiB: 8 waves, 3 K tiles in flight
+        case 56: return launch<128, 128, 2, 4, 4, 64>(a, st);   // 128 KiB: BK = 64, 3 K tiles (96 KiB) in flight
+        case 57: return launch<128, 128, 2, 2, 4, 64>(a, st);   // = tile 5
         default: return hipErrorInvalidValue;
     }
 }

@@ -42,7 +42,9 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          34: (128, 64), 35: (128, 128), 36: (128, 64), 37: (128, 128),     # 34..37: deeper weight pipeline
          38: (128, 32), 39: (128, 32),                                     # Cout <= 32 heads
          # 50..54: csrc/conv.hip with EIGHT waves per workgroup (two per SIMD from one workgroup: the low-resolution layers)
-         50: (128, 128), 51: (128, 128), 52: (128, 128), 53: (256, 128), 54: (128, 256)}
+         50: (128, 128), 51: (128, 128), 52: (128, 128), 53: (256, 128), 54: (128, 256),
+         # 55..57: 4-stage pipelines (three K tiles in flight per workgroup: bytes in flight, not occupancy, for the streaming layers)
+         55: (128, 128), 56: (128, 128), 57: (128, 128)}
 # (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
 #  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)
 
@@ -61,7 +63,7 @@ PLANES = (64, 128, 256, 512)
 ALIGN = 256
 ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
 PRECISIONS = ("f16", "x3")
-X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
+X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 56, 57)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
 
 
 def split_f16(w, scaled=True):

@@ -149,6 +149,9 @@ CASES = [
     (1, 32, 52, 256, 512, 1, 2, 53, False, True, True),
     (2, 16, 24, 64, 256, 1, 1, 54, True, False, False),
     (1, 16, 26, 64, 320, 3, 1, 54, True, True, True),
+    (3, 10, 14, 192, 320, 3, 1, 55, True, True, True),       # 4-stage pipelines (55..57)
+    (2, 16, 24, 64, 256, 1, 1, 56, False, True, False),
+    (2, 8, 12, 512, 256, 1, 1, 57, True, False, True),
     # halo-tiled 3x3 stride-1 kernel (conv3.hip), tile ids 30..33: ragged pixel tiles in both directions
     (2, 16, 24, 64, 64, 3, 1, 30, True, False, False),
     (3, 10, 14, 192, 320, 3, 1, 31, True, False, False),
@@ -201,6 +204,10 @@ X3_CASES = [
     (2, 16, 24, 128, 128, 3, 2, 52, True, False, False),
     (1, 32, 52, 256, 512, 1, 2, 53, False, True, True),
     (1, 16, 26, 64, 320, 3, 1, 54, True, True, True),
+    # 4-stage pipelines (tile ids 55..57), incl. K shorter than the pipeline
+    (3, 10, 14, 192, 320, 3, 1, 55, True, True, True),
+    (2, 16, 24, 64, 256, 1, 1, 56, False, True, False),
+    (2, 8, 12, 512, 256, 1, 1, 57, True, False, True),
     # halo-tiled 3x3 (conv3.hip) in split precision: 32-channel chunks, rows = [hi32 | lo32]
     (2, 16, 24, 64, 64, 3, 1, 30, True, False, False),
     (3, 10, 14, 192, 320, 3, 1, 31, True, False, False),

@@ -101,6 +101,30 @@ def test_fp16_mode_measured_end_to_end_with_the_shipped_tile_table(kind):
     assert m["mpjpe_cm"] < 1.0 and m["max_joint_err_cm"] < 3.0  # measured envelope (~0.3 / ~0.8 cm at Z ~ 3 m): NOT 0.1 cm
 
 
+def test_split_precision_with_refinenet_batch_of_8():
+    """BASELINE configs[4]: batch 8 + RefineNet post-refinement, end to end against the reference path with the oracle's
+    RefineNet (fp32 MLP; 1 ulp-level differences in the GEMM order): refined 3D joints within 1e-3 m."""
+    from benchkit.workload import PEOPLE_CAM
+    from benchkit.recipe import recipe_state_dict
+    from model.refinenet import RefineNet
+    net, sd, imgs = _setup("smooth")
+    net.precision = "x3"
+    net = net.to(DEV)
+    torch.manual_seed(1)
+    rnet = RefineNet().eval()
+    rnet.load_state_dict(recipe_state_dict(rnet.state_dict()))
+    wt, bs = rnet.folded("cpu")
+    ref_w = ([w.t().contiguous().numpy() for w in wt], [b.numpy() for b in bs])
+    cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (B, 1))
+    hip = parity.hip_path(net, imgs.to(DEV), cams, refine=rnet.folded(DEV))
+    ref = parity.reference_path(sd, imgs, cams, threads=min(32, os.cpu_count() or 1), refine=ref_w)
+    m = parity.compare(hip, ref)
+    m.update(precision="x3", weights="smooth", batch=B, refinenet=True)
+    _dump("e2e_parity_x3_refinenet.json", m)
+    assert m["persons_ref"] >= 8 * B and m["peak_match"] == 1.0 and m["person_match"] == 1.0 and m["limb_match"] == 1.0
+    assert m["max_joint_err_cm"] <= 0.1
+
+
 def test_fp16_flip_batch_of_16_agrees_with_batch_of_8():
     """2B = 16 is the flip-TTA batch of the B = 8 pipeline: another tiling of M, same numbers within fp16 tolerance."""
     net, sd, imgs = _setup("smooth")

@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--tile-override", default="", help="e.g. L2:0,L6:5")
     ap.add_argument("--x3", action="store_true", help="split-precision instances (smap_op.precision = 1)")
+    ap.add_argument("--rotate", type=int, default=1,
+                    help="cycle through this many copies of the arena on ONE stream: with copies x tensor bytes > 256 MB every "
+                         "launch finds its operands cold in the Infinity Cache, as inside the full schedule")
     ap.add_argument("--streams", type=int, default=1,
                     help="launch the iterations round-robin on this many streams (own arena each): the difference to one "
                          "stream is the drain-and-dispatch gap between dependent launches that a second stream can hide")
@@ -88,6 +91,12 @@ def main():
                 i[0] += 1
                 L.check(lib.smap_plan_run(h, None, C.c_void_p(arenas[k].data_ptr()), C.c_void_p(blob.data_ptr()), None,
                                           C.c_void_p(streams[k].cuda_stream)), "run")
+        elif args.rotate > 1:
+            arenas = [arena] + [arena.clone() for _ in range(args.rotate - 1)]
+            def run(i=[0]):
+                k = i[0] % args.rotate
+                i[0] += 1
+                L.check(lib.smap_plan_run(h, None, C.c_void_p(arenas[k].data_ptr()), C.c_void_p(blob.data_ptr()), None, st), "run")
         else:
             run = lambda: L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()),
                                                     None, st), "run")
