@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-workgroup phase timeline of the conv kernel (diagnostics build, tools/build_ablate.py --trace):
-    SMAP_HIP_LIB=smap_amd/csrc/obj/libsmap_hip_trace.so python tools/trace_conv.py [L1 L3 ...]
+    SMAP_HIP_LIB=smap_amd/csrc/obj/libsmap_hip_trace.so [SMAP_TRACE_X3=1] python tools/trace_conv.py [L1 L3:20 ...]
 Stamps (s_memtime, 100 MHz constant clock on gfx950 -> printed in us): start, setup done, first K
 tile landed, K loop done, LDS staging done, stores retired; plus the summed wait at the top of each
 K iteration and the CU the workgroup ran on."""
@@ -26,7 +26,7 @@ def main():
         p = list(PRESETS[name])
         if tile:
             p[7] = int(tile)
-        lib, h, arena, blob, flops, byts = build(*p, dev)
+        lib, h, arena, blob, flops, byts = build(*p, dev, x3=bool(os.environ.get('SMAP_TRACE_X3')))
         B, H, W, Cin, Cout, k, s = p[:7]
         bm, bn = TILES[p[7]]
         Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
