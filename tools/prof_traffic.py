@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM traffic of one B = 8 forward from two rocprofv3 PMC passes (tools/gpu_profile.sh with PMC=1):
+"""HBM traffic of one B = 8 forward from two rocprofv3 PMC passes (tools/gpu_visits/gpu_profile.sh with PMC=1):
     python tools/prof_traffic.py gpurun_out/pmc_fetch_<tag>/pmc_counter_collection.csv \
                                  gpurun_out/pmc_write_<tag>/pmc_counter_collection.csv profiles/<name>.json
 Sums FETCH_SIZE / WRITE_SIZE (KB) over the conv launches (conv.hip / conv3.hip / conv1.hip kernels) of the LAST
