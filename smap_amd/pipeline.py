@@ -35,7 +35,10 @@ class _Slot:
                      for _ in range(1 + n_extra)]
         self.p2_f64 = None               # ground-truth modes: the f64 pred_2d (allocated on first use)
         self.ev_bb = torch.cuda.Event()
-        self.ev_post = torch.cuda.Event()
+        # the host waits on this one (submit -> _collect): a BLOCKING event parks the thread in the driver instead of spinning
+        # on the signal -- the submit thread is otherwise ~100 % of a core per rank for nothing, which is what eight ranks
+        # sharing a host would fight over
+        self.ev_post = torch.cuda.Event(blocking=True)
         self.meta = None
         self.busy = False
 

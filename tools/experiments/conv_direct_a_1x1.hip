@@ -1,0 +1,626 @@
+// conv.hip -- conv_bn_relu (model/smap.py:13-45) as an implicit GEMM on the gfx950
+// matrix cores, with folded BN, and bias + residual + ReLU + skip adds fused into
+// the epilogue.  Hand-written for CDNA4: wave64, v_mfma_f32_32x32x16_f16,
+// global_load_lds (LDS-DMA) staging with a source-side XOR swizzle, XCD-aware
+// block order.
+//
+// GEMM view     D[m][n] = sum_k A[m][k] * Wt[n][k]
+//   m = (b, oy, ox) output pixel, M = B*Ho*Wo          (NHWC fp16 activations)
+//   n = output channel, N = cout_pad                   (weights [cout_pad][KH][KW][Cin] fp16)
+//   k = (kh, kw, cin), K = KH*KW*Cin, walked in BK=64 chunks; a chunk never straddles a
+//       (kh,kw) position because Cin % 64 == 0, so the A rows of a chunk are 128
+//       contiguous bytes of one input pixel -- or 16 bytes of zeros from a zero page
+//       when the tap falls into the padding / past M.
+//
+// LDS image of a staged tile: [rows][64 halves] = 128-B rows, written by LDS-DMA
+// (lane-linear: wave w, round i covers rows i*32+w*8 .. +8, lane l -> row l/8, 16-B
+// slot l%8).  Slot s of row r holds K-granule s ^ ((r>>1)&7): the permutation is
+// applied to the per-lane GLOBAL address (the DMA cannot scatter) and again on the
+// ds_read_b128 side, which makes the 16-lane groups of ds_read_b128 conflict free.
+//
+// Epilogue: accumulators (+bias) go to LDS as an fp32 [BM][BN] tile, then every
+// thread owns 8 consecutive channels of one pixel: residual (16-B load) -> ReLU ->
+// post-ReLU skip adds -> one 16-B fp16 store (or two 16-B fp32 stores), i.e. full
+// coalesced NHWC lines.  One rounding to fp16 per output value.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "smap_hip.h"
+#include "plan.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+#ifndef SMAP_ABLATE
+#define SMAP_ABLATE 0            // experiments only (tools/build_ablate.py): 1 no loads, 2 no MFMA, 4 no stores, 8 no epilogue
+#endif
+// FULL = false: epilogue with bias / residual / ReLU only (most layers: ~45 fewer VGPRs, more workgroups per CU);
+// FULL = true : + fused bilinear add and post-ReLU addends.
+// X3 = true  : fp32-equivalent arithmetic on the fp16 matrix cores (smap_op.precision = 1).  Every activation and weight
+//              is stored as TWO fp16 planes hi = fp16(v), lo = fp16(v - hi) (22 significant bits; a pixel is [hi(C) | lo(C)],
+//              the weight matrix [cout_pad][K] hi followed by [cout_pad][K] lo, pre-scaled by a power of two so that lo
+//              stays in fp16's normal range) and a K step issues three MFMAs into the same fp32 accumulator:
+//              hi*hi + hi*lo + lo*hi (the dropped lo*lo term is 2^-24 relative).  A K tile stages four LDS images
+//              (A hi, A lo, W hi, W lo); the epilogue re-splits the fp32 result.  3x the MFMA work and 2x the bytes of
+//              the fp16 mode, ~1e-6 relative error instead of ~1e-3: the mode whose output meets the reference's fp32.
+// WM x WN = 4 or 8 waves.  Eight waves (two per SIMD from ONE workgroup) are for the low-resolution layers whose grids
+// do not fill the chip: a lone wave issues an MFMA only every ~80 cycles, two waves per SIMD reach the pipe rate
+// (tools/ubench/mfma_clock.hip), and with <= 256 workgroups of 4 waves there is no second wave on the SIMD.
+// KT > 0   : DIRECT-A form for 1x1 stride-1 convs with K = KT * BK (K <= 256 in split precision).  An MFMA A fragment is, per
+//             lane, 16 contiguous bytes of one pixel, and that access pattern streams from HBM into registers at the same
+//             6.3 TB/s as coalesced order (tools/ubench/frag_stream.hip) -- so the activation operand skips LDS: every wave
+//             (WN = 1: a wave owns 32*MI rows x all BN columns) requests ALL its A fragments of the tile up front with plain
+//             loads (32 KB per wave in flight instead of one 4 KB K tile behind a barrier), only the weights stream through
+//             the LDS ring, from L2.  The K loop then waits on L2 latencies, not on HBM's, eight times over.
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3, int KT = 0>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a)
+{
+    constexpr bool DA = KT > 0;
+    static_assert(!DA || (WN == 1 && STAGES == 2), "direct-A: a wave owns whole rows of the tile; double-buffered weights");
+    constexpr int NPL = X3 ? 2 : 1;                    // fp16 planes per operand
+    constexpr int NW = WM * WN, NT = NW * 64;          // waves, threads
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(STAGES >= 2 && STAGES <= 4, "2..4 LDS stages");
+    static_assert(BK == 32 || BK == 64, "BK = halves per K chunk");
+    constexpr int ROWB = BK * 2;                       // bytes per LDS row
+    constexpr int SPR = ROWB / 16;                     // 16-byte slots per row (8 / 4)
+    constexpr int RPW = 64 / SPR;                      // rows one wave-wide LDS-DMA instruction covers (8 / 16)
+    constexpr int RPR = NW * RPW;                      // rows per round of all waves (32 / 64 with 4 waves)
+    static_assert((DA || BM % RPR == 0) && BN % RPR == 0, "tile must be a multiple of the DMA round");
+    constexpr int LA = DA ? 0 : BM / RPR, LB = BN / RPR, LA1 = LA > 0 ? LA : 1;
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+    static_assert(MI >= 1 && NI >= 1, "tile too small for the wave grid");
+    constexpr int ABYTES = DA ? 0 : NPL * BM * ROWB;   // A part of a stage (none when the A operand goes straight to registers)
+    constexpr int STAGE = ABYTES + NPL * BN * ROWB;    // [A planes][B planes]
+    constexpr int LPT = NPL * (LA + LB);               // LDS-DMA loads per thread per K tile
+    static_assert((STAGES - 2) * LPT <= 63, "vmcnt is 6 bits");
+    constexpr int LDS_BYTES = STAGES * STAGE > BM * BN * 4 ? STAGES * STAGE : BM * BN * 4;   // pipeline | fp32 epilogue tile
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS is 160 KiB per CU");
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+    SMAP_TL_BEGIN
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
+#ifdef SMAP_TRACE
+    long long tr_t[8]; long long tr_wait = 0;
+    tr_t[0] = __builtin_amdgcn_s_memtime();
+#define TR(i) tr_t[i] = __builtin_amdgcn_s_memtime()
+#else
+#define TR(i)
+#endif
+
+    // ---- XCD-aware block order: blocks b, b+8, b+16.. run on one XCD; give each XCD a
+    //      contiguous range of logical tiles so that the N-tiles of one M-tile (which
+    //      re-read the same activation rows) share an L2.
+    int logical;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int m_tile = logical / a.n_tiles, n_tile = logical - m_tile * a.n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    // ---- per-thread staging geometry.  Every global address of the K loop is
+    //      (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset in one VGPR): the A base is
+    //      the ARENA (whose first 256 bytes are zeros = the padding "zero page"), the B base the
+    //      weight matrix.  Per K tile only the uniform part moves, so the loop body carries no
+    //      per-lane address arithmetic; the per-lane offsets change once per (kh,kw) tap.
+    const int lrow = lane / SPR, lslot = lane % SPR;
+    const int srow = wave * RPW + lrow;                          // row inside a DMA round
+    const int gch = BK == 64 ? (lslot ^ ((srow >> 1) & 7)) : (lslot ^ ((srow >> 2) & 3));   // K-granule this lane fetches
+    const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
+    const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
+    const int HoWo = a.Ho * a.Wo;
+
+    // Weight-tile offsets first, and the weight half of K tile 0 goes out at once: it does not depend on
+    // the pixel arithmetic below, so its L2 latency overlaps the rest of the set-up.
+    unsigned b_off[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i)
+        b_off[i] = (unsigned)(((n0 + i * RPR + srow) * a.K + gch * 8) * 2);
+    auto issue_b = [&](int buf, unsigned boff) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            char* sB = smem + buf * STAGE + ABYTES + pl * BN * ROWB;
+            const char* gB = wt + boff + (X3 ? (long long)pl * a.w_lo : 0LL);
+#pragma unroll
+            for (int i = 0; i < LB; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
+        }
+    };
+    if (!(SMAP_ABLATE & 1)) issue_b(0, 0);
+
+    // Per staged A row: byte offset (from the arena base) of tap (0,0), channel granule gch, and the mask
+    // of in-range taps (bit kh*ksize+kw).  m -> (b, oy, ox) costs two integer divisions ONCE per thread;
+    // the thread's other rows are 32 pixels further along the raster (carry propagation), and the tap
+    // mask is the outer product of three row tests and three column tests (no loop over taps): the
+    // set-up phase was 20-30 % of a short-K workgroup's lifetime (tools/trace_conv.py).
+    unsigned a_off[LA1];
+    unsigned a_mask[LA1];
+    if constexpr (!DA) {
+        int m = m0 + srow;
+        int b = m / HoWo, rem = m - b * HoWo;
+        int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            a_off[i] = 0;
+            a_mask[i] = 0;
+            if (m < a.M) {
+                const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+                const long long e = ((long long)(b * a.H + iy0) * a.W + ix0) * a.in_stride_c + a.in_c_off + gch * 8;
+                a_off[i] = (unsigned)(a.in_off + e * 2);       // wraps for taps above/left of the image; only
+                unsigned vx = 0, mk = 0;                       // used (mod 2^32) when the tap itself is valid
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    if (kw < a.ksize && (unsigned)(ix0 + kw) < (unsigned)a.W) vx |= 1u << kw;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+                    if (kh < a.ksize && (unsigned)(iy0 + kh) < (unsigned)a.H) mk |= vx << (kh * a.ksize);
+                a_mask[i] = mk;
+            }
+            m += RPR;
+            ox += RPR;
+            while (ox >= a.Wo) { ox -= a.Wo; ++oy; }
+            while (oy >= a.Ho) { oy -= a.Ho; ++b; }
+        }
+    }
+    const int cchunks = a.Cin / BK;
+    const int n_iter = a.ksize * a.ksize * cchunks;
+
+    // staging cursor (all wave-uniform -> SGPRs): tap (s_kh, s_kw), channel chunk s_cc
+    int s_kh = 0, s_kw = 0, s_cc = 0;
+    unsigned s_boff = 0;                                       // bytes into a weight row: it * 128
+    unsigned a_cur[LA1];                                       // per-lane offsets of the current tap (0 = zero page)
+    auto set_tap = [&]() {
+        const unsigned tap_off = (unsigned)((s_kh * a.W + s_kw) * a.in_stride_c * 2);
+        const unsigned bit = 1u << (s_kh * a.ksize + s_kw);
+#pragma unroll
+        for (int i = 0; i < LA; ++i) a_cur[i] = (a_mask[i] & bit) ? a_off[i] + tap_off : 0u;
+    };
+    set_tap();
+    auto issue_a = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            char* sA = smem + buf * STAGE + pl * BM * ROWB;
+            // invalid taps: a_cur = 0 -> zero page + s_cc*ROWB (+ the lo-plane offset: the zero page covers both)
+            const char* gA = arena + (unsigned)(s_cc * ROWB + (X3 ? pl * a.in_lo * 2 : 0));
+#pragma unroll
+            for (int i = 0; i < LA; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
+        }
+    };
+    auto advance = [&]() {
+        s_boff += ROWB;
+        if (++s_cc == cchunks) {
+            s_cc = 0;
+            if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; }
+            set_tap();                 // past the last tap the mask bit is 0 -> offsets 0, never issued anyway
+        }
+    };
+    auto stage = [&](int buf) {        // all loads of K tile t are issued before any load of tile t+1 (counted vmcnt)
+        issue_a(buf);
+        issue_b(buf, s_boff);
+        advance();
+    };
+    if (!(SMAP_ABLATE & 1)) { issue_a(0); advance(); }           // activation half of K tile 0
+    // ---- direct-A: every A fragment of this wave's rows, for the whole K, requested now (plain loads into registers)
+    half8 areg[DA ? KT : 1][BK / 16][NPL][MI];
+    if constexpr (DA) {
+        const int r31 = lane & 31, rhi = lane >> 5;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wave * (BM / WM) + mi * 32 + r31;                 // 1x1 stride 1: output pixel m = input pixel m
+            const unsigned aoff = m < a.M ? (unsigned)(a.in_off + ((long long)m * a.in_stride_c + a.in_c_off + rhi * 8) * 2)
+                                          : (unsigned)(rhi * 16);               // rows past M read the zero page
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl)
+                        areg[kt][kk][pl][mi] = (SMAP_ABLATE & 1) ? half8{} :
+                            *reinterpret_cast<const half8*>(arena + aoff + (kt * BK + kk * 16) * 2 + (X3 ? pl * a.in_lo * 2 : 0));
+        }
+    }
+
+    // ---- residual prefetch: the epilogue's residual tile (8 channels x PASSES pixels per thread) is
+    //      requested before the K loop so that its HBM latency hides under the whole main loop
+    //      (a pass-by-pass load in the epilogue exposes one full memory round trip per pass).
+    constexpr int CG = BN / 8;                    // channel groups per row
+    constexpr int PASSES = BM * CG / NT;
+    static_assert(BM * CG % NT == 0, "tile/thread mismatch");
+    half8 rres[PASSES][NPL];
+    if (a.res) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int idx = p * NT + tid;
+            const int row = idx / CG, cg = idx - row * CG;
+            const int m = m0 + row, n = n0 + cg * 8;
+            const long long dense = (m < a.M && n < a.Cout8) ? (long long)m * (NPL * a.Cout8) + n : 0;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                rres[p][pl] = *reinterpret_cast<const half8*>(a.res + dense + pl * a.Cout8);
+        }
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int rswz = BK == 64 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
+    const int a_row0 = wm * (BM / WM) + l31;     // + mi*32
+    const int b_row0 = wn * (BN / WN) + l31;     // + ni*32
+
+    // ---- STAGES-deep LDS-DMA pipeline.  Iteration `it` needs K tile `it`; tiles it+1 .. it+STAGES-2
+    //      stay in flight across the barrier (counted vmcnt + raw s_barrier: a __syncthreads() here
+    //      would drain the DMA queue).  RAW: every wave waits for its own slice of tile `it`, then the
+    //      barrier publishes all slices.  WAR: the buffer refilled after the barrier held tile it-1,
+    //      whose ds_reads were consumed by MFMAs that precede the barrier in program order.
+    TR(1);
+    if constexpr (DA) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            // kt = 0: the weights of tile 0, every A fragment and the residual tile have arrived; later: weight tile kt (from L2)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#ifdef SMAP_TRACE
+            if (kt == 0) tr_t[2] = __builtin_amdgcn_s_memtime();
+#endif
+            if (kt + 1 < KT && !(SMAP_ABLATE & 1)) { issue_b((kt + 1) & 1, s_boff); advance(); }
+            const char* sB = smem + (kt & 1) * STAGE;
+#pragma unroll
+            for (int kk = 0; kk < ((SMAP_ABLATE & 2) ? 0 : BK / 16); ++kk) {
+                const int slot = ((kk * 2 + lhi) ^ rswz) * 16;
+                half8 bf[NPL][NI];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        bf[pl][ni] = *reinterpret_cast<const half8*>(sB + (pl * BN + b_row0 + ni * 32) * ROWB + slot);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        if (X3) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[kt][kk][NPL - 1][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[kt][kk][0][mi], bf[NPL - 1][ni], acc[mi][ni], 0, 0, 0);
+                        }
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[kt][kk][0][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
+                    }
+            }
+        }
+    } else {
+#pragma unroll
+    for (int st = 1; st < STAGES - 1; ++st)                       // K tile 0 went out during the set-up
+        if (st < n_iter && !(SMAP_ABLATE & 1)) stage(st);
+    int buf = 0, nbuf = STAGES - 1;
+    for (int it = 0; it < n_iter; ++it) {
+#ifdef SMAP_TRACE
+        const long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
+        if (it + STAGES - 1 <= n_iter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#ifdef SMAP_TRACE
+        tr_wait += __builtin_amdgcn_s_memtime() - tw0;
+        if (it == 0) tr_t[2] = __builtin_amdgcn_s_memtime();
+#endif
+        if (it + STAGES - 1 < n_iter && !(SMAP_ABLATE & 1)) stage(nbuf);
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + ABYTES;
+#pragma unroll
+        for (int kk = 0; kk < ((SMAP_ABLATE & 2) ? 0 : BK / 16); ++kk) {
+            const int slot = ((kk * 2 + lhi) ^ rswz) * 16;
+            half8 af[NPL][MI], bf[NPL][NI];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    af[pl][mi] = *reinterpret_cast<const half8*>(sA + (pl * BM + a_row0 + mi * 32) * ROWB + slot);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    bf[pl][ni] = *reinterpret_cast<const half8*>(sB + (pl * BN + b_row0 + ni * 32) * ROWB + slot);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if (X3) {       // small cross terms first, then hi*hi
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[NPL - 1][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][mi], bf[NPL - 1][ni], acc[mi][ni], 0, 0, 0);
+                    }
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
+    }
+    }   // !DA
+    TR(3);
+    __syncthreads();   // everyone is done reading the staging buffers
+    if (SMAP_ABLATE & 8) {
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(a.out)[tid] = acc[0][0][1];   // keep acc live
+        return;
+    }
+
+    // ---- epilogue 1: acc + bias -> fp32 [BM][BN] tile in LDS
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = wn * (BN / WN) + ni * 32 + l31;
+        const float bias = a.bias[n0 + col];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (BM / WM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                Cs[row * BN + col] = X3 ? acc[mi][ni][r] * a.acc_scale + bias : acc[mi][ni][r] + bias;
+            }
+    }
+    __syncthreads();
+
+    // ---- epilogue 2: 8 consecutive channels of one pixel per thread.  Software-pipelined over the
+    //      passes: the global loads of pass p+1 (bilinear taps, post-ReLU addends) are issued before the
+    //      arithmetic + store of pass p, so one memory round trip is exposed per tile, not per pass.
+    struct Extra { half8 t00[NPL], t01[NPL], t10[NPL], t11[NPL], a1[NPL], a2[NPL]; float ly0, ly1, lx0, lx1; bool ok; long long o; int row, cg; };
+    constexpr int TS = NPL;                                        // pixel stride multiplier of the dense split tensors
+    auto val = [](const half8 (&h)[NPL], int e) -> float {       // hi (+ lo) -> fp32, exact
+        return X3 ? (float)h[0][e] + (float)h[NPL - 1][e] : (float)h[0][e];
+    };
+    auto load_pass = [&](int p) -> Extra {
+        Extra x;
+        const int idx = p * NT + tid;
+        x.row = idx / CG;
+        x.cg = idx - x.row * CG;
+        const int m = m0 + x.row, n = n0 + x.cg * 8;
+        x.ok = m < a.M && n < a.Cout8 && !((SMAP_ABLATE & 4) && a.M != 7);
+        const int ms = x.ok ? m : 0, ns = x.ok ? n : 0;            // clamped: loads stay in bounds
+        const long long dense = (long long)ms * (TS * a.Cout8) + ns;     // res/add tensors are dense [M][Cout8] (x planes)
+        x.o = (long long)ms * a.out_stride_c + a.out_c_off + ns;
+        if (FULL && a.up) {
+            const int b = ms / HoWo, rem = ms - b * HoWo;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            const Lerp ly = lerp_index(oy, a.up_h, a.Ho), lx = lerp_index(ox, a.up_w, a.Wo);
+            const int us = TS * a.Cout8;
+            const _Float16* tb = a.up + (long long)b * a.up_h * a.up_w * us + ns;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                x.t00[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i0) * us + pl * a.Cout8);
+                x.t01[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i1) * us + pl * a.Cout8);
+                x.t10[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i0) * us + pl * a.Cout8);
+                x.t11[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i1) * us + pl * a.Cout8);
+            }
+            x.ly0 = ly.l0; x.ly1 = ly.l1; x.lx0 = lx.l0; x.lx1 = lx.l1;
+        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            if (FULL && a.add1) x.a1[pl] = *reinterpret_cast<const half8*>(a.add1 + dense + pl * a.Cout8);
+            if (FULL && a.add2) x.a2[pl] = *reinterpret_cast<const half8*>(a.add2 + dense + pl * a.Cout8);
+        }
+        return x;
+    };
+    auto finish_pass = [&](int p, const Extra& x) {
+        float v[8];
+        {
+            const float4 lo = *reinterpret_cast<const float4*>(Cs + x.row * BN + x.cg * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(Cs + x.row * BN + x.cg * 8 + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+            v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        }
+        if (a.res) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += val(rres[p], e);
+        }
+        if (FULL && a.up) {        // Upsample_unit: out = relu(u_skip(x) + up_conv(bilinear_up(prev))) (smap.py:213-217); the
+                           // 1x1 up_conv was applied at low resolution, this is its bilinear resampling
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                v[e] += x.ly0 * (x.lx0 * val(x.t00, e) + x.lx1 * val(x.t01, e)) +
+                        x.ly1 * (x.lx0 * val(x.t10, e) + x.lx1 * val(x.t11, e));
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (FULL && a.add1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += val(x.a1, e);
+        }
+        if (FULL && a.add2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += val(x.a2, e);
+        }
+        if (!x.ok) return;
+        if (a.out_fp32) {
+            float* op = reinterpret_cast<float*>(a.out) + x.o;
+            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
+            *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + x.o) = h;
+            if (X3) {           // lo plane: the part of v that fp16 dropped (v - hi is exact in fp32)
+                half8 l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) l[e] = (_Float16)(v[e] - (float)h[e]);
+                *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + x.o + a.out_lo) = l;
+            }
+        }
+    };
+    TR(4);
+    Extra ex[2];
+    ex[0] = load_pass(0);
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        if (p + 1 < PASSES) ex[(p + 1) & 1] = load_pass(p + 1);
+        finish_pass(p, ex[p & 1]);
+    }
+#ifdef SMAP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR(5);
+    if (a.dbg && tid == 0) {
+        long long* d = a.dbg + (long long)blockIdx.x * 8;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        d[0] = tr_t[0]; d[1] = tr_t[1]; d[2] = tr_t[2]; d[3] = tr_t[3]; d[4] = tr_t[4]; d[5] = tr_t[5]; d[6] = tr_wait; d[7] = hwid;
+    }
+#endif
+    SMAP_TL_END(a)
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64>
+hipError_t launch(const ConvArgs& a, hipStream_t st)
+{
+    if (a.x3) return hipErrorInvalidValue;                 // split-precision ops use the tiles of launch_x3 only
+    if (a.up || a.add1 || a.add2)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, true, false>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, false>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+    return hipGetLastError();
+}
+
+// direct-A instances (1x1 stride 1, K = KT * BK): tile ids 80 (128x128) and 81 (128x64), either precision
+template <int BN, int BK, bool X3, int KT>
+hipError_t launch_da_kt(const ConvArgs& a, hipStream_t st)
+{
+    if (a.up || a.add1 || a.add2)
+        hipLaunchKernelGGL((conv_igemm_kernel<128, BN, 4, 1, 2, BK, true, X3, KT>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<128, BN, 4, 1, 2, BK, false, X3, KT>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+template <int BN, int BK, bool X3>
+hipError_t launch_da(const ConvArgs& a, hipStream_t st)
+{
+    if (a.ksize != 1 || a.stride != 1 || (a.x3 != 0) != X3 || a.K % BK) return hipErrorInvalidValue;
+    switch (a.K / BK) {
+        case 1: if constexpr (BK == 64) return launch_da_kt<BN, BK, X3, 1>(a, st); else return hipErrorInvalidValue;
+        case 2: return launch_da_kt<BN, BK, X3, 2>(a, st);
+        case 4: return launch_da_kt<BN, BK, X3, 4>(a, st);
+        case 8: return launch_da_kt<BN, BK, X3, 8>(a, st);
+        default: return hipErrorInvalidValue;              // K beyond the register budget: the staged kernel
+    }
+}
+
+// split-precision (X3) instances: the same tile ids select them when the op says precision = 1
+template <int BM, int BN, int WM, int WN, int STAGES, int BK>
+hipError_t launch_x3(const ConvArgs& a, hipStream_t st)
+{
+    if (a.up || a.add1 || a.add2)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, true, true>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, true>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// tile selector -> (BM, BN).  Keep in sync with smap_amd/engine.py::TILES.
+//   0..4 : 2-stage (double-buffered) variants; 5..9 : the same tiles with deeper LDS-DMA pipelines
+int smap_conv_tile_dims(int tile, int* bm, int* bn)
+{
+    if (tile >= 30 && tile < 40) return smap_conv3_tile_dims(tile, bm, bn);
+    switch (tile) {
+        case 20: case 24: *bm = 128; *bn = 128; return 0;      // 20..27: BK = 32 staging (smaller LDS, more workgroups per CU)
+        case 21: case 25: *bm = 128; *bn = 64; return 0;
+        case 22: case 26: *bm = 64; *bn = 64; return 0;
+        case 23: case 27: *bm = 64; *bn = 128; return 0;
+        case 55: case 56: case 57: *bm = 128; *bn = 128; return 0;   // 55..57: deep pipelines (3 K tiles in flight)
+        case 80: *bm = 128; *bn = 128; return 0;                     // 80..81: direct-A 1x1 (K <= 256 / 512)
+        case 81: *bm = 128; *bn = 64; return 0;
+        case 50: case 51: case 52: *bm = 128; *bn = 128; return 0;   // 50..54: eight-wave workgroups
+        case 53: *bm = 256; *bn = 128; return 0;
+        case 54: *bm = 128; *bn = 256; return 0;
+        case 0: case 5: *bm = 128; *bn = 128; return 0;
+        case 1: case 6: *bm = 128; *bn = 64; return 0;
+        case 2: case 7: *bm = 64; *bn = 64; return 0;
+        case 3: case 8: *bm = 128; *bn = 32; return 0;
+        case 4: case 9: *bm = 64; *bn = 128; return 0;
+        default: return -1;
+    }
+}
+
+// tiles that have a split-precision instance (plan.hip::validate asks)
+int smap_conv_tile_has_x3(int tile)
+{
+    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 57) ||
+           tile == 80 || tile == 81;
+}
+
+hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
+{
+    if (a.x3) {
+        if (tile >= 30 && tile < 40) return smap_launch_conv3(a, tile, st);     // halo-tiled 3x3, split-precision instance
+        switch (tile) {                                     // LDS = max(STAGES * 2 * (BM + BN) * row bytes, fp32 epilogue tile)
+            case 0: return launch_x3<128, 128, 2, 2, 2, 64>(a, st);   // 128 KiB: BK = 64, half the barriers per K
+            case 1: return launch_x3<128, 64, 2, 2, 2, 64>(a, st);    // 96 KiB
+            case 2: return launch_x3<64, 64, 2, 2, 2, 64>(a, st);     // 64 KiB
+            case 4: return launch_x3<64, 128, 2, 2, 2, 64>(a, st);    // 96 KiB
+            case 3: return launch_x3<128, 32, 4, 1, 2, 64>(a, st);    // 80 KiB (Cout <= 32 heads)
+            case 20: return launch_x3<128, 128, 2, 2, 2, 32>(a, st);  // 64 KiB
+            case 21: return launch_x3<128, 64, 2, 2, 2, 32>(a, st);   // 48 KiB
+            case 22: return launch_x3<64, 64, 2, 2, 2, 32>(a, st);    // 32 KiB
+            case 23: return launch_x3<64, 128, 2, 2, 2, 32>(a, st);   // 48 KiB
+            case 24: return launch_x3<128, 128, 2, 2, 3, 32>(a, st);  // 96 KiB, 2 tiles in flight (fp16 id 24 is 4-stage)
+            case 25: return launch_x3<128, 64, 2, 2, 3, 32>(a, st);   // 72 KiB, 2 tiles in flight
+            case 26: return launch_x3<64, 64, 2, 2, 4, 32>(a, st);    // 64 KiB, 3 tiles in flight
+            case 27: return launch_x3<64, 128, 2, 2, 3, 32>(a, st);   // 72 KiB
+            case 50: return launch_x3<128, 128, 2, 4, 2, 32>(a, st);  // 64 KiB, 8 waves of 64x32
+            case 51: return launch_x3<128, 128, 4, 2, 2, 32>(a, st);  // 64 KiB, 8 waves of 32x64
+            case 52: return launch_x3<128, 128, 2, 4, 2, 64>(a, st);  // 128 KiB, BK = 64
+            case 53: return launch_x3<256, 128, 4, 2, 2, 32>(a, st);  // 96 KiB, 8 waves of 64x64
+            case 54: return launch_x3<128, 256, 2, 4, 2, 32>(a, st);  // 96 KiB, 8 waves of 64x64
+            case 55: return launch_x3<128, 128, 2, 4, 4, 32>(a, st);  // 128 KiB: 8 waves, 3 K tiles (96 KiB) in flight
+            case 56: return launch_x3<128, 128, 4, 2, 4, 32>(a, st);
+            case 57: return launch_x3<128, 128, 2, 2, 4, 32>(a, st);  // 128 KiB: 4 waves, 3 K tiles in flight
+            case 80: return launch_da<128, 32, true>(a, st);          // 64 KiB (epilogue tile); weights ring 32 KiB
+            case 81: return launch_da<64, 32, true>(a, st);           // 32 KiB
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (tile >= 30 && tile < 40) return smap_launch_conv3(a, tile, st);
+    switch (tile) {
+        case 20: return launch<128, 128, 2, 2, 2, 32>(a, st);   // 64 KiB (fp32 epilogue tile)
+        case 21: return launch<128, 64, 2, 2, 2, 32>(a, st);    // 32 KiB
+        case 22: return launch<64, 64, 2, 2, 2, 32>(a, st);     // 16 KiB
+        case 23: return launch<64, 128, 2, 2, 2, 32>(a, st);    // 32 KiB
+        case 24: return launch<128, 128, 2, 2, 4, 32>(a, st);   // 64 KiB, 3 tiles in flight
+        case 25: return launch<128, 64, 2, 2, 3, 32>(a, st);    // 36 KiB
+        case 26: return launch<64, 64, 2, 2, 4, 32>(a, st);     // 32 KiB
+        case 27: return launch<64, 128, 2, 2, 3, 32>(a, st);    // 36 KiB
+        case 0: return launch<128, 128, 2, 2, 2>(a, st);
+        case 1: return launch<128, 64, 2, 2, 2>(a, st);
+        case 2: return launch<64, 64, 2, 2, 2>(a, st);
+        case 3: return launch<128, 32, 4, 1, 2>(a, st);
+        case 4: return launch<64, 128, 2, 2, 2>(a, st);
+        case 5: return launch<128, 128, 2, 2, 4>(a, st);    // 128 KiB LDS, 1 block/CU, 3 tiles in flight
+        case 6: return launch<128, 64, 2, 2, 3>(a, st);     //  72 KiB, 2 blocks/CU
+        case 7: return launch<64, 64, 2, 2, 4>(a, st);      //  64 KiB, 2 blocks/CU
+        case 8: return launch<128, 32, 4, 1, 3>(a, st);     //  60 KiB, 2 blocks/CU
+        case 9: return launch<64, 128, 2, 2, 3>(a, st);     //  72 KiB, 2 blocks/CU
+        case 50: return launch<128, 128, 2, 4, 2, 32>(a, st);   // eight-wave workgroups (fp16: 64 KiB = the fp32 epilogue tile)
+        case 51: return launch<128, 128, 4, 2, 2, 32>(a, st);
+        case 52: return launch<128, 128, 2, 4, 2, 64>(a, st);
+        case 53: return launch<256, 128, 4, 2, 2, 32>(a, st);   // 128 KiB (fp32 epilogue tile)
+        case 54: return launch<128, 256, 2, 4, 2, 32>(a, st);
+        case 55: return launch<128, 128, 2, 4, 4, 32>(a, st);   // 64 KiB: 8 waves, 3 K tiles in flight
+        case 56: return launch<128, 128, 2, 4, 4, 64>(a, st);   // 128 KiB: BK = 64, 3 K tiles (96 KiB) in flight
+        case 57: return launch<128, 128, 2, 2, 4, 64>(a, st);   // = tile 5
+        case 80: return launch_da<128, 64, false>(a, st);       // direct-A 1x1, K <= 512
+        case 81: return launch_da<64, 64, false>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
