@@ -241,6 +241,21 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def thread_cpu_seconds():
+    """{tid: (name, cpu seconds)} of every native thread of this process (/proc): who burns the host while the GPU works."""
+    out = {}
+    try:
+        tck = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            f = open(f"/proc/self/task/{tid}/stat").read()
+            name = f[f.index("(") + 1:f.rindex(")")]
+            rest = f[f.rindex(")") + 2:].split()
+            out[int(tid)] = (name, (int(rest[11]) + int(rest[12])) / tck)
+    except Exception:
+        pass
+    return out
+
+
 def pin_host_threads(local, world):
     """One process per GPU on a shared host: give each rank its own slice of the allowed CPUs and a matching thread
     count, so that eight submit threads + their OpenMP/MKL pools do not fight over the same cores."""
@@ -376,6 +391,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     cpu0 = time.process_time()
+    thr0 = thread_cpu_seconds()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -393,6 +409,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
+    thr1 = thread_cpu_seconds()
+    busiest = sorted(((n, (c - thr0.get(t, (n, 0.0))[1]) / args.steps * 1e3) for t, (n, c) in thr1.items()), key=lambda x: -x[1])[:4]
     bb_ms = [e0.elapsed_time(e1) for e0, e1 in pipe.bb_events]
     # idle time of a backbone stream between two consecutive schedules (batch k-depth's end -> batch k's start)
     ev = pipe.bb_events
@@ -442,7 +460,8 @@ def main():
                                    f"one end-of-run gather of the records",
                        "association_lift_us_per_batch": {k: float(np.median(v)) for k, v in sorted(post_us.items())},
                        "host_ms_per_step": {"submit_wall": host["submit"] / args.steps * 1e3, "process_cpu_per_rank": per_rank_host,
-                                            "threads": host_threads},
+                                            "threads": host_threads,
+                                            "busiest_threads_cpu_ms": [[n, round(v, 2)] for n, v in busiest]},
                        "host_submit_ms_quantiles": [float(np.percentile(host["steps"], q)) for q in (0, 10, 50, 90, 100)],
                        "host_timeline_ms": {"submit_loop_done": t_loop * 1e3, "flush_done": t_flush * 1e3, "total": dt * 1e3}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",

@@ -35,10 +35,7 @@ class _Slot:
                      for _ in range(1 + n_extra)]
         self.p2_f64 = None               # ground-truth modes: the f64 pred_2d (allocated on first use)
         self.ev_bb = torch.cuda.Event()
-        # the host waits on this one (submit -> _collect): a BLOCKING event parks the thread in the driver instead of spinning
-        # on the signal -- the submit thread is otherwise ~100 % of a core per rank for nothing, which is what eight ranks
-        # sharing a host would fight over
-        self.ev_post = torch.cuda.Event(blocking=True)
+        self.ev_post = torch.cuda.Event()       # the host waits on this one: PosePipeline._wait
         self.meta = None
         self.busy = False
 
@@ -174,8 +171,17 @@ class PosePipeline:
         return out
 
     # -- host side ---------------------------------------------------------------------------
+    @staticmethod
+    def _wait(ev, poll_s=2e-4):
+        """Wait for a HIP event WITHOUT spinning: hipEventSynchronize busy-polls the signal (also for events created with
+        the blocking flag on this ROCm), which makes the submit thread ~100 % of a core per rank; a query loop with 0.2 ms
+        sleeps costs ~2 % and at most 0.2 ms of latency, which the second batch in flight hides."""
+        import time
+        while not ev.query():
+            time.sleep(poll_s)
+
     def _collect(self, slot):
-        slot.ev_post.synchronize()
+        self._wait(slot.ev_post)
         tags, extra_tags, annotations = slot.meta
         recs = []
         for idx, h in enumerate(slot.host):
