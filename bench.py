@@ -155,7 +155,7 @@ def forward_only(args, dev, rank, world, B):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=getattr(args, "cdev", dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
@@ -309,16 +309,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     host_threads = pin_host_threads(local, world)
+    # Test hooks (tests/test_entry_gpu.py runs this very function with two ranks on a ONE-GPU box): SMAP_BENCH_SHARE_GPU=1
+    # puts every rank on cuda:0, SMAP_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); the
+    # collectives then run on CPU tensors.  The driver's multi-GPU runs use neither.
+    if os.environ.get("SMAP_BENCH_SHARE_GPU"):
+        local = 0
+    backend = os.environ.get("SMAP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    cdev = dev if backend == "nccl" else torch.device("cpu")      # where collective payloads live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm; one process per GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm; one process per GPU
+        else:
+            dist.init_process_group(backend)
 
     from benchkit.workload import PEOPLE_CAM, make_cfg, people_state_dict, synth_scene
     from model.smap import SMAP
     from smap_amd.dist import gather_bytes
 
     B = args.batch
+    args.cdev = cdev
     if args.forward_only:
         return forward_only(args, dev, rank, world, B)
     from smap_amd.pipeline import PosePipeline
@@ -404,7 +415,7 @@ def main():
     if world > 1:                             # ONE gather per run: every rank's records to every rank (RCCL, comm stream)
         payload = pickle.dumps(collected, protocol=pickle.HIGHEST_PROTOCOL)
         with torch.cuda.stream(pipe.s_comm):
-            gathered = gather_bytes(payload, dev)
+            gathered = gather_bytes(payload, cdev)
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -420,11 +431,11 @@ def main():
         post_us.setdefault(tag, []).append(p0.elapsed_time(p1) * 1e3)
     per_rank_host = [cpu_ms_per_step]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        hc = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(hc, torch.tensor([cpu_ms_per_step], dtype=torch.float64, device=dev))
+        hc = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(hc, torch.tensor([cpu_ms_per_step], dtype=torch.float64, device=cdev))
         per_rank_host = [float(h.item()) for h in hc]
     if rank == 0:
         frames = B * world * args.steps
