@@ -12,12 +12,46 @@ What is compared, per frame (north_star: "peak indices / limb assignments bit-ex
   limbs    for paired skeletons, a joint agrees when it is absent in both or within 0.5 px in both: limb_match.
   3D       over paired skeletons and joints present in both: |dX,dY,dZ| in cm -> mpjpe_cm (mean Euclidean), max_joint_err_cm,
            and root_z_max_err_cm.
+  ties     "Same peaks" between two floating-point forwards is only defined down to the forwards' own resolution: a candidate
+           that clears the 0.2 threshold, or beats its best neighbour, by less than the maps' rounding noise is decided by the
+           summation order (the fp32 CPU forward is itself ~1e-6 of the map scale away from an fp64 one; cuDNN's would be
+           too).  So every peak present in only one path is looked up in the REFERENCE map: its decision margin
+           |v - max(threshold, best neighbour)| relative to the map scale.  peaks_differing counts them,
+           peaks_differing_max_margin is the largest such margin (a genuinely different peak would show ~1e-2), and
+           peaks_clear_mismatch counts those above NEAR_TIE = 1e-5 (~4x the split-precision map error): the number that
+           must be ZERO.
 """
 import numpy as np
 import torch
 
 NJ = 15
 TOL_PX = 0.5
+NEAR_TIE = 1e-5          # decision margin (relative to the key-point map scale) below which a peak is a floating-point tie
+THRESHOLD = 0.2          # association.cpp:55 nms threshold on the /255-scaled maps
+MAXP = 127
+
+
+def peak_pixels(kp):
+    """kp [15,H,W] scaled key-point maps -> set of (c, y, x): nmsRegisterKernel's rule (strict > threshold and all 8
+    neighbours, interior pixels only), first 127 per channel in raster order (nmsBase.cu:10-60,137-175)."""
+    v = torch.from_numpy(np.ascontiguousarray(kp, np.float32))
+    nb = torch.nn.functional.unfold(v[:, None], 3).view(v.shape[0], 9, v.shape[1] - 2, v.shape[2] - 2)
+    centre, others = nb[:, 4], torch.cat([nb[:, :4], nb[:, 5:]], 1).max(1).values
+    mask = ((centre > THRESHOLD) & (centre > others)).numpy()
+    out = set()
+    for c in range(mask.shape[0]):
+        ys, xs = np.nonzero(mask[c])
+        for y, x in list(zip(ys, xs))[:MAXP]:
+            out.add((c, int(y) + 1, int(x) + 1))
+    return out
+
+
+def decision_margin(kp_ref, c, y, x):
+    """|value - max(threshold, best neighbour)| of pixel (c, y, x) in the reference key-point maps, relative to their scale."""
+    v = float(kp_ref[c, y, x])
+    win = kp_ref[c, y - 1:y + 2, x - 1:x + 2].astype(np.float64).copy()
+    win[1, 1] = -np.inf
+    return abs(v - max(THRESHOLD, float(win.max()))) / max(float(np.abs(kp_ref).max()), 1e-30)
 
 
 def reference_path(sd, imgs, cams, root_idx=2, threads=None, refine=None):
@@ -90,10 +124,14 @@ def compare(hip, ref, root_idx=2):
     n_j = m_j = 0
     errs, rz_errs = [], []
     worst_frame = None
+    margins = []
     maps = {"hms": 0.0, "det_d": 0.0, "root_d": 0.0}
     for f, (a, b) in enumerate(zip(hip, ref)):
         for k in maps:                                                  # backbone: max |d| / max |ref| per output
             maps[k] = max(maps[k], float(np.abs(a[k] - b[k]).max() / max(np.abs(b[k]).max(), 1e-30)))
+        if "hms" in a and "hms" in b:                                   # peaks present in one path only: how close was the call?
+            pa, pb = peak_pixels(a["hms"][:NJ]), peak_pixels(b["hms"][:NJ])
+            margins.extend(decision_margin(b["hms"][:NJ], *p) for p in pa ^ pb)
         for c in range(NJ):
             na, nb = int(a["peaks"][c, 0, 0]), int(b["peaks"][c, 0, 0])
             n_pk += max(na, nb)
@@ -122,6 +160,8 @@ def compare(hip, ref, root_idx=2):
     return {
         "frames": len(hip), "peaks_ref": int(sum(int(b["peaks"][c, 0, 0]) for b in ref for c in range(NJ))),
         "peak_match": m_pk / n_pk if n_pk else 1.0, "peaks_unmatched": int(n_pk - m_pk),
+        "peaks_differing": len(margins), "peaks_differing_max_margin": float(max(margins)) if margins else 0.0,
+        "peaks_clear_mismatch": int(sum(m > NEAR_TIE for m in margins)),
         "persons_ref": int(sum(len(b["bodys"]) for b in ref)), "person_match": m_pe / n_pe if n_pe else 1.0,
         "limb_match": m_j / n_j if n_j else 1.0, "joints_compared": int(errs.size),
         "mpjpe_cm": float(errs.mean()) if errs.size else 0.0, "max_joint_err_cm": float(errs.max()) if errs.size else 0.0,

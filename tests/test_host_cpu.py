@@ -138,6 +138,7 @@ def test_parity_compare_counts_what_it_says():
 
     same = parity.compare([frame()], [frame()])
     assert same["peak_match"] == same["person_match"] == same["limb_match"] == 1.0 and same["max_joint_err_cm"] == 0.0
+    assert same["peaks_differing"] == 0 and same["peaks_clear_mismatch"] == 0
     assert same["peaks_ref"] == 60 and same["persons_ref"] == 2 and same["joints_compared"] == 30
     sub = parity.compare([frame(shift=0.2, z_err=0.05)], [frame()])           # sub-pixel shift: still the same peaks
     assert sub["peak_match"] == 1.0 and sub["limb_match"] == 1.0
@@ -146,6 +147,30 @@ def test_parity_compare_counts_what_it_says():
     assert moved["peak_match"] < 0.5 and moved["person_match"] == 0.0
     lost = parity.compare([frame(drop_person=True)], [frame()])
     assert lost["person_match"] == 0.5 and lost["peak_match"] == 1.0
+
+
+def test_peak_ties_are_told_from_real_mismatches():
+    """A candidate that clears the threshold by 1e-7 of the map scale in one path and misses it in the other is a floating-
+    point tie; one that differs by 1e-2 is a mismatch."""
+    from benchkit import parity
+    rng = np.random.default_rng(5)
+    base = rng.uniform(0.0, 0.1, (43, 32, 48)).astype(np.float32)
+    base[3, 10, 20], base[7, 20, 30] = 0.9, 0.5                     # two clear peaks (scale = 0.9)
+
+    def frame(hms):
+        peaks = np.zeros((15, 128, 3), np.float32)
+        return dict(peaks=peaks, bodys=np.zeros((0, 15, 4), np.float32), p2=np.zeros((0, 15, 4)), p3=np.zeros((0, 15, 4)),
+                    rz=np.zeros((0,)), hms=hms, det_d=np.ones((1, 2, 2), np.float32), root_d=np.ones((2, 2), np.float32))
+
+    assert parity.peak_pixels(base[:15]) == {(3, 10, 20), (7, 20, 30)}
+    tie_ref, tie_hip = base.copy(), base.copy()
+    tie_ref[5, 8, 8], tie_hip[5, 8, 8] = 0.2 + 2e-7, 0.2 - 2e-7      # just above / just below the 0.2 threshold
+    m = parity.compare([frame(tie_hip)], [frame(tie_ref)])
+    assert m["peaks_differing"] == 1 and m["peaks_clear_mismatch"] == 0 and m["peaks_differing_max_margin"] < 1e-6
+    bad_hip = base.copy()
+    bad_hip[7, 20, 30] = 0.1                                          # a clear peak lost
+    m = parity.compare([frame(bad_hip)], [frame(base)])
+    assert m["peaks_differing"] == 1 and m["peaks_clear_mismatch"] == 1 and m["peaks_differing_max_margin"] > 0.1
 
 
 def test_people_weights_are_calibrated_data_not_weights():
