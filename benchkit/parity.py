@@ -54,10 +54,11 @@ def decision_margin(kp_ref, c, y, x):
     return abs(v - max(THRESHOLD, float(win.max()))) / max(float(np.abs(kp_ref).max()), 1e-30)
 
 
-def reference_path(sd, imgs, cams, root_idx=2, threads=None, refine=None):
+def reference_path(sd, imgs, cams, root_idx=2, threads=None, refine=None, flip_pair=None):
     """imgs [B,3,H,W] fp32 CPU, cams [B,9] -> list of per-frame dicts (peaks, bodys, p2, p3, rz, hms, det_d, root_d).
     refine = (W[5] [out,in], b[5]) BN-folded RefineNet weights (numpy): p3 becomes the refined pose (BASELINE configs[4],
-    test_util.py:102-131)."""
+    test_util.py:102-131).  flip_pair (43 channel indices): the flip-TTA of test.py:55-70 -- a second forward on the
+    mirrored image, merged by the reference's channel loop (restated here in torch fp32, same operation order)."""
     from oracle import oracle_lib as O
     from oracle.backbone_ref import smap_forward
     if threads:
@@ -66,6 +67,13 @@ def reference_path(sd, imgs, cams, root_idx=2, threads=None, refine=None):
     with torch.no_grad():
         for i in range(imgs.shape[0]):                      # frame by frame: bounded memory, same numbers (eval-mode BN)
             hms, det_d, root_d = smap_forward(sd, imgs[i:i + 1])
+            if flip_pair is not None:
+                hf = smap_forward(sd, torch.flip(imgs[i:i + 1], [-1]))[0]
+                flipped = torch.flip(hf, [-1])[:, list(flip_pair)]
+                sign = torch.ones(len(flip_pair))
+                sign[NJ::2] = -1.0                             # PAF-x channels change sign under mirroring
+                hms = hms + flipped * sign.view(1, -1, 1, 1)
+                hms[:, NJ:] *= 0.5                             # only the PAF channels are averaged (test.py:66-69)
             hms = hms[0].clone()
             hms[:NJ] /= 255                                  # test.py:111-112
             hms[NJ:] /= 127
@@ -78,11 +86,16 @@ def reference_path(sd, imgs, cams, root_idx=2, threads=None, refine=None):
     return outs
 
 
-def hip_path(net, imgs_dev, cams, root_idx=2, refine=None):
+def hip_path(net, imgs_dev, cams, root_idx=2, refine=None, flip_pair=None):
     """The product path through its public pieces (model.smap.SMAP -> dapalib batch entry points), per-frame numpy.
-    refine = RefineNet.folded(device) -> the refined pose replaces p3."""
+    refine = RefineNet.folded(device) -> the refined pose replaces p3; flip_pair -> the engine that runs the flip-TTA inside
+    its schedule (what PosePipeline(do_flip=True) uses)."""
     from smap_amd import dapalib
-    hms, det_d, root_d = net(imgs_dev)
+    if flip_pair is not None:
+        B, _, H, W = imgs_dev.shape
+        hms, det_d, root_d = net.engine(B, H, W, imgs_dev.device, flip_pair=flip_pair).run(imgs_dev.float().contiguous())
+    else:
+        hms, det_d, root_d = net(imgs_dev)
     hms = hms.clone()
     dapalib.scale_hms_(hms)
     bodys, counts, peaks, _ = dapalib.connect_batch(hms, root_d, root_idx, True, return_intermediate=True)

@@ -135,6 +135,27 @@ def test_split_precision_more_frames(seed):
     _assert_north_star(m)
 
 
+def test_split_precision_flip_tta_end_to_end():
+    """The reference's SHIPPED setting (test.sh: --do_flip 1): HIP engine with the flip-TTA inside its schedule -> association ->
+    lifting vs the reference path with its second, mirrored forward and channel-loop merge (test.py:55-70) on the CPU."""
+    from benchkit.workload import PEOPLE_CAM
+    from exps.stage3_root2.config import cfg
+    kpt = cfg.DATASET.KEYPOINT.NUM
+    pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
+    net, sd, imgs = _setup("smooth")
+    nb = 4                                           # 4 frames = 8 CPU forwards
+    net.precision = "x3"
+    net = net.to(DEV)
+    cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (nb, 1))
+    hip = parity.hip_path(net, imgs[:nb].to(DEV), cams, flip_pair=pair)
+    ref = parity.reference_path(sd, imgs[:nb], cams, threads=min(32, os.cpu_count() or 1), flip_pair=pair)
+    m = parity.compare(hip, ref)
+    m.update(precision="x3", weights="smooth", batch=nb, flip_tta=True)
+    _dump("e2e_parity_x3_flip.json", m)
+    assert m["peaks_ref"] >= 20 * nb                 # the summed key-point maps sit higher: more candidates, capped at 127
+    _assert_north_star(m)
+
+
 def test_split_precision_with_refinenet_batch_of_8():
     """BASELINE configs[4]: batch 8 + RefineNet post-refinement, end to end against the reference path with the oracle's
     RefineNet (fp32 MLP; 1 ulp-level differences in the GEMM order): refined 3D joints within 1e-3 m."""
