@@ -467,6 +467,9 @@ def main():
                                       "backbone: fp16 storage / fp32 MFMA accumulate (~2e-3 relative on the maps)") +
                                      "; heads fp32; association fp32 (+f64 where the reference is); lifting f64",
                        "weights": "by-key recipe, stage-2 heads calibrated to ~24 peaks per key-point channel (benchkit/workload.py)",
+                       "precision_modes": "x3 (this line unless --precision f16): meets the reference's fp32 results end to end "
+                                          "(e2e_parity below); f16: ~2x the frames/s, ~0.36 cm mean / 1.06 cm max joint error at 3 m "
+                                          "(profiles/r2_final_bench_f16.json) -- not within the 1e-3 m of the north star",
                        "pipeline": f"post-processing of batch k overlaps later backbones; {args.depth} backbone(s) in flight; "
                                    f"one end-of-run gather of the records",
                        "association_lift_us_per_batch": {k: float(np.median(v)) for k, v in sorted(post_us.items())},
