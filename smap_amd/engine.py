@@ -289,6 +289,8 @@ class Graph:
         else:
             wk = torch.zeros((cout_pad, K), dtype=torch.float16)
             wk[:cout] = w.permute(0, 2, 3, 1).reshape(cout, K).to(torch.float16)
+            if not torch.isfinite(wk).all():
+                raise ValueError(f"{name}: folded weights exceed the fp16 range (max |w| = {float(w.abs().max()):.3g})")
         bk = torch.zeros((cout_pad,), dtype=torch.float32)
         bk[:cout] = b.to(torch.float32)
         out = self.tensor(name, Ho, Wo, _rup(cout, 8), 4 if out_fp32 else 2)
