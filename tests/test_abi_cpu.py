@@ -63,13 +63,14 @@ def test_smap_forward_has_no_cpu_path():
 
 
 def test_product_never_imports_oracle():
-    """The oracle is test infrastructure: nothing under the product tree may reference it."""
+    """The oracle and benchkit (workloads + the end-to-end checker, which imports the oracle) are test / bench
+    infrastructure: nothing under the product tree may reference them."""
     bad = []
     for base in ("smap_amd", "model", "exps", "dataset", "lib", "dapalib.py"):
         p = os.path.join(ROOT, base)
         files = [p] if os.path.isfile(p) else [os.path.join(d, f) for d, _, fs in os.walk(p) for f in fs
                                                if f.endswith((".py", ".hip", ".h", ".cpp"))]
         for f in files:
-            if re.search(r"^\s*(from|import)\s+oracle\b|oracle_lib|smap_oracle", open(f).read(), flags=re.M):
+            if re.search(r"^\s*(from|import)\s+(oracle|benchkit)\b|oracle_lib|smap_oracle", open(f).read(), flags=re.M):
                 bad.append(f)
     assert not bad, bad
