@@ -20,6 +20,7 @@ SOURCES = [
     ("assoc.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
     ("conv3.hip", []),
+    ("convp.hip", []),
     ("plan.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),

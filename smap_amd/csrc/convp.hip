@@ -1,0 +1,381 @@
+// convp.hip -- conv_bn_relu (model/smap.py:13-45) as a PERSISTENT, wave-specialised implicit GEMM for gfx950
+// (tile ids 60..69).  Same GEMM view, operand layouts and LDS image as conv.hip (NHWC fp16 or fp16 hi/lo pairs,
+// weights [cout_pad][KH][KW][Cin], 64-byte LDS rows of one BK = 32 chunk with the source-side XOR swizzle); what
+// differs is who does what, and for how long:
+//
+//   * ONE workgroup per CU, alive for the whole launch: it walks a contiguous range of the M x N tiles, the N tiles of
+//     one M tile back to back (their activation rows are then re-read from the XCD's L2, not from HBM).
+//   * 4 LOADER waves issue every LDS-DMA (global_load_lds) of the launch and nothing else.  They run ahead of the
+//     multiplying waves by STAGES-1 K tiles ACROSS tile boundaries: while the compute waves are in the epilogue of tile
+//     t, the first K tiles of tile t+1 are already landing.  A loader's vmcnt only ever counts its own loads, in issue
+//     order, so the counted s_waitcnt stays valid from the first K tile of the launch to the last (a wave that also
+//     stores cannot do that: loads and stores share vmcnt and retire out of order with respect to each other).
+//   * WM x WN COMPUTE waves (two per SIMD) only read LDS, multiply and run the epilogue.  One raw s_barrier per K tile
+//     joins the two groups: the loaders arrive once "K tile g has landed", the compute waves once "K tile g-1 is read".
+//   * The epilogue stays in REGISTERS: the MFMA takes the WEIGHT fragment as its first operand, so a lane ends up with
+//     4 consecutive channels of one pixel per accumulator group; one v_permlane32_swap per dword pairs the two
+//     half-waves up to 8 consecutive channels = one 16-byte NHWC store per plane (and 16-byte residual / addend loads
+//     of the same shape).  No LDS transpose, no epilogue barrier, so the whole LDS is K-tile ring.
+//
+// Supported epilogues: bias, residual, ReLU, post-ReLU addends, fp16 / split fp16 outputs (no fused bilinear add, no
+// fp32 output: plan.hip::validate keeps those ops on conv.hip tiles).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "smap_hip.h"
+#include "plan.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+constexpr int P_NLW = 4;          // loader waves
+constexpr int P_BK = 32;          // halves per K chunk
+constexpr int P_ROWB = P_BK * 2;  // bytes per LDS row
+constexpr int P_SPR = P_ROWB / 16;     // 16-byte slots per row
+constexpr int P_RPW = 64 / P_SPR;      // rows per wave-wide LDS-DMA instruction (16)
+constexpr int P_RPR = P_NLW * P_RPW;   // rows per round of the four loader waves (64)
+constexpr int P_BIAS_MAX = 2048;       // output channels (cout_pad) the LDS bias table holds
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool X3>
+__global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const ConvArgs a, const int tiles_total)
+{
+    constexpr int NPL = X3 ? 2 : 1;
+    constexpr int NCW = WM * WN;
+    static_assert(BM % P_RPR == 0 && BN % P_RPR == 0, "tile must be a multiple of the DMA round");
+    constexpr int LA = BM / P_RPR, LB = BN / P_RPR;
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+    static_assert(MI >= 1 && NI >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave grid");
+    constexpr int STAGE = NPL * (BM + BN) * P_ROWB;
+    constexpr int LPT = NPL * (LA + LB);                          // LDS-DMA instructions per loader thread per K tile
+    static_assert(STAGES >= 2 && (STAGES - 2) * LPT <= 63, "vmcnt is 6 bits");
+    constexpr int RING = STAGES * STAGE;
+    static_assert(RING + P_BIAS_MAX * 4 <= 160 * 1024, "LDS is 160 KiB per CU");
+    __shared__ __attribute__((aligned(16))) char smem[RING + P_BIAS_MAX * 4];      // K-tile ring | bias / acc_scale of every output channel
+
+    SMAP_TL_BEGIN
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // this workgroup's contiguous range of logical tiles; logical -> (m_tile, n_tile) with n fastest
+    int t_begin, t_count;
+    {
+        const int G = gridDim.x, b = blockIdx.x;
+        const int q = tiles_total / G, r = tiles_total - q * G;
+        t_begin = b * q + (b < r ? b : r);
+        t_count = q + (b < r ? 1 : 0);
+    }
+    const int kt_per_tile = a.ksize * a.ksize * (a.Cin / P_BK);
+    const int g_total = t_count * kt_per_tile;                    // K tiles this workgroup walks (= barriers per wave)
+
+    // bias table: the accumulators START at bias / acc_scale (acc_scale is a power of two: exact), so the epilogue
+    // needs no per-channel load at all
+    {
+        float* sbias = reinterpret_cast<float*>(smem + RING);
+        const float inv = X3 ? 1.f / a.acc_scale : 1.f;
+        for (int i = tid; i < a.n_tiles * BN; i += (NCW + P_NLW) * 64) sbias[i] = a.bias[i] * inv;
+        __syncthreads();
+    }
+
+    if (wave >= NCW) {
+        // =============================================================== loader waves
+        const int lw = wave - NCW;
+        const int lrow = lane / P_SPR, lslot = lane % P_SPR;
+        const int srow = lw * P_RPW + lrow;                       // row inside a DMA round
+        const int gch = lslot ^ ((srow >> 2) & 3);                // K granule this lane fetches (source-side swizzle)
+        const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
+        const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
+        const int HoWo = a.Ho * a.Wo;
+        const int cchunks = a.Cin / P_BK;
+
+        unsigned b_off[LB], a_off[LA], a_mask[LA], a_cur[LA];
+        int s_kh = 0, s_kw = 0, s_cc = 0, s_tile = 0;             // issue cursor (wave-uniform)
+        unsigned s_boff = 0;
+        auto set_tap = [&]() {
+            const unsigned tap_off = (unsigned)((s_kh * a.W + s_kw) * a.in_stride_c * 2);
+            const unsigned bit = 1u << (s_kh * a.ksize + s_kw);
+#pragma unroll
+            for (int i = 0; i < LA; ++i) a_cur[i] = (a_mask[i] & bit) ? a_off[i] + tap_off : 0u;
+        };
+        auto setup_tile = [&]() {                                 // geometry of logical tile t_begin + s_tile
+            const int logical = t_begin + s_tile;
+            const int m_tile = logical / a.n_tiles, n_tile = logical - m_tile * a.n_tiles;
+            const int m0 = m_tile * BM, n0 = n_tile * BN;
+#pragma unroll
+            for (int i = 0; i < LB; ++i) b_off[i] = (unsigned)(((n0 + i * P_RPR + srow) * a.K + gch * 8) * 2);
+            int m = m0 + srow;
+            int b = m / HoWo, rem = m - b * HoWo;
+            int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                a_off[i] = 0;
+                a_mask[i] = 0;
+                if (m < a.M) {
+                    const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+                    const long long e = ((long long)(b * a.H + iy0) * a.W + ix0) * a.in_stride_c + a.in_c_off + gch * 8;
+                    a_off[i] = (unsigned)(a.in_off + e * 2);      // wraps for taps above / left of the image: only used when the tap is valid
+                    unsigned vx = 0, mk = 0;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        if (kw < a.ksize && (unsigned)(ix0 + kw) < (unsigned)a.W) vx |= 1u << kw;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+                        if (kh < a.ksize && (unsigned)(iy0 + kh) < (unsigned)a.H) mk |= vx << (kh * a.ksize);
+                    a_mask[i] = mk;
+                }
+                m += P_RPR;
+                ox += P_RPR;
+                while (ox >= a.Wo) { ox -= a.Wo; ++oy; }
+                while (oy >= a.Ho) { oy -= a.Ho; ++b; }
+            }
+            s_kh = s_kw = s_cc = 0;
+            s_boff = 0;
+            set_tap();
+        };
+        auto issue = [&](int buf) {                               // all loads of one K tile, then move the cursor
+            char* sbase = smem + buf * STAGE;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                char* sA = sbase + pl * BM * P_ROWB;
+                const char* gA = arena + (unsigned)(s_cc * P_ROWB + (X3 ? pl * a.in_lo * 2 : 0));   // a_cur = 0: zero page
+#pragma unroll
+                for (int i = 0; i < LA; ++i)
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * P_RPR + lw * P_RPW) * P_ROWB), 16, 0, 0);
+            }
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                char* sB = sbase + (NPL * BM + pl * BN) * P_ROWB;
+                const char* gB = wt + s_boff + (X3 ? (long long)pl * a.w_lo : 0LL);
+#pragma unroll
+                for (int i = 0; i < LB; ++i)
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * P_RPR + lw * P_RPW) * P_ROWB), 16, 0, 0);
+            }
+            s_boff += P_ROWB;
+            if (++s_cc == cchunks) {
+                s_cc = 0;
+                if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; }
+                if (s_kh == a.ksize) {                            // tile done: next tile of this workgroup
+                    if (++s_tile < t_count) setup_tile();
+                } else {
+                    set_tap();
+                }
+            }
+        };
+        setup_tile();
+#pragma unroll
+        for (int st = 0; st < STAGES - 1; ++st)
+            if (st < g_total) issue(st);
+        int nbuf = STAGES - 1;
+        for (int g = 0; g < g_total; ++g) {
+            if (g + STAGES - 1 <= g_total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // K tile g is published; K tile g-1 has been read
+            asm volatile("" ::: "memory");
+            if (g + STAGES - 1 < g_total) issue(nbuf);
+            nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
+        }
+    } else {
+        // =============================================================== compute waves
+        const int wm = wave / WN, wn = wave - wm * WN;
+        const int l31 = lane & 31, lhi = lane >> 5;
+        const int rswz = (l31 >> 2) & 3;
+        const int p_row0 = wm * (BM / WM) + l31;                  // + mi*32: pixel rows of the A image
+        const int c_row0 = wn * (BN / WN) + l31;                  // + ni*32: channel rows of the W image
+        int buf = 0;
+        for (int t = 0; t < t_count; ++t) {
+            const int logical = t_begin + t;
+            const int m_tile = logical / a.n_tiles, n_tile = logical - m_tile * a.n_tiles;
+            const int m0 = m_tile * BM, n0 = n_tile * BN;
+            f32x16 acc[NI][MI];                                   // rows = channels (weights are the first MFMA operand), columns = pixels
+            {
+                const float* sbias = reinterpret_cast<const float*>(smem + RING) + n0 + wn * (BN / WN) + 4 * lhi;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(sbias + ni * 32 + 8 * g);
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            acc[ni][mi][4 * g + 0] = b4.x; acc[ni][mi][4 * g + 1] = b4.y;
+                            acc[ni][mi][4 * g + 2] = b4.z; acc[ni][mi][4 * g + 3] = b4.w;
+                        }
+                    }
+            }
+            for (int kt = 0; kt < kt_per_tile; ++kt) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const char* sA = smem + buf * STAGE;
+                const char* sB = sA + NPL * BM * P_ROWB;
+#pragma unroll
+                for (int kk = 0; kk < P_BK / 16; ++kk) {
+                    const int slot = ((kk * 2 + lhi) ^ rswz) * 16;
+                    half8 pf[NPL][MI], wf[NPL][NI];
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+                            pf[pl][mi] = *reinterpret_cast<const half8*>(sA + (pl * BM + p_row0 + mi * 32) * P_ROWB + slot);
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            wf[pl][ni] = *reinterpret_cast<const half8*>(sB + (pl * BN + c_row0 + ni * 32) * P_ROWB + slot);
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            if (X3) {       // small cross terms first, then hi*hi (same order as conv.hip)
+                                acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][ni], pf[NPL - 1][mi], acc[ni][mi], 0, 0, 0);
+                                acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[NPL - 1][ni], pf[0][mi], acc[ni][mi], 0, 0, 0);
+                            }
+                            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][ni], pf[0][mi], acc[ni][mi], 0, 0, 0);
+                        }
+                }
+                buf = buf + 1 == STAGES ? 0 : buf + 1;
+            }
+
+            // ---- register epilogue.  acc[ni][mi][4*g + e] = channel c0 + 8*g + 4*lhi + e of pixel l31; after the
+            //      half-wave swap of the group pairs (2j, 2j+1), acc[ni][mi][8*j .. 8*j+7] are the 8 consecutive channels
+            //      c0 + 16*j + 8*lhi .. +7 of that pixel: one 16-byte access per plane.  Everything below works in place
+            //      on the accumulators, one tensor at a time: all loads of a tensor go out before the first is used.
+            constexpr int NCH = NI * MI * 2;                      // (pixel, 8-channel) chunks per lane
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned x = __builtin_bit_cast(unsigned, acc[ni][mi][8 * j + e]);
+                            const unsigned y = __builtin_bit_cast(unsigned, acc[ni][mi][8 * j + 4 + e]);
+                            const auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+                            acc[ni][mi][8 * j + e] = (X3 ? a.acc_scale : 1.f) * __builtin_bit_cast(float, (unsigned)sw[0]);
+                            acc[ni][mi][8 * j + 4 + e] = (X3 ? a.acc_scale : 1.f) * __builtin_bit_cast(float, (unsigned)sw[1]);
+                        }
+            unsigned m_dense[MI], m_out[MI];                      // per-pixel element offsets (32-bit: plan.hip::validate bounds the tensors)
+            bool m_ok[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = m0 + wm * (BM / WM) + mi * 32 + l31;
+                m_ok[mi] = m < a.M;
+                const unsigned ms = m_ok[mi] ? (unsigned)m : 0u;  // clamped: loads stay in bounds
+                m_dense[mi] = ms * (unsigned)(NPL * a.Cout8);
+                m_out[mi] = ms * (unsigned)a.out_stride_c + (unsigned)a.out_c_off;
+            }
+            const int n_lane = n0 + wn * (BN / WN) + 8 * lhi;     // + ni*32 + 16*j
+            auto add_tensor = [&](const _Float16* __restrict__ t) {
+                half8 h[NCH][NPL];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int c = (mi * NI + ni) * 2 + j;
+                            const int n = n_lane + ni * 32 + 16 * j;
+                            const unsigned off = m_dense[mi] + (n < a.Cout8 ? (unsigned)n : 0u);
+#pragma unroll
+                            for (int pl = 0; pl < NPL; ++pl) h[c][pl] = *reinterpret_cast<const half8*>(t + off + pl * a.Cout8);
+                        }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int c = (mi * NI + ni) * 2 + j;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                acc[ni][mi][8 * j + e] += X3 ? (float)h[c][0][e] + (float)h[c][NPL - 1][e] : (float)h[c][0][e];
+                        }
+            };
+            if (a.res) add_tensor(a.res);
+            if (a.relu) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[ni][mi][r] = acc[ni][mi][r] > 0.f ? acc[ni][mi][r] : 0.f;
+            }
+            if (a.add1) add_tensor(a.add1);
+            if (a.add2) add_tensor(a.add2);
+            _Float16* __restrict__ outp = reinterpret_cast<_Float16*>(a.out);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)                       // the chunks of one pixel back to back: they complete its 128-byte lines
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int n = n_lane + ni * 32 + 16 * j;
+                        if (!(m_ok[mi] && n < a.Cout8)) continue;
+                        _Float16* op = outp + (m_out[mi] + (unsigned)n);
+                        half8 h;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = (_Float16)acc[ni][mi][8 * j + e];
+                        *reinterpret_cast<half8*>(op) = h;
+                        if (X3) {       // lo plane: what fp16 dropped (v - hi is exact in fp32)
+                            half8 l;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) l[e] = (_Float16)(acc[ni][mi][8 * j + e] - (float)h[e]);
+                            *reinterpret_cast<half8*>(op + a.out_lo) = l;
+                        }
+                    }
+        }
+    }
+    SMAP_TL_END(a)
+}
+
+int cu_count()
+{
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool X3>
+hipError_t launchp(const ConvArgs& a, hipStream_t st)
+{
+    const int tiles = a.m_tiles * a.n_tiles;
+    const int cus = cu_count();
+    const int grid = tiles < cus ? tiles : cus;
+    hipLaunchKernelGGL((convp_kernel<BM, BN, WM, WN, STAGES, X3>), dim3(grid), dim3((WM * WN + P_NLW) * 64), 0, st, a, tiles);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int smap_convp_tile_dims(int tile, int* bm, int* bn)
+{
+    switch (tile) {
+        case 60: *bm = 128; *bn = 256; return 0;      // 8 compute waves of 64 px x 64 ch
+        case 61: *bm = 256; *bn = 128; return 0;
+        case 62: *bm = 128; *bn = 128; return 0;      // 8 compute waves of 32 px x 64 ch
+        default: return -1;
+    }
+}
+
+hipError_t smap_launch_convp(const ConvArgs& a, int tile, hipStream_t st)
+{
+    if (a.up || a.out_fp32) return hipErrorInvalidValue;
+    if (a.x3) {
+        switch (tile) {
+            case 60: return launchp<128, 256, 2, 4, 3, true>(a, st);     // 3 x 48 KiB
+            case 61: return launchp<256, 128, 4, 2, 3, true>(a, st);     // 3 x 48 KiB
+            case 62: return launchp<128, 128, 4, 2, 4, true>(a, st);     // 4 x 32 KiB
+            default: return hipErrorInvalidValue;
+        }
+    }
+    switch (tile) {
+        case 60: return launchp<128, 256, 2, 4, 4, false>(a, st);        // 4 x 24 KiB
+        case 61: return launchp<256, 128, 4, 2, 4, false>(a, st);
+        case 62: return launchp<128, 128, 4, 2, 4, false>(a, st);        // 4 x 16 KiB
+        default: return hipErrorInvalidValue;
+    }
+}

@@ -58,6 +58,8 @@ int smap_conv_tile_has_x3(int tile);                                        // c
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st);
 int smap_conv3_tile_dims(int tile, int* bm, int* bn);                       // conv3.hip (tile ids 30..33, halo-tiled 3x3)
 hipError_t smap_launch_conv3(const ConvArgs& a, int tile, hipStream_t st);
+int smap_convp_tile_dims(int tile, int* bm, int* bn);                       // convp.hip (tile ids 60..69, persistent wave-specialised GEMM)
+hipError_t smap_launch_convp(const ConvArgs& a, int tile, hipStream_t st);
 
 #ifdef SMAP_TIMELINE
 // every workgroup of a conv kernel calls these two (first / last statement): 100 MHz device-wide clock

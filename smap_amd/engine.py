@@ -44,7 +44,9 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          # 50..54: csrc/conv.hip with EIGHT waves per workgroup (two per SIMD from one workgroup: the low-resolution layers)
          50: (128, 128), 51: (128, 128), 52: (128, 128), 53: (256, 128), 54: (128, 256),
          # 55..57: 4-stage pipelines (three K tiles in flight per workgroup: bytes in flight, not occupancy, for the streaming layers)
-         55: (128, 128), 56: (128, 128), 57: (128, 128)}
+         55: (128, 128), 56: (128, 128), 57: (128, 128),
+         # 60..62: csrc/convp.hip, persistent workgroups with loader waves and a register epilogue (no fused bilinear add, no fp32 out)
+         60: (128, 256), 61: (256, 128), 62: (128, 128)}
 # (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
 #  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)
 
@@ -63,7 +65,7 @@ PLANES = (64, 128, 256, 512)
 ALIGN = 256
 ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
 PRECISIONS = ("f16", "x3")
-X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 56, 57)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
+X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 56, 57, 60, 61, 62)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
 
 
 def split_f16(w, scaled=True):
@@ -82,27 +84,44 @@ def split_f16(w, scaled=True):
 _TILE_TABLE_X3 = None
 
 
+def _table_entry(v):
+    """A table value is one tile id or a ranked list of them (best first): the specialised kernels do not take every op of
+    a shape (conv3.hip: plain 3x3 only; convp.hip: no fused bilinear add, no fp32 output), Graph.conv picks the first
+    entry that is legal for the op at hand."""
+    return [int(t) for t in v] if isinstance(v, (list, tuple)) else [int(v)]
+
+
+def tile_legal(tile, *, cout, cout_pad=None, plain3=True, up=False, out_fp32=False):
+    """Can tile id `tile` run an op with these properties?  Mirrors csrc/plan.hip::validate."""
+    if 30 <= tile < 40:
+        return plain3
+    if 60 <= tile < 70:
+        cp = cout_pad if cout_pad is not None else _rup(cout, TILES[tile][1])
+        return not up and not out_fp32 and cout % 8 == 0 and cp <= 2048
+    return True
+
+
 def pick_tile_x3(M, cout, key=None):
-    """Split precision: the measured table (tools/autotune.py --precision x3 -> smap_amd/tile_table_x3.json) when the
-    shape is in it, else the largest BK = 32 tile that still gives >= 512 workgroups / the one with most workgroups."""
+    """Split precision: candidates in order of preference -- the measured table (tools/autotune.py --precision x3 ->
+    smap_amd/tile_table_x3.json) when the shape is in it, then the largest BK = 32 tile that still gives >= 512
+    workgroups / the one with most workgroups."""
     global _TILE_TABLE_X3
     if _TILE_TABLE_X3 is None:
         import json
         path = os.environ.get("SMAP_TILE_TABLE_X3") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table_x3.json")
         _TILE_TABLE_X3 = json.load(open(path)) if os.path.exists(path) and not os.environ.get("SMAP_NO_TILE_TABLE") else {}
-    if key is not None and key in _TILE_TABLE_X3:
-        return int(_TILE_TABLE_X3[key])
+    cands = _table_entry(_TILE_TABLE_X3[key]) if key is not None and key in _TILE_TABLE_X3 else []
     if cout <= 32:
-        return 3
+        return cands + [3]
     best, best_blocks = None, -1
     for t in ((21, 22) if cout <= 64 else (20, 23, 21, 22)):
         bm, bn = TILES[t]
         blocks = -(-M // bm) * (-(-cout // bn))
         if blocks >= 512:
-            return t
+            return cands + [t]
         if blocks > best_blocks:
             best, best_blocks = t, blocks
-    return best
+    return cands + [best]
 
 
 def _rup(x, m):
@@ -200,7 +219,7 @@ def pick_tile(M, cout, key=None):
                 best, best_cost = t, cost
         return best
     if key is not None and key in _TILE_TABLE:
-        return int(_TILE_TABLE[key])
+        return _table_entry(_TILE_TABLE[key])[0]
     return pick_tile_heuristic(M, cout)
 
 
@@ -258,20 +277,20 @@ class Graph:
         Wo = (x.W + 2 * pad - ksize) // stride + 1
         nfr = self.B if frames is None else frames
         M = nfr * Ho * Wo
-        tile = pick_tile(M, cout, f"{nfr},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
-        tile = {**DEFAULT_REMAP, **_tile_remap()}.get(tile, tile)
+        key = f"{nfr},{x.H},{x.W},{cin},{cout},{ksize},{stride}"
+        plain3 = ksize == 3 and stride == 1 and res is None and add1 is None and add2 is None and up is None
+        legal = lambda t: tile_legal(t, cout=cout, plain3=plain3, up=up is not None, out_fp32=out_fp32)
         if self.x3:
-            tile = pick_tile_x3(M, cout, f"{nfr},{x.H},{x.W},{cin},{cout},{ksize},{stride}")
+            cands = pick_tile_x3(M, cout, key)
             x3t = os.environ.get("SMAP_X3_TILE", "")         # A/B hook: force one split-precision tile where it fits
             if x3t and cout > 32 and not (cout <= 64 and TILES[int(x3t)][1] > 64):
-                tile = int(x3t)
-        plain3 = ksize == 3 and stride == 1 and res is None and add1 is None and add2 is None and up is None
-        if 30 <= tile < 40 and not plain3 and self.x3:
-            tile = pick_tile_x3(M, cout)
-        elif self.x3:
-            pass
-        elif 30 <= tile < 40 and not plain3:                # the halo-tiled kernel has no fused epilogues (table keyed by shape only)
-            tile = pick_tile_heuristic(M, cout)
+                cands = [int(x3t)] + cands
+            tile = next(t for t in cands if legal(t))
+        else:
+            tile = pick_tile(M, cout, key)
+            tile = {**DEFAULT_REMAP, **_tile_remap()}.get(tile, tile)
+            if not legal(tile):                                 # the table is keyed by shape only
+                tile = pick_tile_heuristic(M, cout)
         halo = os.environ.get("SMAP_HALO3", "")     # A/B hook: "16" / "32" = pixel-tile width, optional ":64" / ":128" = BN
         if halo and plain3 and cout > 32:
             tw, _, hbn = halo.partition(":")

@@ -149,6 +149,13 @@ CASES = [
     (1, 32, 52, 256, 512, 1, 2, 53, False, True, True),
     (2, 16, 24, 64, 256, 1, 1, 54, True, False, False),
     (1, 16, 26, 64, 320, 3, 1, 54, True, True, True),
+    # persistent wave-specialised kernel (convp.hip, tile ids 60..62): register epilogue, loader waves
+    (2, 16, 24, 64, 256, 1, 1, 60, False, False, False),
+    (3, 10, 14, 192, 320, 3, 1, 60, True, True, True),       # ragged M, Cout not a tile multiple, every epilogue input
+    (2, 16, 24, 128, 128, 3, 2, 61, True, False, False),
+    (1, 32, 52, 256, 512, 1, 2, 61, False, True, True),
+    (8, 64, 104, 64, 256, 1, 1, 62, True, True, False),      # 832 tiles on <= 256 workgroups: the persistent walk
+    (2, 8, 12, 512, 256, 1, 1, 62, True, False, True),
     (3, 10, 14, 192, 320, 3, 1, 55, True, True, True),       # 4-stage pipelines (55..57)
     (2, 16, 24, 64, 256, 1, 1, 56, False, True, False),
     (2, 8, 12, 512, 256, 1, 1, 57, True, False, True),
@@ -208,6 +215,15 @@ X3_CASES = [
     (3, 10, 14, 192, 320, 3, 1, 55, True, True, True),
     (2, 16, 24, 64, 256, 1, 1, 56, False, True, False),
     (2, 8, 12, 512, 256, 1, 1, 57, True, False, True),
+    # persistent wave-specialised kernel (convp.hip)
+    (2, 16, 24, 64, 256, 1, 1, 60, False, False, False),
+    (3, 10, 14, 192, 320, 3, 1, 60, True, True, True),
+    (8, 64, 104, 128, 512, 1, 1, 60, True, True, False),     # 832 tiles on <= 256 workgroups, K = 4 tiles of 32
+    (2, 16, 24, 128, 128, 3, 2, 61, True, False, False),
+    (1, 32, 52, 256, 512, 1, 2, 61, False, True, True),
+    (8, 32, 52, 256, 256, 3, 1, 61, True, False, False),     # 3x3 taps through the persistent loader, tiles < workgroups
+    (8, 64, 104, 64, 256, 1, 1, 62, True, True, False),
+    (2, 8, 12, 2048, 256, 1, 1, 62, True, False, True),
     # halo-tiled 3x3 (conv3.hip) in split precision: 32-channel chunks, rows = [hi32 | lo32]
     (2, 16, 24, 64, 64, 3, 1, 30, True, False, False),
     (3, 10, 14, 192, 320, 3, 1, 31, True, False, False),

@@ -31,6 +31,12 @@ def main():
                     help="only revisit the shapes the specialised kernels cover: keep the tile of the existing table unless "
                          "a halo-tiled 3x3 (csrc/conv3.hip, ids 30..39) or weight-stationary 1x1 (csrc/conv1.hip, ids "
                          "40..41) variant is at least GAIN (e.g. 0.05) faster")
+    ap.add_argument("--convp", type=float, default=-1.0, metavar="GAIN",
+                    help="only measure the persistent wave-specialised tiles (csrc/convp.hip, ids 60..62) against the tile "
+                         "the existing table holds, cold (three rotating arenas); a shape's entry becomes the ranked list "
+                         "[convp tile, old tile] when the convp tile is at least GAIN faster (ops it cannot take -- fused "
+                         "bilinear add, fp32 output -- fall through to the old tile)")
+    ap.add_argument("--table", default="", help="existing table to start from (--convp / --halo); default: the shipped one")
     args = ap.parse_args()
     x3 = args.precision == "x3"
     if x3 and args.out == os.path.join(ROOT, "smap_amd", "tile_table.json"):
@@ -48,15 +54,18 @@ def main():
         p, x = op.p, op.inp
         key = (args.batch, x.H, x.W, p["Cin"], p["Cout"], p["ksize"], p["stride"])
         fused = op.res is not None or op.add1 is not None or op.add2 is not None or bool(op.aux)
-        shapes.setdefault(key, [0, op.res is not None, True])
+        shapes.setdefault(key, [0, op.res is not None, True, 0])
         shapes[key][0] += 1
         shapes[key][2] &= not fused                      # halo kernel: plain epilogue only
+        shapes[key][3] += int(not op.aux and not p["out_fp32"] and p["Cout"] % 8 == 0)    # ops convp.hip can take
     dev = torch.device("cuda:0")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     table, total_best, total_default = {}, 0.0, 0.0
-    old = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table.json"))) if args.halo else {}
+    convp = args.convp >= 0
+    shipped = args.table or os.path.join(ROOT, "smap_amd", "tile_table_x3.json" if x3 else "tile_table.json")
+    old = json.load(open(shipped)) if (args.halo or convp) else {}
     table.update(old)
-    for key, (count, has_res, plain) in sorted(shapes.items()):
+    for key, (count, has_res, plain, n_convp) in sorted(shapes.items()):
         B, H, W, Cin, Cout, k, s = key
         halo_ok = plain and k == 3 and s == 1
         skey = ",".join(map(str, key))
@@ -77,11 +86,20 @@ def main():
                 cands += [38, 39] if Cout <= 32 else [t for t in range(30, 38) if not (Cout <= 64 and TILES[t][1] > 64)]
         if args.halo:
             cands = [old[skey]] + [t for t in cands if t >= 30] + ([40, 41] if ws_ok else [])
+        if convp:
+            if not n_convp or skey not in old or Cout <= 32:
+                continue
+            old_t = old[skey][-1] if isinstance(old[skey], list) else old[skey]
+            cands = [old_t] + [t for t in (60, 61, 62) if not (Cout <= 64 and TILES[t][1] > 64) and
+                               (Cout + TILES[t][1] - 1) // TILES[t][1] * TILES[t][1] <= 2048]
         res = {}
         for t in cands:
             lib, h, arena, blob, flops, byts = build(B, H, W, Cin, Cout, k, s, t, int(has_res), dev, x3=x3)
-            run = lambda: L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()),
-                                                    None, st), "run")
+            arenas = [arena] + ([arena.clone(), arena.clone()] if convp else [])
+            def run(i=[0]):
+                ar = arenas[i[0] % len(arenas)]
+                i[0] += 1
+                L.check(lib.smap_plan_run(h, None, C.c_void_p(ar.data_ptr()), C.c_void_p(blob.data_ptr()), None, st), "run")
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
@@ -93,13 +111,23 @@ def main():
             torch.cuda.synchronize()
             res[t] = e0.elapsed_time(e1) * 1e3 / args.iters
             lib.smap_plan_destroy(h)
-            del arena, blob
+            del arena, blob, arenas
         best = min(res, key=res.get)
+        if convp:
+            old_t = cands[0]
+            print(key, "x%d (%d convp-able)" % (count, n_convp), {t: round(v, 1) for t, v in res.items()}, "best", best, flush=True)
+            if best != old_t and res[best] <= (1.0 - args.convp) * res[old_t]:
+                table[skey] = [best, old_t]
+                total_best += res[best] * n_convp + res[old_t] * (count - n_convp)
+            else:
+                total_best += res[old_t] * count
+            total_default += res[old_t] * count
+            continue
         if args.halo and res[best] > (1.0 - args.halo) * res[old[skey]]:
             best = old[skey]
         from smap_amd.engine import pick_tile_heuristic, pick_tile_x3
         Mo = B * ((H + 2 * (k // 2) - k) // s + 1) * ((W + 2 * (k // 2) - k) // s + 1)
-        dflt = pick_tile_x3(Mo, Cout) if x3 else pick_tile_heuristic(Mo, Cout)
+        dflt = pick_tile_x3(Mo, Cout)[-1] if x3 else pick_tile_heuristic(Mo, Cout)
         table[",".join(map(str, key))] = best
         total_best += res[best] * count
         total_default += res.get(dflt, res[best]) * count

@@ -25,6 +25,14 @@ PRESETS = {          # B, H, W, Cin, Cout, k, stride, tile, residual
     "L8": (8, 64, 104, 128, 128, 3, 1, 1, 0),     # layer2 3x3
     "L9": (8, 128, 208, 256, 43, 3, 1, 2, 0),     # last-stage keypoint/PAF head 3x3
     "L10": (8, 128, 208, 256, 14, 3, 1, 8, 0),    # last-stage head, Cout 14
+    "L11": (8, 64, 104, 512, 512, 1, 1, 0, 0),    # up3 skip1
+    "L12": (8, 64, 104, 512, 256, 1, 1, 0, 0),    # up3 lateral
+    "L13": (8, 32, 52, 1024, 1024, 1, 1, 0, 0),   # up2 skip1
+    "L14": (8, 32, 52, 1024, 256, 1, 1, 0, 0),    # layer3 c1
+    "L15": (8, 64, 104, 256, 512, 1, 1, 0, 0),    # up3 skip2
+    "L16": (8, 64, 104, 512, 128, 1, 1, 0, 0),    # layer2 c1
+    "L17": (8, 16, 26, 2048, 2048, 1, 1, 0, 0),   # up1 skip1
+    "L18": (8, 16, 26, 512, 2048, 1, 1, 0, 1),    # layer4 c3
 }
 
 
