@@ -38,6 +38,15 @@ constexpr int P_SPR = P_ROWB / 16;     // 16-byte slots per row
 constexpr int P_RPW = 64 / P_SPR;      // rows per wave-wide LDS-DMA instruction (16)
 constexpr int P_RPR = P_NLW * P_RPW;   // rows per round of the four loader waves (64)
 constexpr int P_BIAS_MAX = 2048;       // output channels (cout_pad) the LDS bias table holds
+#ifndef SMAP_CONVP_ABLATE
+#define SMAP_CONVP_ABLATE 0       // experiments only (tools/build_convp_variants.py): 1 no LDS-DMA, 2 no ds_read / MFMA, 4 no stores, 8 no epilogue
+#endif
+#ifdef SMAP_TRACE                 // diagnostics build: summed phase times of compute wave 0 / loader wave 0 per workgroup (s_memtime)
+#define PTIME() __builtin_amdgcn_s_memtime()
+#define PSTAMP(x) x
+#else
+#define PSTAMP(x)
+#endif
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool X3>
 __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const ConvArgs a, const int tiles_total)
@@ -137,7 +146,7 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
         auto issue = [&](int buf) {                               // all loads of one K tile, then move the cursor
             char* sbase = smem + buf * STAGE;
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
+            for (int pl = 0; pl < ((SMAP_CONVP_ABLATE & 1) ? 0 : NPL); ++pl) {
                 char* sA = sbase + pl * BM * P_ROWB;
                 const char* gA = arena + (unsigned)(s_cc * P_ROWB + (X3 ? pl * a.in_lo * 2 : 0));   // a_cur = 0: zero page
 #pragma unroll
@@ -145,7 +154,7 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
                     __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * P_RPR + lw * P_RPW) * P_ROWB), 16, 0, 0);
             }
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
+            for (int pl = 0; pl < ((SMAP_CONVP_ABLATE & 1) ? 0 : NPL); ++pl) {
                 char* sB = sbase + (NPL * BM + pl * BN) * P_ROWB;
                 const char* gB = wt + s_boff + (X3 ? (long long)pl * a.w_lo : 0LL);
 #pragma unroll
@@ -163,19 +172,30 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
                 }
             }
         };
+        PSTAMP(long long tr_vm = 0; long long tr_bar = 0; long long tr_iss = 0; const long long tr_begin = PTIME();)
         setup_tile();
 #pragma unroll
         for (int st = 0; st < STAGES - 1; ++st)
             if (st < g_total) issue(st);
         int nbuf = STAGES - 1;
         for (int g = 0; g < g_total; ++g) {
+            PSTAMP(const long long t0 = PTIME();)
             if (g + STAGES - 1 <= g_total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PSTAMP(const long long t1 = PTIME();)
             __builtin_amdgcn_s_barrier();                         // K tile g is published; K tile g-1 has been read
             asm volatile("" ::: "memory");
+            PSTAMP(const long long t2 = PTIME();)
             if (g + STAGES - 1 < g_total) issue(nbuf);
             nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
+            PSTAMP(tr_vm += t1 - t0; tr_bar += t2 - t1; tr_iss += PTIME() - t2;)
         }
+#ifdef SMAP_TRACE
+        if (a.dbg && lw == 0 && lane == 0) {
+            long long* d = a.dbg + (long long)blockIdx.x * 16 + 8;
+            d[0] = tr_begin; d[1] = PTIME(); d[2] = tr_vm; d[3] = tr_bar; d[4] = tr_iss; d[5] = g_total;
+        }
+#endif
     } else {
         // =============================================================== compute waves
         const int wm = wave / WN, wn = wave - wm * WN;
@@ -184,6 +204,7 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
         const int p_row0 = wm * (BM / WM) + l31;                  // + mi*32: pixel rows of the A image
         const int c_row0 = wn * (BN / WN) + l31;                  // + ni*32: channel rows of the W image
         int buf = 0;
+        PSTAMP(long long tr_bar = 0; long long tr_mma = 0; long long tr_epi = 0; const long long tr_begin = PTIME();)
         for (int t = 0; t < t_count; ++t) {
             const int logical = t_begin + t;
             const int m_tile = logical / a.n_tiles, n_tile = logical - m_tile * a.n_tiles;
@@ -204,12 +225,14 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
                     }
             }
             for (int kt = 0; kt < kt_per_tile; ++kt) {
+                PSTAMP(const long long t0 = PTIME();)
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                PSTAMP(const long long t1 = PTIME(); tr_bar += t1 - t0;)
                 const char* sA = smem + buf * STAGE;
                 const char* sB = sA + NPL * BM * P_ROWB;
 #pragma unroll
-                for (int kk = 0; kk < P_BK / 16; ++kk) {
+                for (int kk = 0; kk < ((SMAP_CONVP_ABLATE & 2) ? 0 : P_BK / 16); ++kk) {
                     const int slot = ((kk * 2 + lhi) ^ rswz) * 16;
                     half8 pf[NPL][MI], wf[NPL][NI];
 #pragma unroll
@@ -233,6 +256,12 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
                         }
                 }
                 buf = buf + 1 == STAGES ? 0 : buf + 1;
+                PSTAMP(tr_mma += PTIME() - t1;)
+            }
+            PSTAMP(const long long te0 = PTIME();)
+            if (SMAP_CONVP_ABLATE & 8) {
+                if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(a.out)[tid] = acc[0][0][1];   // keep acc live
+                continue;
             }
 
             // ---- register epilogue.  acc[ni][mi][4*g + e] = channel c0 + 8*g + 4*lhi + e of pixel l31; after the
@@ -248,11 +277,11 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const unsigned x = __builtin_bit_cast(unsigned, acc[ni][mi][8 * j + e]);
-                            const unsigned y = __builtin_bit_cast(unsigned, acc[ni][mi][8 * j + 4 + e]);
-                            const auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
-                            acc[ni][mi][8 * j + e] = (X3 ? a.acc_scale : 1.f) * __builtin_bit_cast(float, (unsigned)sw[0]);
-                            acc[ni][mi][8 * j + 4 + e] = (X3 ? a.acc_scale : 1.f) * __builtin_bit_cast(float, (unsigned)sw[1]);
+                            const float xf = acc[ni][mi][8 * j + e], yf = acc[ni][mi][8 * j + 4 + e];   // (bit_cast of a vector ELEMENT lvalue reads element 0)
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf), __float_as_uint(yf), false, false);
+                            const unsigned s0 = sw[0], s1 = sw[1];
+                            acc[ni][mi][8 * j + e] = (X3 ? a.acc_scale : 1.f) * __uint_as_float(s0);
+                            acc[ni][mi][8 * j + 4 + e] = (X3 ? a.acc_scale : 1.f) * __uint_as_float(s1);
                         }
             unsigned m_dense[MI], m_out[MI];                      // per-pixel element offsets (32-bit: plan.hip::validate bounds the tensors)
             bool m_ok[MI];
@@ -310,7 +339,7 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int n = n_lane + ni * 32 + 16 * j;
-                        if (!(m_ok[mi] && n < a.Cout8)) continue;
+                        if (!(m_ok[mi] && n < a.Cout8) || ((SMAP_CONVP_ABLATE & 4) && a.M != 7)) continue;
                         _Float16* op = outp + (m_out[mi] + (unsigned)n);
                         half8 h;
 #pragma unroll
@@ -323,7 +352,14 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
                             *reinterpret_cast<half8*>(op + a.out_lo) = l;
                         }
                     }
+            PSTAMP(tr_epi += PTIME() - te0;)
         }
+#ifdef SMAP_TRACE
+        if (a.dbg && wave == 0 && lane == 0) {
+            long long* d = a.dbg + (long long)blockIdx.x * 16;
+            d[0] = tr_begin; d[1] = PTIME(); d[2] = tr_bar; d[3] = tr_mma; d[4] = tr_epi; d[5] = t_count;
+        }
+#endif
     }
     SMAP_TL_END(a)
 }
