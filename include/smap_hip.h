@@ -139,9 +139,18 @@ typedef struct smap_op {
     int32_t tile;                   /* CONV tile selector: 0=128x128 1=128x64 2=64x64 3=128x32 4=64x128 */
     int32_t n_aux;                  /* HEADSUM: number of source tensors (1..3)                  */
     int64_t in_off, out_off;        /* arena byte offsets                                        */
-    int64_t w_off, bias_off;        /* weight-blob byte offsets (CONV: fp16 [cout_pad][K] + fp32 [cout_pad];
-                                       STEM: fp16 [64][176] with K = (kh, c, kw padded to 8) + 8 zero
-                                       columns, + fp32 [64])                         */
+    int64_t w_off, bias_off;        /* weight-blob byte offsets.  CONV: fp16 weights of [cout_pad][K], K = (kh, kw, cin), stored
+                                       as ONE CONTIGUOUS BLOCK PER STAGED WEIGHT TILE in the kernel's LDS order, so that
+                                       every wave-wide LDS-DMA reads one contiguous KiB (strided 64-byte row segments
+                                       stream from L2 at half the rate):
+                                         [n tile][K tile][plane][BN rows][16-byte slots]
+                                       BN = the N extent of `tile` (smap_conv_tile_dims), K tile = smap_conv_tile_bk(tile,
+                                       precision) halves in K order, slot s of row r = K granule s ^ ((r>>1)&7) (64-half
+                                       tiles) or s ^ ((r>>2)&3) (32-half tiles); halo tiles 30..39: blocks ordered
+                                       [n tile][channel chunk][tap], 128-byte rows of 64 channels (precision 1: of 32
+                                       channels as granules 0..3 = hi, 4..7 = lo), slot s = granule s ^ ((r>>1)&7).
+                                       Reference packer: smap_amd/engine.py::pack_conv_weights.  + fp32 bias [cout_pad].
+                                       STEM: fp16 [64][176] with K = (kh, c, kw padded to 8) + 8 zero columns, + fp32 [64] */
     int64_t res_off;                /* dense [M][Cout] tensor added before ReLU, or -1           */
     int64_t add1_off, add2_off;     /* dense tensors added AFTER ReLU (smap.py:142-153), or -1   */
     int64_t aux_off[3];             /* CONV: aux[0] = optional low-res fp16 [B,aux_h,aux_w,Cout] tensor, bilinearly
@@ -170,6 +179,10 @@ typedef struct smap_op {
 
 /* sizeof(smap_op) as compiled: lets a foreign-language binding verify its struct mirror. */
 int smap_sizeof_op(void);
+/* Geometry of a CONV tile id, for whoever packs the weight blob: M x N extent of the output tile (0 on success, -1 for an
+ * unknown id) and the halves per staged K tile for `precision` (0 for an unknown id). */
+int smap_conv_tile_dims(int tile, int* bm, int* bn);
+int smap_conv_tile_bk(int tile, int precision);
 
 typedef struct smap_plan smap_plan;
 

@@ -42,7 +42,9 @@ def run_graph(g, imgs, quantize, keep=False):
             x = T[op.inp.name][:, p["in_c_off"]:p["in_c_off"] + cin]
             if quantize:
                 K = k * k * cin
-                wk = blob[p["w_off"]:p["w_off"] + p["cout_pad"] * K * 2].view(torch.float16).view(p["cout_pad"], K)
+                from smap_amd.engine import unpack_conv_weights      # the blob holds pre-tiled weight blocks
+                wk = unpack_conv_weights(blob[p["w_off"]:p["w_off"] + p["cout_pad"] * K * 2].view(torch.float16), p["tile"], False,
+                                         k, cin, p["cout_pad"])[0]
                 w = wk[:cout].float().view(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()
                 b = blob[p["bias_off"]:p["bias_off"] + p["cout_pad"] * 4].view(torch.float32)[:cout].clone()
             else:

@@ -107,21 +107,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
     const int HoWo = a.Ho * a.Wo;
 
-    // Weight-tile offsets first, and the weight half of K tile 0 goes out at once: it does not depend on
-    // the pixel arithmetic below, so its L2 latency overlaps the rest of the set-up.
-    unsigned b_off[LB];
+    // Weight tiles: the host packs every (n tile, K tile) weight tile as one contiguous block in LDS order, swizzle included
+    // (smap_amd/engine.py::pack_conv_weights), so a wave-wide LDS-DMA reads ONE contiguous KiB -- strided 64-byte row
+    // segments of a [cout][K] matrix stream from L2 at half that rate (tools/ubench/lds_dma_rows.hip).  The weight half of
+    // K tile 0 goes out at once: it does not depend on the pixel arithmetic below, its L2 latency overlaps the set-up.
+    constexpr int WBLK = NPL * BN * ROWB;                       // bytes of one packed weight tile
+    const unsigned w_lane = (unsigned)((wave * RPW) * ROWB + lane * 16);
+    const char* __restrict__ wt_tile = wt + (long long)n_tile * (a.K / BK) * WBLK;
+    auto issue_b = [&](int buf, int it) {
+        char* sB = smem + buf * STAGE + NPL * BM * ROWB;
+        const char* gB = wt_tile + (long long)it * WBLK + w_lane;
 #pragma unroll
-    for (int i = 0; i < LB; ++i)
-        b_off[i] = (unsigned)(((n0 + i * RPR + srow) * a.K + gch * 8) * 2);
-    auto issue_b = [&](int buf, unsigned boff) {
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            char* sB = smem + buf * STAGE + (NPL * BM + pl * BN) * ROWB;
-            const char* gB = wt + boff + (X3 ? (long long)pl * a.w_lo : 0LL);
-#pragma unroll
-            for (int i = 0; i < LB; ++i)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
-        }
+        for (int j = 0; j < NPL * LB; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + j * RPR * ROWB), (lds_void*)(sB + (j * RPR + wave * RPW) * ROWB), 16, 0, 0);
     };
     if (!(SMAP_ABLATE & 1)) issue_b(0, 0);
 
@@ -164,7 +162,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 
     // staging cursor (all wave-uniform -> SGPRs): tap (s_kh, s_kw), channel chunk s_cc
     int s_kh = 0, s_kw = 0, s_cc = 0;
-    unsigned s_boff = 0;                                       // bytes into a weight row: it * 128
+    int s_it = 0;                                              // K tile the cursor stands on
     unsigned a_cur[LA];                                        // per-lane offsets of the current tap (0 = zero page)
     auto set_tap = [&]() {
         const unsigned tap_off = (unsigned)((s_kh * a.W + s_kw) * a.in_stride_c * 2);
@@ -185,7 +183,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         }
     };
     auto advance = [&]() {
-        s_boff += ROWB;
+        ++s_it;
         if (++s_cc == cchunks) {
             s_cc = 0;
             if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; }
@@ -194,7 +192,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     };
     auto stage = [&](int buf) {        // all loads of K tile t are issued before any load of tile t+1 (counted vmcnt)
         issue_a(buf);
-        issue_b(buf, s_boff);
+        issue_b(buf, s_it);
         advance();
     };
     if (!(SMAP_ABLATE & 1)) { issue_a(0); advance(); }           // activation half of K tile 0
@@ -442,9 +440,21 @@ hipError_t launch_x3(const ConvArgs& a, hipStream_t st)
 
 }  // namespace
 
+// halves per staged K tile (= the packing unit of the weight blob, include/smap_hip.h); mirrors the BK template arguments
+// of smap_launch_conv below and smap_amd/engine.py::tile_bk (tests/test_host_cpu.py compares the two)
+extern "C" int smap_conv_tile_bk(int tile, int precision)
+{
+    int bm, bn;
+    if (smap_conv_tile_dims(tile, &bm, &bn)) return 0;
+    if (tile >= 30 && tile < 40) return precision ? 32 : 64;
+    if (tile >= 60 && tile < 70) return 32;
+    if (precision) return (tile <= 4 || tile == 52) ? 64 : 32;
+    return ((tile >= 20 && tile <= 27) || tile == 50 || tile == 51 || tile == 53 || tile == 54 || tile == 55) ? 32 : 64;
+}
+
 // tile selector -> (BM, BN).  Keep in sync with smap_amd/engine.py::TILES.
 //   0..4 : 2-stage (double-buffered) variants; 5..9 : the same tiles with deeper LDS-DMA pipelines
-int smap_conv_tile_dims(int tile, int* bm, int* bn)
+extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
 {
     if (tile >= 30 && tile < 40) return smap_conv3_tile_dims(tile, bm, bn);
     if (tile >= 60 && tile < 70) return smap_convp_tile_dims(tile, bm, bn);
@@ -469,7 +479,7 @@ int smap_conv_tile_dims(int tile, int* bm, int* bn)
 // tiles that have a split-precision instance (plan.hip::validate asks)
 int smap_conv_tile_has_x3(int tile)
 {
-    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 57) || (tile >= 60 && tile <= 62);
+    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 57) || (tile >= 60 && tile <= 68);
 }
 
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)

@@ -99,17 +99,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
     const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
 
-    unsigned b_off[LB];
-#pragma unroll
-    for (int i = 0; i < LB; ++i)
-        b_off[i] = (unsigned)(((n0 + i * 32 + srow) * a.K + gch * 8) * 2 + (X3 ? (long long)gpl * a.w_lo : 0LL));
-    auto issue_b = [&](int buf, unsigned boff) {
+    // weight tiles: one contiguous, pre-swizzled block per (n tile, chunk, tap) (smap_amd/engine.py::pack_conv_weights)
+    const int w_chunks = a.Cin / CH;
+    const char* __restrict__ wt_tile = wt + (long long)n_tile * w_chunks * 9 * B_BYTES + (wave * 8) * ROWB + lane * 16;
+    auto issue_b = [&](int buf, int blk) {                      // blk = cc * 9 + tap
         char* sB = smem + NA * A_BYTES + buf * B_BYTES;
-        const char* gB = wt + boff;
+        const char* gB = wt_tile + (long long)blk * B_BYTES;
         if (SMAP_ABLATE & 1) return;
 #pragma unroll
         for (int i = 0; i < LB; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + i * 32 * ROWB), (lds_void*)(sB + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
     };
     issue_b(0, 0);                                              // weights of (cc 0, tap 0): no pixel math needed
 
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     const int cchunks = a.Cin / CH;
     const int n_iter = cchunks * 9;
 #pragma unroll
-    for (int d = 1; d < D; ++d) issue_b(d, (unsigned)(d * a.Cin * 2));      // taps 1..D-1 of chunk 0 (D <= 9)
+    for (int d = 1; d < D; ++d) issue_b(d, d);                              // taps 1..D-1 of chunk 0 (D <= 9)
     for (int cc = 0; cc < cchunks; ++cc) {
         const bool last = cc + 1 == cchunks;
         const char* sA = smem + (cc & 1) * A_BYTES;
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
             {
                 const int nt = tap + D;                                     // tap index of iteration it+D
                 const int ncc = cc + nt / 9, ntap = nt % 9;
-                if (ncc < cchunks) issue_b((it + D) % NB, (unsigned)((ntap * a.Cin + ncc * CH) * 2));
+                if (ncc < cchunks) issue_b((it + D) % NB, ncc * 9 + ntap);
                 if (tap == 0 && !last) issue_a((cc + 1) & 1, cc + 1);
             }
             const char* sB = smem + NA * A_BYTES + (it % NB) * B_BYTES;

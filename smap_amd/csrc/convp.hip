@@ -39,7 +39,7 @@ constexpr int P_RPW = 64 / P_SPR;      // rows per wave-wide LDS-DMA instruction
 constexpr int P_RPR = P_NLW * P_RPW;   // rows per round of the four loader waves (64)
 constexpr int P_BIAS_MAX = 2048;       // output channels (cout_pad) the LDS bias table holds
 #ifndef SMAP_CONVP_ABLATE
-#define SMAP_CONVP_ABLATE 0       // experiments only (tools/build_convp_variants.py): 1 no LDS-DMA, 2 no ds_read / MFMA, 4 no stores, 8 no epilogue
+#define SMAP_CONVP_ABLATE 0       // experiments only (tools/build_convp_variants.py): 1 no LDS-DMA, 2 no ds_read / MFMA, 4 no stores, 8 no epilogue, 16 no activation DMA, 32 no weight DMA
 #endif
 #ifdef SMAP_TRACE                 // diagnostics build: summed phase times of compute wave 0 / loader wave 0 per workgroup (s_memtime)
 #define PTIME() __builtin_amdgcn_s_memtime()
@@ -48,7 +48,10 @@ constexpr int P_BIAS_MAX = 2048;       // output channels (cout_pad) the LDS bia
 #define PSTAMP(x)
 #endif
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool X3>
+// NLA = 0: all four loader waves fetch activations and weights of a K tile, in that order.  NLA = 1..3: SPLIT loaders --
+// NLA waves fetch only activations (the HBM stream), the other 4 - NLA only weights (the L2 stream), each with its own
+// in-order vmcnt, so that a slow activation line never holds up the retirement of a weight tile issued after it.
+template <int BM, int BN, int WM, int WN, int STAGES, bool X3, int NLA = 0>
 __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const ConvArgs a, const int tiles_total)
 {
     constexpr int NPL = X3 ? 2 : 1;
@@ -91,17 +94,149 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
     if (wave >= NCW) {
         // =============================================================== loader waves
         const int lw = wave - NCW;
+        const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
+        const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
+        PSTAMP(long long tr_vm = 0; long long tr_bar = 0; long long tr_iss = 0; const long long tr_begin = PTIME();)
+        if constexpr (NLA > 0) {
+        if (lw < NLA) {
+            // ---------------------------------------------------------- activation loaders (split mode)
+            constexpr int NA = NLA > 0 ? NLA : 1;
+            constexpr int RPRA = NA * P_RPW, LA2 = BM / RPRA, LPTA = NPL * LA2;
+            static_assert(BM % RPRA == 0 && (STAGES - 2) * LPTA <= 63, "activation loader split");
+            const int lrow = lane / P_SPR, lslot = lane % P_SPR;
+            const int srow = lw * P_RPW + lrow;
+            const int gch = lslot ^ ((srow >> 2) & 3);
+            const int HoWo = a.Ho * a.Wo;
+            const int cchunks = a.Cin / P_BK;
+            unsigned a_off[LA2], a_mask[LA2], a_cur[LA2];
+            int s_kh = 0, s_kw = 0, s_cc = 0, s_tile = 0;
+            auto set_tap = [&]() {
+                const unsigned tap_off = (unsigned)((s_kh * a.W + s_kw) * a.in_stride_c * 2);
+                const unsigned bit = 1u << (s_kh * a.ksize + s_kw);
+#pragma unroll
+                for (int i = 0; i < LA2; ++i) a_cur[i] = (a_mask[i] & bit) ? a_off[i] + tap_off : 0u;
+            };
+            auto setup_tile = [&]() {
+                const int logical = t_begin + s_tile;
+                const int m_tile = logical / a.n_tiles;
+                int m = m_tile * BM + srow;
+                int b = m / HoWo, rem = m - b * HoWo;
+                int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+#pragma unroll
+                for (int i = 0; i < LA2; ++i) {
+                    a_off[i] = 0;
+                    a_mask[i] = 0;
+                    if (m < a.M) {
+                        const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+                        const long long e = ((long long)(b * a.H + iy0) * a.W + ix0) * a.in_stride_c + a.in_c_off + gch * 8;
+                        a_off[i] = (unsigned)(a.in_off + e * 2);
+                        unsigned vx = 0, mk = 0;
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+                            if (kw < a.ksize && (unsigned)(ix0 + kw) < (unsigned)a.W) vx |= 1u << kw;
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh)
+                            if (kh < a.ksize && (unsigned)(iy0 + kh) < (unsigned)a.H) mk |= vx << (kh * a.ksize);
+                        a_mask[i] = mk;
+                    }
+                    m += RPRA;
+                    ox += RPRA;
+                    while (ox >= a.Wo) { ox -= a.Wo; ++oy; }
+                    while (oy >= a.Ho) { oy -= a.Ho; ++b; }
+                }
+                s_kh = s_kw = s_cc = 0;
+                set_tap();
+            };
+            auto issue = [&](int buf) {
+                char* sbase = smem + buf * STAGE;
+#pragma unroll
+                for (int pl = 0; pl < ((SMAP_CONVP_ABLATE & (1 | 16)) ? 0 : NPL); ++pl) {
+                    char* sA = sbase + pl * BM * P_ROWB;
+                    const char* gA = arena + (unsigned)(s_cc * P_ROWB + (X3 ? pl * a.in_lo * 2 : 0));
+#pragma unroll
+                    for (int i = 0; i < LA2; ++i)
+                        __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * RPRA + lw * P_RPW) * P_ROWB), 16, 0, 0);
+                }
+                if (++s_cc == cchunks) {
+                    s_cc = 0;
+                    if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; }
+                    if (s_kh == a.ksize) {
+                        if (++s_tile < t_count) setup_tile();
+                    } else {
+                        set_tap();
+                    }
+                }
+            };
+            setup_tile();
+#pragma unroll
+            for (int st = 0; st < STAGES - 1; ++st)
+                if (st < g_total) issue(st);
+            int nbuf = STAGES - 1;
+            for (int g = 0; g < g_total; ++g) {
+                PSTAMP(const long long t0 = PTIME();)
+                if (g + STAGES - 1 <= g_total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPTA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PSTAMP(const long long t1 = PTIME();)
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                PSTAMP(const long long t2 = PTIME();)
+                if (g + STAGES - 1 < g_total) issue(nbuf);
+                nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
+                PSTAMP(tr_vm += t1 - t0; tr_bar += t2 - t1; tr_iss += PTIME() - t2;)
+            }
+        } else {
+            // ---------------------------------------------------------- weight loaders (split mode)
+            constexpr int NB = NLA > 0 ? P_NLW - NLA : 1;
+            constexpr int RPRB = NB * P_RPW, LB2 = BN / RPRB, LPTB = NPL * LB2;
+            static_assert(BN % RPRB == 0 && (STAGES - 2) * LPTB <= 63, "weight loader split");
+            constexpr int WBLK = NPL * BN * P_ROWB;
+            const int wi = lw - NLA;
+            const unsigned w_lane = (unsigned)((wi * P_RPW) * P_ROWB + lane * 16);
+            int s_tile = 0, s_it = 0;
+            const char* __restrict__ wt_tile = wt;
+            auto setup_tile = [&]() {
+                const int logical = t_begin + s_tile;
+                const int n_tile = logical % a.n_tiles;
+                wt_tile = wt + (long long)n_tile * kt_per_tile * WBLK + w_lane;
+                s_it = 0;
+            };
+            auto issue = [&](int buf) {
+                if (!(SMAP_CONVP_ABLATE & (1 | 32))) {
+                    char* sB = smem + buf * STAGE + NPL * BM * P_ROWB;
+                    const char* gB = wt_tile + (long long)s_it * WBLK;
+#pragma unroll
+                    for (int j = 0; j < NPL * LB2; ++j)
+                        __builtin_amdgcn_global_load_lds((gbl_void*)(gB + j * RPRB * P_ROWB), (lds_void*)(sB + (j * RPRB + wi * P_RPW) * P_ROWB), 16, 0, 0);
+                }
+                if (++s_it == kt_per_tile && ++s_tile < t_count) setup_tile();
+            };
+            setup_tile();
+#pragma unroll
+            for (int st = 0; st < STAGES - 1; ++st)
+                if (st < g_total) issue(st);
+            int nbuf = STAGES - 1;
+            for (int g = 0; g < g_total; ++g) {
+                if (g + STAGES - 1 <= g_total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPTB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (g + STAGES - 1 < g_total) issue(nbuf);
+                nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
+            }
+        }
+        } else {
         const int lrow = lane / P_SPR, lslot = lane % P_SPR;
         const int srow = lw * P_RPW + lrow;                       // row inside a DMA round
         const int gch = lslot ^ ((srow >> 2) & 3);                // K granule this lane fetches (source-side swizzle)
-        const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
-        const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
         const int HoWo = a.Ho * a.Wo;
         const int cchunks = a.Cin / P_BK;
 
-        unsigned b_off[LB], a_off[LA], a_mask[LA], a_cur[LA];
+        unsigned a_off[LA], a_mask[LA], a_cur[LA];
         int s_kh = 0, s_kw = 0, s_cc = 0, s_tile = 0;             // issue cursor (wave-uniform)
-        unsigned s_boff = 0;
+        int s_it = 0;                                             // K tile inside the tile
+        constexpr int WBLK = NPL * BN * P_ROWB;                   // one packed weight tile (engine.py::pack_conv_weights)
+        const unsigned w_lane = (unsigned)((lw * P_RPW) * P_ROWB + lane * 16);
+        const char* __restrict__ wt_tile = wt;
         auto set_tap = [&]() {
             const unsigned tap_off = (unsigned)((s_kh * a.W + s_kw) * a.in_stride_c * 2);
             const unsigned bit = 1u << (s_kh * a.ksize + s_kw);
@@ -111,9 +246,8 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
         auto setup_tile = [&]() {                                 // geometry of logical tile t_begin + s_tile
             const int logical = t_begin + s_tile;
             const int m_tile = logical / a.n_tiles, n_tile = logical - m_tile * a.n_tiles;
-            const int m0 = m_tile * BM, n0 = n_tile * BN;
-#pragma unroll
-            for (int i = 0; i < LB; ++i) b_off[i] = (unsigned)(((n0 + i * P_RPR + srow) * a.K + gch * 8) * 2);
+            const int m0 = m_tile * BM;
+            wt_tile = wt + (long long)n_tile * kt_per_tile * WBLK + w_lane;
             int m = m0 + srow;
             int b = m / HoWo, rem = m - b * HoWo;
             int oy = rem / a.Wo, ox = rem - oy * a.Wo;
@@ -140,28 +274,27 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
                 while (oy >= a.Ho) { oy -= a.Ho; ++b; }
             }
             s_kh = s_kw = s_cc = 0;
-            s_boff = 0;
+            s_it = 0;
             set_tap();
         };
         auto issue = [&](int buf) {                               // all loads of one K tile, then move the cursor
             char* sbase = smem + buf * STAGE;
 #pragma unroll
-            for (int pl = 0; pl < ((SMAP_CONVP_ABLATE & 1) ? 0 : NPL); ++pl) {
+            for (int pl = 0; pl < ((SMAP_CONVP_ABLATE & (1 | 16)) ? 0 : NPL); ++pl) {
                 char* sA = sbase + pl * BM * P_ROWB;
                 const char* gA = arena + (unsigned)(s_cc * P_ROWB + (X3 ? pl * a.in_lo * 2 : 0));   // a_cur = 0: zero page
 #pragma unroll
                 for (int i = 0; i < LA; ++i)
                     __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * P_RPR + lw * P_RPW) * P_ROWB), 16, 0, 0);
             }
+            if (!(SMAP_CONVP_ABLATE & (1 | 32))) {                // the weight tile: one contiguous block, already in LDS order
+                char* sB = sbase + NPL * BM * P_ROWB;
+                const char* gB = wt_tile + (long long)s_it * WBLK;
 #pragma unroll
-            for (int pl = 0; pl < ((SMAP_CONVP_ABLATE & 1) ? 0 : NPL); ++pl) {
-                char* sB = sbase + (NPL * BM + pl * BN) * P_ROWB;
-                const char* gB = wt + s_boff + (X3 ? (long long)pl * a.w_lo : 0LL);
-#pragma unroll
-                for (int i = 0; i < LB; ++i)
-                    __builtin_amdgcn_global_load_lds((gbl_void*)(gB + b_off[i]), (lds_void*)(sB + (i * P_RPR + lw * P_RPW) * P_ROWB), 16, 0, 0);
+                for (int j = 0; j < NPL * LB; ++j)
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(gB + j * P_RPR * P_ROWB), (lds_void*)(sB + (j * P_RPR + lw * P_RPW) * P_ROWB), 16, 0, 0);
             }
-            s_boff += P_ROWB;
+            ++s_it;
             if (++s_cc == cchunks) {
                 s_cc = 0;
                 if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; }
@@ -172,7 +305,6 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
                 }
             }
         };
-        PSTAMP(long long tr_vm = 0; long long tr_bar = 0; long long tr_iss = 0; const long long tr_begin = PTIME();)
         setup_tile();
 #pragma unroll
         for (int st = 0; st < STAGES - 1; ++st)
@@ -189,6 +321,7 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
             if (g + STAGES - 1 < g_total) issue(nbuf);
             nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
             PSTAMP(tr_vm += t1 - t0; tr_bar += t2 - t1; tr_iss += PTIME() - t2;)
+        }
         }
 #ifdef SMAP_TRACE
         if (a.dbg && lw == 0 && lane == 0) {
@@ -375,13 +508,13 @@ int cu_count()
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool X3>
+template <int BM, int BN, int WM, int WN, int STAGES, bool X3, int NLA = 0>
 hipError_t launchp(const ConvArgs& a, hipStream_t st)
 {
     const int tiles = a.m_tiles * a.n_tiles;
     const int cus = cu_count();
     const int grid = tiles < cus ? tiles : cus;
-    hipLaunchKernelGGL((convp_kernel<BM, BN, WM, WN, STAGES, X3>), dim3(grid), dim3((WM * WN + P_NLW) * 64), 0, st, a, tiles);
+    hipLaunchKernelGGL((convp_kernel<BM, BN, WM, WN, STAGES, X3, NLA>), dim3(grid), dim3((WM * WN + P_NLW) * 64), 0, st, a, tiles);
     return hipGetLastError();
 }
 
@@ -393,6 +526,9 @@ int smap_convp_tile_dims(int tile, int* bm, int* bn)
         case 60: *bm = 128; *bn = 256; return 0;      // 8 compute waves of 64 px x 64 ch
         case 61: *bm = 256; *bn = 128; return 0;
         case 62: *bm = 128; *bn = 128; return 0;      // 8 compute waves of 32 px x 64 ch
+        case 63: case 64: case 65: *bm = 128; *bn = 64; return 0;
+        case 66: *bm = 128; *bn = 256; return 0;                // tile 60 with split loaders (2 + 2 waves)
+        case 68: *bm = 128; *bn = 128; return 0;                // tile 62 with split loaders (2 + 2)   // N = 64 layers: 8 waves of 32 px x 32 ch, 6 / 3 / 2 stages
         default: return -1;
     }
 }
@@ -405,6 +541,11 @@ hipError_t smap_launch_convp(const ConvArgs& a, int tile, hipStream_t st)
             case 60: return launchp<128, 256, 2, 4, 3, true>(a, st);     // 3 x 48 KiB
             case 61: return launchp<256, 128, 4, 2, 3, true>(a, st);     // 3 x 48 KiB
             case 62: return launchp<128, 128, 4, 2, 4, true>(a, st);     // 4 x 32 KiB
+            case 63: return launchp<128, 64, 4, 2, 6, true>(a, st);      // 6 x 24 KiB
+            case 64: return launchp<128, 64, 4, 2, 3, true>(a, st);
+            case 65: return launchp<128, 64, 4, 2, 2, true>(a, st);
+            case 66: return launchp<128, 256, 2, 4, 3, true, 2>(a, st);
+            case 68: return launchp<128, 128, 4, 2, 4, true, 2>(a, st);
             default: return hipErrorInvalidValue;
         }
     }
@@ -412,6 +553,11 @@ hipError_t smap_launch_convp(const ConvArgs& a, int tile, hipStream_t st)
         case 60: return launchp<128, 256, 2, 4, 4, false>(a, st);        // 4 x 24 KiB
         case 61: return launchp<256, 128, 4, 2, 4, false>(a, st);
         case 62: return launchp<128, 128, 4, 2, 4, false>(a, st);        // 4 x 16 KiB
+        case 63: return launchp<128, 64, 4, 2, 6, false>(a, st);
+        case 64: return launchp<128, 64, 4, 2, 3, false>(a, st);
+        case 65: return launchp<128, 64, 4, 2, 2, false>(a, st);
+        case 66: return launchp<128, 256, 2, 4, 4, false, 2>(a, st);
+        case 68: return launchp<128, 128, 4, 2, 4, false, 2>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -53,7 +53,6 @@ __device__ __forceinline__ Lerp lerp_index(int dst, int in_size, int out_size)
     return r;
 }
 
-int smap_conv_tile_dims(int tile, int* bm, int* bn);
 int smap_conv_tile_has_x3(int tile);                                        // conv.hip: tile ids with a split-precision instance
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st);
 int smap_conv3_tile_dims(int tile, int* bm, int* bn);                       // conv3.hip (tile ids 30..33, halo-tiled 3x3)

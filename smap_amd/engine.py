@@ -46,7 +46,8 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          # 55..57: 4-stage pipelines (three K tiles in flight per workgroup: bytes in flight, not occupancy, for the streaming layers)
          55: (128, 128), 56: (128, 128), 57: (128, 128),
          # 60..62: csrc/convp.hip, persistent workgroups with loader waves and a register epilogue (no fused bilinear add, no fp32 out)
-         60: (128, 256), 61: (256, 128), 62: (128, 128)}
+         60: (128, 256), 61: (256, 128), 62: (128, 128), 63: (128, 64), 64: (128, 64), 65: (128, 64),
+         66: (128, 256), 68: (128, 128)}
 # (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
 #  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)
 
@@ -65,7 +66,7 @@ PLANES = (64, 128, 256, 512)
 ALIGN = 256
 ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
 PRECISIONS = ("f16", "x3")
-X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 56, 57, 60, 61, 62)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
+X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 56, 57, 60, 61, 62, 63, 64, 65, 66, 68)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
 
 
 def split_f16(w, scaled=True):
@@ -122,6 +123,73 @@ def pick_tile_x3(M, cout, key=None):
         if blocks > best_blocks:
             best, best_blocks = t, blocks
     return cands + [best]
+
+
+def tile_family(tile):
+    """Which kernel a tile id selects: "halo" (csrc/conv3.hip), "persist" (csrc/convp.hip) or "igemm" (csrc/conv.hip)."""
+    return "halo" if 30 <= tile < 40 else "persist" if 60 <= tile < 70 else "igemm"
+
+
+def tile_bk(tile, x3):
+    """Halves per K chunk of the LDS rows a tile id stages (csrc/conv.hip::smap_launch_conv, csrc/convp.hip; the C side exports
+    the same table as smap_conv_tile_bk, tests/test_host_cpu.py keeps the two in step).  The halo kernel's rows are always
+    128 bytes: 64 channels, or [hi32 | lo32] of 32 channels in split precision."""
+    fam = tile_family(tile)
+    if fam == "halo":
+        return 32 if x3 else 64
+    if fam == "persist":
+        return 32
+    if x3:
+        return 64 if tile in (0, 1, 2, 3, 4, 52) else 32
+    return 32 if tile in (20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 53, 54, 55) else 64
+
+
+def pack_conv_weights(w2, tile, x3, ksize, cin):
+    """fp16 [planes][cout_pad][K] (K = (kh, kw, cin), planes = hi | lo in split precision) -> the byte image the conv kernels'
+    LDS-DMA reads, as ONE CONTIGUOUS BLOCK PER STAGED WEIGHT TILE: [n tile][K tile][plane][row][16-byte slot], the slot
+    order already carrying the kernels' XOR swizzle -- a weight tile is then BN x row-bytes of consecutive addresses, i.e.
+    every wave-wide global_load_lds reads one contiguous KiB.  (Strided 64-byte row segments out of a [cout][K] matrix
+    stream from L2 at half the rate: profiles/r3_v3_ubench_lds_dma_rows.log; weight tiles are re-streamed by every M tile
+    and were the larger half of the L2 -> LDS traffic.)
+      igemm / persist (csrc/conv.hip, convp.hip): K tile = BK halves in (kh, kw, cin) order; slot s of row r holds granule
+        s ^ ((r >> 1) & 7) (BK = 64) or s ^ ((r >> 2) & 3) (BK = 32);
+      halo (csrc/conv3.hip): tiles ordered [channel chunk][tap]; 128-byte rows of 64 channels, or in split precision of
+        32 channels as logical granules 0..3 = hi, 4..7 = lo; slot s of row r holds logical granule s ^ ((r >> 1) & 7)."""
+    planes, cout_pad, K = w2.shape
+    assert planes == (2 if x3 else 1) and K == ksize * ksize * cin
+    bn = TILES[tile][1]
+    nt = cout_pad // bn
+    assert nt * bn == cout_pad
+    r = torch.arange(bn)
+    if tile_family(tile) == "halo":
+        assert ksize == 3
+        ch = 32 if x3 else 64
+        cch = cin // ch
+        w = w2.reshape(planes, nt, bn, 9, cch, ch // 8, 8)
+        if x3:       # logical granule = plane * 4 + g
+            rows = w.permute(1, 4, 3, 2, 0, 5, 6).reshape(nt, cch, 9, bn, 8, 8)
+        else:
+            rows = w[0].permute(0, 3, 2, 1, 4, 5)
+        idx = torch.arange(8)[None, :] ^ ((r[:, None] >> 1) & 7)
+        return rows[:, :, :, r[:, None], idx, :].contiguous()
+    bk = tile_bk(tile, x3)
+    spr = bk // 8
+    kt = K // bk
+    assert kt * bk == K
+    rows = w2.reshape(planes, nt, bn, kt, spr, 8).permute(1, 3, 0, 2, 4, 5)          # [nt][kt][plane][row][granule][8]
+    swz = ((r >> 1) & 7) if bk == 64 else ((r >> 2) & 3)
+    idx = torch.arange(spr)[None, :] ^ swz[:, None]
+    return rows[:, :, :, r[:, None], idx, :].contiguous()
+
+
+def unpack_conv_weights(packed, tile, x3, ksize, cin, cout_pad):
+    """Inverse of pack_conv_weights: the flat fp16 image -> [planes][cout_pad][K] (oracle/graph_interp.py, tests)."""
+    planes, K = (2 if x3 else 1), ksize * ksize * cin
+    perm = pack_conv_weights(torch.arange(planes * cout_pad * K, dtype=torch.int64).reshape(planes, cout_pad, K),
+                             tile, x3, ksize, cin).reshape(-1)
+    out = torch.empty(planes * cout_pad * K, dtype=packed.dtype)
+    out[perm] = packed.reshape(-1)
+    return out.reshape(planes, cout_pad, K)
 
 
 def _rup(x, m):
@@ -306,10 +374,11 @@ class Graph:
             wk = torch.zeros((2, cout_pad, K), dtype=torch.float16)
             wk[0, :cout], wk[1, :cout] = hi, lo
         else:
-            wk = torch.zeros((cout_pad, K), dtype=torch.float16)
-            wk[:cout] = w.permute(0, 2, 3, 1).reshape(cout, K).to(torch.float16)
+            wk = torch.zeros((1, cout_pad, K), dtype=torch.float16)
+            wk[0, :cout] = w.permute(0, 2, 3, 1).reshape(cout, K).to(torch.float16)
             if not torch.isfinite(wk).all():
                 raise ValueError(f"{name}: folded weights exceed the fp16 range (max |w| = {float(w.abs().max()):.3g})")
+        wk = pack_conv_weights(wk, tile, self.x3, ksize, cin)          # one contiguous block per staged weight tile
         bk = torch.zeros((cout_pad,), dtype=torch.float32)
         bk[:cout] = b.to(torch.float32)
         out = self.tensor(name, Ho, Wo, _rup(cout, 8), 4 if out_fp32 else 2)

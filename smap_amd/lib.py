@@ -17,7 +17,7 @@ SO_PATH = os.environ.get("SMAP_HIP_LIB") or os.path.join(HERE, "libsmap_hip.so")
 # every symbol include/smap_hip.h declares
 SYMBOLS = [
     "smap_version", "smap_scale_hms", "smap_flip_merge", "smap_nms", "smap_paf_score", "smap_group", "smap_lift",
-    "smap_refine", "smap_register_gt", "smap_lift_gt", "smap_refine_gt", "smap_refine_mlp", "smap_preprocess", "smap_sizeof_op", "smap_plan_create", "smap_plan_destroy", "smap_plan_run", "smap_plan_run_range",
+    "smap_refine", "smap_register_gt", "smap_lift_gt", "smap_refine_gt", "smap_refine_mlp", "smap_preprocess", "smap_sizeof_op", "smap_conv_tile_dims", "smap_conv_tile_bk", "smap_plan_create", "smap_plan_destroy", "smap_plan_run", "smap_plan_run_range",
 ]
 
 
@@ -74,6 +74,8 @@ def load():
     lib.smap_lift_gt.argtypes = lib.smap_lift.argtypes
     lib.smap_refine_gt.argtypes = lib.smap_refine.argtypes
     lib.smap_preprocess.argtypes = [vp, ip, ip, ip, ip, ip, ip, vp, ip, ip, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]
+    lib.smap_conv_tile_dims.argtypes = [ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.smap_conv_tile_bk.argtypes = [ip, ip]
     lib.smap_plan_create.argtypes = [C.POINTER(SmapOp), ip, C.POINTER(vp)]
     lib.smap_plan_destroy.argtypes = [vp]
     lib.smap_plan_destroy.restype = None

@@ -52,8 +52,11 @@ def _run_single_conv(B, H, W, Cin, Cout, k, stride, tile, relu, use_res, use_add
         wk = torch.zeros(2, cout_pad, K, dtype=torch.float16)
         wk[0, :Cout], wk[1, :Cout] = hi, lo
     else:
-        wk = torch.zeros(cout_pad, K, dtype=torch.float16)
-        wk[:Cout] = w.permute(0, 2, 3, 1).reshape(Cout, K)
+        wk = torch.zeros(1, cout_pad, K, dtype=torch.float16)
+        wk[0, :Cout] = w.permute(0, 2, 3, 1).reshape(Cout, K)
+    from smap_amd.engine import pack_conv_weights, tile_family
+    if tile in TILES and not (tile_family(tile) == "halo" and k != 3):     # (ops the plan must reject keep any bytes)
+        wk = pack_conv_weights(wk, tile, x3, k, Cin)       # weight tiles as contiguous, pre-swizzled blocks (the conv ABI)
     bk = torch.zeros(cout_pad)
     bk[:Cout] = bias
     # weight blob: [wk | bias]; arena: [x | res | a1 | a2 | out]
@@ -224,6 +227,10 @@ X3_CASES = [
     (8, 32, 52, 256, 256, 3, 1, 61, True, False, False),     # 3x3 taps through the persistent loader, tiles < workgroups
     (8, 64, 104, 64, 256, 1, 1, 62, True, True, False),
     (2, 8, 12, 2048, 256, 1, 1, 62, True, False, True),
+    (8, 64, 104, 128, 256, 1, 1, 66, True, True, False),     # split loaders: activation waves / weight waves
+    (3, 10, 14, 192, 320, 3, 1, 66, True, True, True),
+    (8, 32, 52, 256, 256, 3, 1, 68, True, False, False),
+    (2, 16, 24, 256, 64, 1, 1, 63, True, False, False),      # N = 64 tile, 6-stage ring
     # halo-tiled 3x3 (conv3.hip) in split precision: 32-channel chunks, rows = [hi32 | lo32]
     (2, 16, 24, 64, 64, 3, 1, 30, True, False, False),
     (3, 10, 14, 192, 320, 3, 1, 31, True, False, False),

@@ -91,15 +91,46 @@ def test_flip_graph_runs_two_B_frames_and_merges_in_the_head_sum(small_sd):
 
 
 def test_tile_tables_name_existing_tiles():
-    from smap_amd.engine import TILES, X3_TILES
+    from smap_amd.engine import TILES, X3_TILES, _table_entry
     t16 = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table.json")))
     tx3 = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table_x3.json")))
-    assert t16 and all(int(v) in TILES for v in t16.values())
-    assert tx3 and all(int(v) in X3_TILES + (3,) + tuple(range(30, 40)) for v in tx3.values())
+    assert t16 and all(t in TILES for v in t16.values() for t in _table_entry(v))
+    assert tx3 and all(t in X3_TILES + (3,) + tuple(range(30, 40)) for v in tx3.values() for t in _table_entry(v))
     for key, v in tx3.items():
         B, H, W, cin, cout, k, s = map(int, key.split(","))
-        assert B == 8 and (int(v) < 30 or int(v) >= 40 or (k == 3 and s == 1))       # halo tiles: plain 3x3 stride 1 only
-        assert cout > 32 or int(v) in (3, 38, 39)
+        for t in _table_entry(v):
+            assert B == 8 and (t < 30 or t >= 40 or (k == 3 and s == 1))     # halo tiles: plain 3x3 stride 1 only
+            assert cout > 32 or t in (3, 38, 39)
+        assert not 60 <= _table_entry(v)[-1] < 70                            # a ranked list ends on a tile that takes every op
+
+
+def test_tile_geometry_tables_agree_with_the_library():
+    """engine.py packs the weight blob per tile (BN rows x BK halves blocks); the kernels' template arguments are the truth."""
+    import ctypes as C
+    from smap_amd import lib as L
+    from smap_amd.engine import TILES, tile_bk
+    lib = L.load()
+    for t in range(0, 80):
+        bm, bn = C.c_int(), C.c_int()
+        rc = lib.smap_conv_tile_dims(t, C.byref(bm), C.byref(bn))
+        assert (rc == 0) == (t in TILES), t
+        if rc == 0:
+            assert (bm.value, bn.value) == TILES[t], t
+            for prec in (0, 1):
+                assert lib.smap_conv_tile_bk(t, prec) == tile_bk(t, bool(prec)), (t, prec)
+        else:
+            assert lib.smap_conv_tile_bk(t, 0) == 0
+
+
+def test_weight_packing_is_a_permutation_and_inverts():
+    from smap_amd.engine import TILES, pack_conv_weights, unpack_conv_weights
+    for tile, x3, k, cin, cout_pad in ((0, False, 3, 128, 256), (20, True, 1, 64, 128), (31, True, 3, 64, 256), (36, False, 3, 64, 64),
+                                       (52, True, 1, 128, 256), (60, True, 3, 64, 512), (3, True, 3, 64, 32)):
+        planes, K = (2 if x3 else 1), k * k * cin
+        w = torch.randn(planes, cout_pad, K).half()
+        p = pack_conv_weights(w, tile, x3, k, cin)
+        assert p.numel() == w.numel() and torch.equal(p.reshape(-1).sort().values, w.reshape(-1).sort().values)
+        assert torch.equal(unpack_conv_weights(p.reshape(-1), tile, x3, k, cin, cout_pad), w)
 
 
 def test_lazy_records_equal_eager_records():

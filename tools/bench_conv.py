@@ -33,6 +33,7 @@ PRESETS = {          # B, H, W, Cin, Cout, k, stride, tile, residual
     "L16": (8, 64, 104, 512, 128, 1, 1, 0, 0),    # layer2 c1
     "L17": (8, 16, 26, 2048, 2048, 1, 1, 0, 0),   # up1 skip1
     "L18": (8, 16, 26, 512, 2048, 1, 1, 0, 1),    # layer4 c3
+    "L19": (8, 128, 208, 256, 64, 1, 1, 1, 0),    # layer1 c1 / cross_conv
 }
 
 
