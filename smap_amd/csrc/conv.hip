@@ -35,7 +35,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 #ifndef SMAP_ABLATE
-#define SMAP_ABLATE 0            // experiments only (tools/build_ablate.py): 1 no loads, 2 no MFMA, 4 no stores, 8 no epilogue
+#define SMAP_ABLATE 0            // experiments only (tools/build_ablate.py): 1 no loads, 2 no MFMA, 4 no stores, 8 no epilogue, 32 no bilinear tap loads, 64 no bilinear index math
 #endif
 // FULL = false: epilogue with bias / residual / ReLU only (most layers: ~45 fewer VGPRs, more workgroups per CU);
 // FULL = true : + fused bilinear add and post-ReLU addends.
@@ -325,13 +325,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         const long long dense = (long long)ms * (TS * a.Cout8) + ns;     // res/add tensors are dense [M][Cout8] (x planes)
         x.o = (long long)ms * a.out_stride_c + a.out_c_off + ns;
         if (FULL && a.up) {
-            const int b = ms / HoWo, rem = ms - b * HoWo;
-            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            const Lerp ly = lerp_index(oy, a.up_h, a.Ho), lx = lerp_index(ox, a.up_w, a.Wo);
+            const int b = (SMAP_ABLATE & 64) ? 0 : ms / HoWo, rem = ms - b * HoWo;
+            const int oy = (SMAP_ABLATE & 64) ? (ms & 63) : rem / a.Wo, ox = (SMAP_ABLATE & 64) ? (ms & 127) : rem - oy * a.Wo;
+            Lerp ly = lerp_index(oy, a.up_h, a.Ho), lx = lerp_index(ox, a.up_w, a.Wo);
+            if (SMAP_ABLATE & 64) { ly.i0 = oy >> 1; ly.i1 = ly.i0; ly.l0 = 0.5f; ly.l1 = 0.5f; lx.i0 = ox >> 1; lx.i1 = lx.i0; lx.l0 = 0.5f; lx.l1 = 0.5f; }
             const int us = TS * a.Cout8;
             const _Float16* tb = a.up + (long long)b * a.up_h * a.up_w * us + ns;
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
+            for (int pl = 0; pl < ((SMAP_ABLATE & 32) ? 0 : NPL); ++pl) {
                 x.t00[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i0) * us + pl * a.Cout8);
                 x.t01[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i1) * us + pl * a.Cout8);
                 x.t10[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i0) * us + pl * a.Cout8);
@@ -396,12 +397,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         }
     };
     TR(4);
-    Extra ex[2];
-    ex[0] = load_pass(0);
+#ifndef SMAP_EPI_DEPTH
+#define SMAP_EPI_DEPTH 1          // passes whose loads are in flight ahead of the one being finished (FULL epilogue: 2)
+#endif
+    constexpr int ED = (FULL && PASSES > 2) ? SMAP_EPI_DEPTH : 1;
+    Extra ex[ED + 1];
+#pragma unroll
+    for (int p = 0; p < ED && p < PASSES; ++p) ex[p] = load_pass(p);
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-        if (p + 1 < PASSES) ex[(p + 1) & 1] = load_pass(p + 1);
-        finish_pass(p, ex[p & 1]);
+        if (p + ED < PASSES) ex[(p + ED) % (ED + 1)] = load_pass(p + ED);
+        finish_pass(p, ex[p % (ED + 1)]);
     }
 #ifdef SMAP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

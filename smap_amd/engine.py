@@ -111,7 +111,8 @@ def pick_tile_x3(M, cout, key=None):
         import json
         path = os.environ.get("SMAP_TILE_TABLE_X3") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table_x3.json")
         _TILE_TABLE_X3 = json.load(open(path)) if os.path.exists(path) and not os.environ.get("SMAP_NO_TILE_TABLE") else {}
-    cands = _table_entry(_TILE_TABLE_X3[key]) if key is not None and key in _TILE_TABLE_X3 else []
+    keys = [key] if isinstance(key, str) else list(key or [])          # several keys: most specific first
+    cands = [t for k in keys if k in _TILE_TABLE_X3 for t in _table_entry(_TILE_TABLE_X3[k])]
     if cout <= 32:
         return cands + [3]
     best, best_blocks = None, -1
@@ -349,7 +350,8 @@ class Graph:
         plain3 = ksize == 3 and stride == 1 and res is None and add1 is None and add2 is None and up is None
         legal = lambda t: tile_legal(t, cout=cout, plain3=plain3, up=up is not None, out_fp32=out_fp32)
         if self.x3:
-            cands = pick_tile_x3(M, cout, key)
+            # ops with the fused bilinear add have their own entries (the tap loads of the epilogue favour wider tiles)
+            cands = pick_tile_x3(M, cout, [key + ",up", key] if up is not None else key)
             x3t = os.environ.get("SMAP_X3_TILE", "")         # A/B hook: force one split-precision tile where it fits
             if x3t and cout > 32 and not (cout <= 64 and TILES[int(x3t)][1] > 64):
                 cands = [int(x3t)] + cands

@@ -97,7 +97,8 @@ def test_tile_tables_name_existing_tiles():
     assert t16 and all(t in TILES for v in t16.values() for t in _table_entry(v))
     assert tx3 and all(t in X3_TILES + (3,) + tuple(range(30, 40)) for v in tx3.values() for t in _table_entry(v))
     for key, v in tx3.items():
-        B, H, W, cin, cout, k, s = map(int, key.split(","))
+        B, H, W, cin, cout, k, s = map(int, key.split(",")[:7])              # optional 8th field: "up" (ops with a fused bilinear add)
+        assert key.split(",")[7:] in ([], ["up"])
         for t in _table_entry(v):
             assert B == 8 and (t < 30 or t >= 40 or (k == 3 and s == 1))     # halo tiles: plain 3x3 stride 1 only
             assert cout > 32 or t in (3, 38, 39)

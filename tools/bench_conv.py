@@ -34,10 +34,12 @@ PRESETS = {          # B, H, W, Cin, Cout, k, stride, tile, residual
     "L17": (8, 16, 26, 2048, 2048, 1, 1, 0, 0),   # up1 skip1
     "L18": (8, 16, 26, 512, 2048, 1, 1, 0, 1),    # layer4 c3
     "L19": (8, 128, 208, 256, 64, 1, 1, 1, 0),    # layer1 c1 / cross_conv
+    "L20": (8, 128, 208, 256, 256, 1, 1, 0, 0, 1),  # up4.out: lateral + fused bilinear add of the 64x104 up_conv output
+    "L21": (8, 64, 104, 512, 256, 1, 1, 0, 0, 1),   # up3.out
 }
 
 
-def build(B, H, W, Cin, Cout, k, s, tile, res, dev, x3=False):
+def build(B, H, W, Cin, Cout, k, s, tile, res, dev, x3=False, up=0):
     """x3: split-precision op (hi/lo planes: strides and weight matrix doubled, smap_op.precision = 1)."""
     lib = L.load()
     pl = 2 if x3 else 1
@@ -49,7 +51,8 @@ def build(B, H, W, Cin, Cout, k, s, tile, res, dev, x3=False):
     al = lambda n: (n + 255) // 256 * 256
     c8 = (Cout + 7) // 8 * 8
     x_b, o_b = al(B * H * W * Cin * 2 * pl), al(B * Ho * Wo * c8 * 2 * pl)
-    arena = (torch.randn((16384 + x_b + 2 * o_b) // 2 + 128, device=dev) * 0.5).half()
+    u_b = al(B * (Ho // 2) * (Wo // 2) * c8 * 2 * pl) if up else 0
+    arena = (torch.randn((16384 + x_b + 2 * o_b + u_b) // 2 + 128, device=dev) * 0.5).half()
     w_b = al(cout_pad * K * 2 * pl)
     blob = torch.zeros(w_b + al(cout_pad * 4), dtype=torch.uint8, device=dev)
     blob[:cout_pad * K * 2 * pl] = (torch.randn(cout_pad * K * pl, device=dev) * K ** -0.5).half().view(torch.uint8)
@@ -63,6 +66,8 @@ def build(B, H, W, Cin, Cout, k, s, tile, res, dev, x3=False):
     op.add1_off = op.add2_off = op.ext_off = -1
     for i in range(3):
         op.aux_off[i] = -1
+    if up:
+        op.aux_off[0], op.aux_h[0], op.aux_w[0] = 16384 + x_b + 2 * o_b, Ho // 2, Wo // 2
     h = C.c_void_p()
     L.check(lib.smap_plan_create(C.byref(op), 1, C.byref(h)), "create")
     flops = 2.0 * B * Ho * Wo * Cout * K
@@ -91,7 +96,7 @@ def main():
         p = list(PRESETS[n])
         if n in ov:
             p[7] = int(ov[n])
-        lib, h, arena, blob, flops, byts = build(*p, dev, x3=args.x3)
+        lib, h, arena, blob, flops, byts = build(*p[:9], dev, x3=args.x3, up=p[9] if len(p) > 9 else 0)
         if args.streams > 1:
             streams = [torch.cuda.Stream(dev) for _ in range(args.streams)]
             arenas = [arena] + [arena.clone() for _ in range(args.streams - 1)]

@@ -29,6 +29,18 @@ if "--trace" in sys.argv:       # phase-stamp build: libsmap_hip_trace.so (ConvA
     subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     print(out)
     sys.exit(0)
+if "--epi-depth" in sys.argv:   # FULL epilogue with 2 passes of loads in flight: libsmap_hip_epi2.so
+    objs = []
+    for src, extra in B.SOURCES:
+        op = os.path.join(B.OBJ, src.rsplit(".", 1)[0] + ".o")
+        if src == "conv.hip":
+            op = os.path.join(B.OBJ, "epi2_conv.o")
+            subprocess.check_call([B._hipcc()] + B.COMMON + extra + ["-DSMAP_EPI_DEPTH=2", "-c", os.path.join(B.CSRC, src), "-o", op])
+        objs.append(op)
+    out = os.path.join(B.OBJ, "libsmap_hip_epi2.so")
+    subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    print(out)
+    sys.exit(0)
 for n in [int(x) for x in sys.argv[1:]] or [1, 2, 8, 9, 10]:
     objs = []
     for src, extra in B.SOURCES:
