@@ -453,7 +453,7 @@ extern "C" int smap_conv_tile_bk(int tile, int precision)
     int bm, bn;
     if (smap_conv_tile_dims(tile, &bm, &bn)) return 0;
     if (tile >= 30 && tile < 40) return precision ? 32 : 64;
-    if (tile >= 60 && tile < 70) return 32;
+    if (tile >= 60 && tile < 80) return tile == 69 ? 64 : 32;
     if (precision) return (tile <= 4 || tile == 52) ? 64 : 32;
     return ((tile >= 20 && tile <= 27) || tile == 50 || tile == 51 || tile == 53 || tile == 54 || tile == 55) ? 32 : 64;
 }
@@ -463,7 +463,7 @@ extern "C" int smap_conv_tile_bk(int tile, int precision)
 extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
 {
     if (tile >= 30 && tile < 40) return smap_conv3_tile_dims(tile, bm, bn);
-    if (tile >= 60 && tile < 70) return smap_convp_tile_dims(tile, bm, bn);
+    if (tile >= 60 && tile < 80) return smap_convp_tile_dims(tile, bm, bn);
     switch (tile) {
         case 20: case 24: *bm = 128; *bn = 128; return 0;      // 20..27: BK = 32 staging (smaller LDS, more workgroups per CU)
         case 21: case 25: *bm = 128; *bn = 64; return 0;
@@ -485,12 +485,12 @@ extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
 // tiles that have a split-precision instance (plan.hip::validate asks)
 int smap_conv_tile_has_x3(int tile)
 {
-    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 57) || (tile >= 60 && tile <= 68);
+    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 57) || (tile >= 60 && tile <= 70);
 }
 
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
 {
-    if (tile >= 60 && tile < 70) return smap_launch_convp(a, tile, st);      // persistent wave-specialised kernel, both precisions
+    if (tile >= 60 && tile < 80) return smap_launch_convp(a, tile, st);      // persistent wave-specialised kernel, both precisions
     if (a.x3) {
         if (tile >= 30 && tile < 40) return smap_launch_conv3(a, tile, st);     // halo-tiled 3x3, split-precision instance
         switch (tile) {                                     // LDS = max(STAGES * 2 * (BM + BN) * row bytes, fp32 epilogue tile)

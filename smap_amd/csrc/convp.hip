@@ -31,12 +31,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-constexpr int P_NLW = 4;          // loader waves
-constexpr int P_BK = 32;          // halves per K chunk
-constexpr int P_ROWB = P_BK * 2;  // bytes per LDS row
-constexpr int P_SPR = P_ROWB / 16;     // 16-byte slots per row
-constexpr int P_RPW = 64 / P_SPR;      // rows per wave-wide LDS-DMA instruction (16)
-constexpr int P_RPR = P_NLW * P_RPW;   // rows per round of the four loader waves (64)
 constexpr int P_BIAS_MAX = 2048;       // output channels (cout_pad) the LDS bias table holds
 #ifndef SMAP_CONVP_ABLATE
 #define SMAP_CONVP_ABLATE 0       // experiments only (tools/build_convp_variants.py): 1 no LDS-DMA, 2 no ds_read / MFMA, 4 no stores, 8 no epilogue, 16 no activation DMA, 32 no weight DMA
@@ -51,9 +45,14 @@ constexpr int P_BIAS_MAX = 2048;       // output channels (cout_pad) the LDS bia
 // NLA = 0: all four loader waves fetch activations and weights of a K tile, in that order.  NLA = 1..3: SPLIT loaders --
 // NLA waves fetch only activations (the HBM stream), the other 4 - NLA only weights (the L2 stream), each with its own
 // in-order vmcnt, so that a slow activation line never holds up the retirement of a weight tile issued after it.
-template <int BM, int BN, int WM, int WN, int STAGES, bool X3, int NLA = 0>
+template <int BM, int BN, int WM, int WN, int STAGES, bool X3, int NLA = 0, int P_BK = 32, int P_NLW = 4>
 __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const ConvArgs a, const int tiles_total)
 {
+    static_assert(P_BK == 32 || P_BK == 64, "halves per K chunk");
+    constexpr int P_ROWB = P_BK * 2;       // bytes per LDS row
+    constexpr int P_SPR = P_ROWB / 16;     // 16-byte slots per row
+    constexpr int P_RPW = 64 / P_SPR;      // rows per wave-wide LDS-DMA instruction (16 / 8)
+    constexpr int P_RPR = P_NLW * P_RPW;   // rows per round of the four loader waves (64 / 32)
     constexpr int NPL = X3 ? 2 : 1;
     constexpr int NCW = WM * WN;
     static_assert(BM % P_RPR == 0 && BN % P_RPR == 0, "tile must be a multiple of the DMA round");
@@ -93,6 +92,9 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
 
     if (wave >= NCW) {
         // =============================================================== loader waves
+#ifdef SMAP_CONVP_LOADER_PRIO
+        __builtin_amdgcn_s_setprio(SMAP_CONVP_LOADER_PRIO);
+#endif
         const int lw = wave - NCW;
         const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
         const char* __restrict__ wt = reinterpret_cast<const char*>(a.w);
@@ -105,7 +107,7 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
             static_assert(BM % RPRA == 0 && (STAGES - 2) * LPTA <= 63, "activation loader split");
             const int lrow = lane / P_SPR, lslot = lane % P_SPR;
             const int srow = lw * P_RPW + lrow;
-            const int gch = lslot ^ ((srow >> 2) & 3);
+            const int gch = P_BK == 64 ? (lslot ^ ((srow >> 1) & 7)) : (lslot ^ ((srow >> 2) & 3));
             const int HoWo = a.Ho * a.Wo;
             const int cchunks = a.Cin / P_BK;
             unsigned a_off[LA2], a_mask[LA2], a_cur[LA2];
@@ -227,7 +229,7 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
         } else {
         const int lrow = lane / P_SPR, lslot = lane % P_SPR;
         const int srow = lw * P_RPW + lrow;                       // row inside a DMA round
-        const int gch = lslot ^ ((srow >> 2) & 3);                // K granule this lane fetches (source-side swizzle)
+        const int gch = P_BK == 64 ? (lslot ^ ((srow >> 1) & 7)) : (lslot ^ ((srow >> 2) & 3));   // K granule this lane fetches (source-side swizzle)
         const int HoWo = a.Ho * a.Wo;
         const int cchunks = a.Cin / P_BK;
 
@@ -333,7 +335,7 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
         // =============================================================== compute waves
         const int wm = wave / WN, wn = wave - wm * WN;
         const int l31 = lane & 31, lhi = lane >> 5;
-        const int rswz = (l31 >> 2) & 3;
+        const int rswz = P_BK == 64 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
         const int p_row0 = wm * (BM / WM) + l31;                  // + mi*32: pixel rows of the A image
         const int c_row0 = wn * (BN / WN) + l31;                  // + ni*32: channel rows of the W image
         int buf = 0;
@@ -508,13 +510,13 @@ int cu_count()
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool X3, int NLA = 0>
+template <int BM, int BN, int WM, int WN, int STAGES, bool X3, int NLA = 0, int BK = 32, int P_NLW = 4>
 hipError_t launchp(const ConvArgs& a, hipStream_t st)
 {
     const int tiles = a.m_tiles * a.n_tiles;
     const int cus = cu_count();
     const int grid = tiles < cus ? tiles : cus;
-    hipLaunchKernelGGL((convp_kernel<BM, BN, WM, WN, STAGES, X3, NLA>), dim3(grid), dim3((WM * WN + P_NLW) * 64), 0, st, a, tiles);
+    hipLaunchKernelGGL((convp_kernel<BM, BN, WM, WN, STAGES, X3, NLA, BK, P_NLW>), dim3(grid), dim3((WM * WN + P_NLW) * 64), 0, st, a, tiles);
     return hipGetLastError();
 }
 
@@ -528,7 +530,9 @@ int smap_convp_tile_dims(int tile, int* bm, int* bn)
         case 62: *bm = 128; *bn = 128; return 0;      // 8 compute waves of 32 px x 64 ch
         case 63: case 64: case 65: *bm = 128; *bn = 64; return 0;
         case 66: *bm = 128; *bn = 256; return 0;                // tile 60 with split loaders (2 + 2 waves)
-        case 68: *bm = 128; *bn = 128; return 0;                // tile 62 with split loaders (2 + 2)   // N = 64 layers: 8 waves of 32 px x 32 ch, 6 / 3 / 2 stages
+        case 68: *bm = 128; *bn = 128; return 0;                // tile 62 with split loaders (2 + 2)
+        case 69: *bm = 128; *bn = 128; return 0;                // tile 62 with 64-half K tiles (128-byte rows = full lines), 2 stages
+        case 70: *bm = 128; *bn = 128; return 0;                // tile 62 with EIGHT loader waves   // N = 64 layers: 8 waves of 32 px x 32 ch, 6 / 3 / 2 stages
         default: return -1;
     }
 }
@@ -546,6 +550,8 @@ hipError_t smap_launch_convp(const ConvArgs& a, int tile, hipStream_t st)
             case 65: return launchp<128, 64, 4, 2, 2, true>(a, st);
             case 66: return launchp<128, 256, 2, 4, 3, true, 2>(a, st);
             case 68: return launchp<128, 128, 4, 2, 4, true, 2>(a, st);
+            case 69: return launchp<128, 128, 4, 2, 2, true, 0, 64>(a, st);   // 2 x 64 KiB
+            case 70: return launchp<128, 128, 4, 2, 4, true, 0, 32, 8>(a, st);
             default: return hipErrorInvalidValue;
         }
     }
@@ -558,6 +564,8 @@ hipError_t smap_launch_convp(const ConvArgs& a, int tile, hipStream_t st)
         case 65: return launchp<128, 64, 4, 2, 2, false>(a, st);
         case 66: return launchp<128, 256, 2, 4, 4, false, 2>(a, st);
         case 68: return launchp<128, 128, 4, 2, 4, false, 2>(a, st);
+        case 69: return launchp<128, 128, 4, 2, 4, false, 0, 64>(a, st);  // 4 x 32 KiB
+        case 70: return launchp<128, 128, 4, 2, 4, false, 0, 32, 8>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -465,7 +465,7 @@ static int validate(const smap_op& o)
             if (o.tile >= 30 && o.tile < 40 && (o.ksize != 3 || o.stride != 1 || o.pad != 1 || o.res_off >= 0 || o.add1_off >= 0 ||
                                  o.add2_off >= 0 || o.aux_off[0] >= 0))
                 return SMAP_E_ARG;                       // halo-tiled kernel: plain 3x3 stride-1 convs only
-            if (o.tile >= 60 && o.tile < 70 && (o.out_fp32 || o.aux_off[0] >= 0 || o.Cout % 8 || o.cout_pad > 2048))
+            if (o.tile >= 60 && o.tile < 80 && (o.out_fp32 || o.aux_off[0] >= 0 || o.Cout % 8 || o.cout_pad > 2048))
                 return SMAP_E_ARG;                       // persistent kernel: register epilogue, fp16 outputs, no fused bilinear add, bias table of 2048 channels in LDS
             if (o.in_stride_c % 8 || o.in_c_off % 8 || o.out_stride_c % 8 || o.out_c_off % 8) return SMAP_E_ARG;
             if (o.out_stride_c < ((o.Cout + 7) & ~7)) return SMAP_E_ARG;

@@ -47,7 +47,7 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          55: (128, 128), 56: (128, 128), 57: (128, 128),
          # 60..62: csrc/convp.hip, persistent workgroups with loader waves and a register epilogue (no fused bilinear add, no fp32 out)
          60: (128, 256), 61: (256, 128), 62: (128, 128), 63: (128, 64), 64: (128, 64), 65: (128, 64),
-         66: (128, 256), 68: (128, 128)}
+         66: (128, 256), 68: (128, 128), 69: (128, 128), 70: (128, 128)}
 # (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
 #  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)
 
@@ -66,7 +66,7 @@ PLANES = (64, 128, 256, 512)
 ALIGN = 256
 ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
 PRECISIONS = ("f16", "x3")
-X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 56, 57, 60, 61, 62, 63, 64, 65, 66, 68)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
+X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 56, 57, 60, 61, 62, 63, 64, 65, 66, 68, 69, 70)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
 
 
 def split_f16(w, scaled=True):
@@ -96,7 +96,7 @@ def tile_legal(tile, *, cout, cout_pad=None, plain3=True, up=False, out_fp32=Fal
     """Can tile id `tile` run an op with these properties?  Mirrors csrc/plan.hip::validate."""
     if 30 <= tile < 40:
         return plain3
-    if 60 <= tile < 70:
+    if 60 <= tile < 80:
         cp = cout_pad if cout_pad is not None else _rup(cout, TILES[tile][1])
         return not up and not out_fp32 and cout % 8 == 0 and cp <= 2048
     return True
@@ -128,7 +128,7 @@ def pick_tile_x3(M, cout, key=None):
 
 def tile_family(tile):
     """Which kernel a tile id selects: "halo" (csrc/conv3.hip), "persist" (csrc/convp.hip) or "igemm" (csrc/conv.hip)."""
-    return "halo" if 30 <= tile < 40 else "persist" if 60 <= tile < 70 else "igemm"
+    return "halo" if 30 <= tile < 40 else "persist" if 60 <= tile < 80 else "igemm"
 
 
 def tile_bk(tile, x3):
@@ -139,7 +139,7 @@ def tile_bk(tile, x3):
     if fam == "halo":
         return 32 if x3 else 64
     if fam == "persist":
-        return 32
+        return 64 if tile == 69 else 32
     if x3:
         return 64 if tile in (0, 1, 2, 3, 4, 52) else 32
     return 32 if tile in (20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 53, 54, 55) else 64

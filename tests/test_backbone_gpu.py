@@ -231,6 +231,8 @@ X3_CASES = [
     (3, 10, 14, 192, 320, 3, 1, 66, True, True, True),
     (8, 32, 52, 256, 256, 3, 1, 68, True, False, False),
     (2, 16, 24, 256, 64, 1, 1, 63, True, False, False),      # N = 64 tile, 6-stage ring
+    (8, 32, 52, 256, 256, 3, 1, 69, True, False, False),     # 64-half K tiles
+    (3, 10, 14, 192, 320, 3, 1, 69, True, True, True),
     # halo-tiled 3x3 (conv3.hip) in split precision: 32-channel chunks, rows = [hi32 | lo32]
     (2, 16, 24, 64, 64, 3, 1, 30, True, False, False),
     (3, 10, 14, 192, 320, 3, 1, 31, True, False, False),

@@ -36,6 +36,8 @@ def main():
                          "the existing table holds, cold (three rotating arenas); a shape's entry becomes the ranked list "
                          "[convp tile, old tile] when the convp tile is at least GAIN faster (ops it cannot take -- fused "
                          "bilinear add, fp32 output -- fall through to the old tile)")
+    ap.add_argument("--cold", action="store_true", help="three rotating arenas per candidate: every launch finds its operands cold in "
+                    "the Infinity Cache, as inside the full schedule (the warm loop flatters HBM-shaped layers by 5-20 %%)")
     ap.add_argument("--table", default="", help="existing table to start from (--convp / --halo); default: the shipped one")
     args = ap.parse_args()
     x3 = args.precision == "x3"
@@ -81,7 +83,8 @@ def main():
         cands = [t for t in cands if t < 30 or (halo_ok and t < 40)]
         if x3:
             from smap_amd.engine import X3_TILES
-            cands = [3] if Cout <= 32 else [t for t in X3_TILES if not (Cout <= 64 and TILES[t][1] > 64)]
+            cands = [3] if Cout <= 32 else [t for t in X3_TILES if not (Cout <= 64 and TILES[t][1] > 64) and t not in (66, 68)
+                                            and not (Cout > 64 and TILES[t][1] == 64 and t >= 60)]
             if halo_ok:      # halo-tiled 3x3 kernel has split-precision instances too
                 cands += [38, 39] if Cout <= 32 else [t for t in range(30, 38) if not (Cout <= 64 and TILES[t][1] > 64)]
         if args.halo:
@@ -94,8 +97,11 @@ def main():
                                (Cout + TILES[t][1] - 1) // TILES[t][1] * TILES[t][1] <= 2048]
         res = {}
         for t in cands:
-            lib, h, arena, blob, flops, byts = build(B, H, W, Cin, Cout, k, s, t, int(has_res), dev, x3=x3)
-            arenas = [arena] + ([arena.clone(), arena.clone()] if convp else [])
+            try:
+                lib, h, arena, blob, flops, byts = build(B, H, W, Cin, Cout, k, s, t, int(has_res), dev, x3=x3)
+            except L.SmapError:                         # the plan rejects this tile for this op
+                continue
+            arenas = [arena] + ([arena.clone(), arena.clone()] if (convp or args.cold) else [])
             def run(i=[0]):
                 ar = arenas[i[0] % len(arenas)]
                 i[0] += 1
@@ -128,7 +134,14 @@ def main():
         from smap_amd.engine import pick_tile_heuristic, pick_tile_x3
         Mo = B * ((H + 2 * (k // 2) - k) // s + 1) * ((W + 2 * (k // 2) - k) // s + 1)
         dflt = pick_tile_x3(Mo, Cout)[-1] if x3 else pick_tile_heuristic(Mo, Cout)
-        table[",".join(map(str, key))] = best
+        ranked = sorted(res, key=res.get)
+        from smap_amd.engine import tile_family
+        entry = []
+        for t in ranked:                                 # ranked list down to the first tile that takes every op of the shape
+            entry.append(t)
+            if tile_family(t) == "igemm":
+                break
+        table[",".join(map(str, key))] = entry[0] if len(entry) == 1 else entry
         total_best += res[best] * count
         total_default += res.get(dflt, res[best]) * count
         print(key, "x%d" % count, {t: round(v, 1) for t, v in res.items()}, "best", best, "default", dflt, flush=True)

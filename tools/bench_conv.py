@@ -34,6 +34,12 @@ PRESETS = {          # B, H, W, Cin, Cout, k, stride, tile, residual
     "L17": (8, 16, 26, 2048, 2048, 1, 1, 0, 0),   # up1 skip1
     "L18": (8, 16, 26, 512, 2048, 1, 1, 0, 1),    # layer4 c3
     "L19": (8, 128, 208, 256, 64, 1, 1, 1, 0),    # layer1 c1 / cross_conv
+    "L6b": (16, 16, 26, 512, 512, 3, 1, 2, 0),    # layer4 3x3 at twice the batch: what a 2-way split-K grid would look like to the CUs
+    "L22": (8, 16, 26, 2048, 512, 1, 1, 2, 0),    # layer4 c1
+    "L22b": (16, 16, 26, 2048, 512, 1, 1, 2, 0),
+    "L18b": (16, 16, 26, 512, 2048, 1, 1, 0, 1),
+    "L2b": (16, 32, 52, 256, 256, 3, 1, 2, 0),
+    "L14b": (16, 32, 52, 1024, 256, 1, 1, 0, 0),
     "L20": (8, 128, 208, 256, 256, 1, 1, 0, 0, 1),  # up4.out: lateral + fused bilinear add of the 64x104 up_conv output
     "L21": (8, 64, 104, 512, 256, 1, 1, 0, 0, 1),   # up3.out
 }
