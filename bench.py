@@ -74,6 +74,7 @@ _CPU_CHILD = r"""
 # per-frame results the end-to-end parity figures are computed from (benchkit/parity.py).
 import sys, time, os, json, pickle, torch, numpy as np
 root, threads, frames, seed, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+flip = len(sys.argv) > 6 and sys.argv[6] == "flip"
 sys.path.insert(0, root)
 from benchkit import parity
 from benchkit.workload import make_cfg, people_state_dict, PEOPLE_CAM
@@ -83,9 +84,11 @@ torch.manual_seed(0)
 sd = people_state_dict(SMAP(make_cfg((128, 208))).state_dict(), "smooth")
 x = torch.randn(8, 3, 512, 832, generator=torch.Generator().manual_seed(seed))[:frames]
 cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (frames, 1))
-parity.reference_path(sd, x[:1], cams[:1])                     # warm-up (oneDNN primitive cache, page faults)
+cfg = make_cfg((128, 208))
+fp = (list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [cfg.DATASET.KEYPOINT.NUM + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]) if flip else None
+parity.reference_path(sd, x[:1], cams[:1], flip_pair=fp)       # warm-up (oneDNN primitive cache, page faults)
 t0 = time.time()
-ref = parity.reference_path(sd, x, cams)
+ref = parity.reference_path(sd, x, cams, flip_pair=fp)         # --flip: the reference's two forwards + channel loop (test.py:55-70)
 dt = (time.time() - t0) / frames
 # association + lifting alone: single thread (the reference's own path: its OpenMP pragmas are commented out,
 # association.cpp:79,100) and frame-parallel over the cores
@@ -104,7 +107,7 @@ pickle.dump({"ref": ref, "sec_per_frame": dt, "assoc_1thread_ms": t_as1 * 1e3, "
 """
 
 
-def cpu_reference(frames, seed):
+def cpu_reference(frames, seed, flip=False):
     """Runs _CPU_CHILD under a hard timeout (a mis-sized OpenMP team on the box's host CPU must not stall the bench).
     Returns its result dict or {"error": ...}."""
     import subprocess
@@ -112,7 +115,7 @@ def cpu_reference(frames, seed):
     threads = usable_cpus(32)
     out = os.path.join(tempfile.mkdtemp(prefix="smap_bench_"), "ref.pkl")
     try:
-        r = subprocess.run([sys.executable, "-c", _CPU_CHILD, ROOT, str(threads), str(frames), str(seed), out],
+        r = subprocess.run([sys.executable, "-c", _CPU_CHILD, ROOT, str(threads), str(frames), str(seed), out] + (["flip"] if flip else []),
                            capture_output=True, text=True, timeout=240, cwd=ROOT)
         if r.returncode != 0:
             return {"error": r.stderr[-300:]}
@@ -276,8 +279,8 @@ def pin_host_threads(local, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU reference pass (no cpu_baseline, no config.e2e_parity): kernel experiments only")
@@ -357,9 +360,11 @@ def main():
     if want_ref:
         import concurrent.futures as cf
         nref = min(B, 8)
-        ref_future = cf.ThreadPoolExecutor(1).submit(cpu_reference, nref, SEED)
+        ref_future = cf.ThreadPoolExecutor(1).submit(cpu_reference, nref, SEED, args.flip)
         from benchkit import parity
-        hip_frames = parity.hip_path(net, imgs[:nref] if B == nref else imgs, cams)[:nref] if B >= nref else None
+        # the parity block reports THIS configuration: with --flip both sides run the flip-TTA (HIP: mirror + merge inside the schedule)
+        fp = (list(run_cfg.DATASET.KEYPOINT.FLIP_ORDER) + [run_cfg.DATASET.KEYPOINT.NUM + c for c in run_cfg.DATASET.PAF.FLIP_CHANNEL]) if args.flip else None
+        hip_frames = parity.hip_path(net, imgs[:nref] if B == nref else imgs, cams, flip_pair=fp)[:nref] if B >= nref else None
 
     pipe = PosePipeline(net, run_cfg, B, H, W, dev, refine_weights=refine_w, n_extra=1, depth=args.depth, numpy_records=True,
                         do_flip=args.flip)

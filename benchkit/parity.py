@@ -18,7 +18,8 @@ What is compared, per frame (north_star: "peak indices / limb assignments bit-ex
            too).  So every peak present in only one path is looked up in the REFERENCE map: its decision margin
            |v - max(threshold, best neighbour)| relative to the map scale.  peaks_differing counts them,
            peaks_differing_max_margin is the largest such margin (a genuinely different peak would show ~1e-2), and
-           peaks_clear_mismatch counts those above NEAR_TIE = 1e-5 (~4x the split-precision map error): the number that
+           peaks_clear_mismatch counts those above NEAR_TIE = 1e-6 (a third of the split-precision map error; the ties observed
+           on MI355X have margins of 3e-8 .. 9e-8): the number that
            must be ZERO.
 """
 import numpy as np
@@ -26,7 +27,7 @@ import torch
 
 NJ = 15
 TOL_PX = 0.5
-NEAR_TIE = 1e-5          # decision margin (relative to the key-point map scale) below which a peak is a floating-point tie
+NEAR_TIE = 1e-6          # decision margin (relative to the key-point map scale) below which a peak is a floating-point tie
 THRESHOLD = 0.2          # association.cpp:55 nms threshold on the /255-scaled maps
 MAXP = 127
 

@@ -174,7 +174,10 @@ typedef struct smap_op {
                                        are merged into frame b: out[b,c,y,x] = v[b,c,y,x] + s_c * v[b+flip_from, pair[c], y,
                                        W-1-x], s_c = -1 on PAF-x channels (c >= in_c_off, (c - in_c_off) even), then
                                        channels >= in_c_off are halved; pair = int32[Cout] at w_off in the weight blob. */
-    int32_t reserved_;
+    int32_t status_off;             /* HEADSUM: byte offset (> 0) in the fp32 output buffer of an int32 STATUS word, or 0 = none.
+                                       smap_plan_run clears it, the head sum ORs in 1 when a value it writes is not finite:
+                                       split precision keeps fp16's RANGE, an activation beyond 65504 turns into inf / NaN
+                                       downstream; the host checks the word when it collects the maps. */
 } smap_op;
 
 /* sizeof(smap_op) as compiled: lets a foreign-language binding verify its struct mirror. */
@@ -194,7 +197,7 @@ void smap_plan_destroy(smap_plan* plan);
 /* Runs the whole schedule on `stream`.
  * input : [B,3,H,W] fp32 NCHW images; arena: activation arena; weights: weight blob;
  * out   : fp32 output buffer (hms [B,43,h,w] | det_d [B,14,h,w] | root_d [B,1,h,w] at the
- *         offsets recorded in the HEADSUM ops). */
+ *         offsets recorded in the HEADSUM ops, plus the int32 status word at status_off when the ops name one). */
 int smap_plan_run(const smap_plan* plan, const float* input, void* arena, const void* weights,
                   float* out, void* stream);
 /* Runs ops [first, first+count) only (tests, per-layer profiling). */

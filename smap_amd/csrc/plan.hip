@@ -386,7 +386,8 @@ __device__ __forceinline__ float4 head_value4(const HeadSrc& s, const Lerp* ly, 
 // the same fp32 operations, in the same order, as the reference's channel loop (and as smap_flip_merge).
 template <bool FLIP>
 __global__ __launch_bounds__(256) void headsum_kernel(HeadSrc s, float* __restrict__ out, int Ho, int Wo, int C,
-                                                      int Cs, int flip_from, const int* __restrict__ pair, int n_kpt)
+                                                      int Cs, int flip_from, const int* __restrict__ pair, int n_kpt,
+                                                      int* __restrict__ status)
 {
     __shared__ float tile[(FLIP ? 2 : 1) * 48 * (HS_PX + 1)];
     float* tile2 = tile + 48 * (HS_PX + 1);
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(256) void headsum_kernel(HeadSrc s, float* __restri
             if (c >= n_kpt) v = v * 0.5f;
         }
         out[(((size_t)b * C + c) * Ho + y) * Wo + x] = v;
+        if (status && !(fabsf(v) <= 3.4028234e38f)) atomicOr(status, 1);       // inf / NaN: an activation left the fp16 range upstream
     }
 }
 
@@ -499,6 +501,7 @@ static int validate(const smap_op& o)
         case SMAP_OP_HEADSUM:
             if (o.n_aux < 1 || o.n_aux > 3 || o.Cout > 48 || o.Cin < o.Cout || o.ext_off < 0) return SMAP_E_ARG;
             if (o.flip_from < 0 || (o.flip_from > 0 && (o.w_off < 0 || o.in_c_off < 0 || o.in_c_off > o.Cout))) return SMAP_E_ARG;
+            if (o.status_off < 0 || o.status_off % 4) return SMAP_E_ARG;
             return 0;
         default:
             return SMAP_E_ARG;
@@ -549,6 +552,11 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
     const char* wb = static_cast<const char*>(weights);
     auto A = [&](int64_t off) -> _Float16* { return off < 0 ? nullptr : reinterpret_cast<_Float16*>(ar + off); };
     if (hipError_t e = hipMemsetAsync(ar, 0, SMAP_ZERO_PAGE, st); e != hipSuccess) return hip_rc(e);
+    for (int i = first; i < first + count; ++i)          // the status word (one per schedule) starts every run at 0
+        if (plan->ops[i].kind == SMAP_OP_HEADSUM && plan->ops[i].status_off > 0 && out) {
+            if (hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(out) + plan->ops[i].status_off, 0, 4, st); e != hipSuccess) return hip_rc(e);
+            break;
+        }
     for (int i = first; i < first + count; ++i) {
         const smap_op& o = plan->ops[i];
         hipError_t e = hipSuccess;
@@ -651,12 +659,13 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                 }
                 dim3 grid((o.Wo + HS_PX - 1) / HS_PX, o.Ho, o.B);
                 float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + o.ext_off);
+                int* status = o.status_off > 0 ? reinterpret_cast<int*>(reinterpret_cast<char*>(out) + o.status_off) : nullptr;
                 if (o.flip_from > 0)
                     hipLaunchKernelGGL(headsum_kernel<true>, grid, dim3(256), 0, st, s, dst, o.Ho, o.Wo, o.Cout, o.Cin,
-                                       o.flip_from, reinterpret_cast<const int*>(wb + o.w_off), o.in_c_off);
+                                       o.flip_from, reinterpret_cast<const int*>(wb + o.w_off), o.in_c_off, status);
                 else
                     hipLaunchKernelGGL(headsum_kernel<false>, grid, dim3(256), 0, st, s, dst, o.Ho, o.Wo, o.Cout, o.Cin,
-                                       0, nullptr, 0);
+                                       0, nullptr, 0, status);
                 e = hipGetLastError();
                 break;
             }

@@ -295,6 +295,11 @@ def pick_tile(M, cout, key=None):
 DEFAULT_REMAP = {}
 
 
+class ArenaTooLarge(ValueError):
+    """The schedule's conv inputs would end above 4 GiB (the conv kernels address activations with 32-bit byte offsets
+    from the arena base, csrc/plan.hip::validate): run the frames in smaller batches."""
+
+
 class Graph:
     def __init__(self, sd, B, H, W, stage_num=3, chl=256, kpt_paf=43, paf=14, keep_ref=False, precision="f16",
                  flip_pair=None):
@@ -309,6 +314,8 @@ class Graph:
         self.frames = B                       # frames of the input / output
         if self.flip_pair is not None:
             assert len(self.flip_pair) == kpt_paf
+            if sorted(self.flip_pair) != list(range(kpt_paf)):      # the head sum indexes LDS with these values
+                raise ValueError("flip_pair must be a permutation of the %d output channels (cfg FLIP_ORDER / PAF.FLIP_CHANNEL)" % kpt_paf)
             B = 2 * B                         # frames of every activation tensor
         assert H % 32 == 0 and W % 32 == 0, "input must be a multiple of 32 (5 stride-2 levels)"
         self.sd, self.B, self.H, self.W = sd, B, H, W
@@ -495,6 +502,7 @@ class Graph:
             self.out_layout = dict(hms=(0, n_hms), det_d=(B * n_hms * h * w * 4, n_d),
                                    root_d=(B * (n_hms + n_d) * h * w * 4, 1))
             self.out_bytes = B * (n_hms + n_d + 1) * h * w * 4
+            self.status_off = self.out_bytes                 # int32 status word behind the maps (include/smap_hip.h)
             # outputs_2d = res4 + res3 + res2 (smap.py:417)
             self.ops.append(Op(OP_HEADSUM, aux=[head_t["res4"], head_t["res3"], head_t["res2"]],
                                p=dict(Cout=n_hms, ext_off=self.out_layout["hms"][0], **flip_p)))
@@ -546,6 +554,11 @@ class Graph:
                             merged.append((o, sz))
                     free = merged
         self.arena_bytes = max(top, ALIGN)
+        for op in self.ops:
+            if op.kind == OP_CONV and op.inp.off + op.inp.nbytes > (1 << 32):
+                raise ArenaTooLarge(f"{op.out.name}: conv input ends at {(op.inp.off + op.inp.nbytes) / 2 ** 30:.2f} GiB of a "
+                                    f"{self.arena_bytes / 2 ** 30:.2f} GiB arena ({self.B} frames, precision {self.precision}); the "
+                                    "conv kernels take inputs below 4 GiB -- use a smaller batch (PosePipeline splits by itself)")
         return self.arena_bytes
 
     def emit(self):
@@ -607,6 +620,7 @@ class Graph:
                     o.aux_off[k], o.aux_h[k], o.aux_w[k] = t.off, t.H, t.W
                 o.ext_off = p["ext_off"]
                 o.B = self.frames                          # output frames (flip-TTA: the mirrored half is merged in)
+                o.status_off = self.status_off
                 if p.get("flip_from"):
                     o.flip_from, o.in_c_off, o.w_off = p["flip_from"], p["n_kpt"], p["w_off"]
         return arr
@@ -661,14 +675,26 @@ class BackboneEngine:
         return e
 
     def new_output(self):
-        """A fresh fp32 output buffer (hms | det_d | root_d); pass it to run(out=...) to double-buffer."""
-        return torch.empty((self.out_floats,), dtype=torch.float32, device=self.device)     # HEADSUM writes every element
+        """A fresh fp32 output buffer (hms | det_d | root_d | status word); pass it to run(out=...) to double-buffer.
+        Zero-filled: a partial run(first, count) (debug / trace tools) must not hand back uninitialised memory."""
+        return torch.zeros((self.out_floats + 1,), dtype=torch.float32, device=self.device)
+
+    def status(self, out=None):
+        """The status word of the last run into `out` (synchronises): bit 0 = a non-finite value reached the output
+        maps, i.e. an activation left the fp16 range on the way (split precision has fp16's range, not fp32's)."""
+        buf = self.out if out is None else out
+        return int(buf[self.out_floats:self.out_floats + 1].view(torch.int32).item())
+
+    def raise_if_nonfinite(self, out=None):
+        if self.status(out) & 1:
+            raise RuntimeError("SMAP backbone produced non-finite outputs: an activation exceeded the fp16 range (65504) of the "
+                               f"'{self.precision}' arithmetic; see INTEGRATION.md section 5")
 
     def views(self, out):
         B, n = self.B, self.B * self.h * self.w
         k, p = self.kpt_paf, self.paf
         return (out[:n * k].view(B, k, self.h, self.w), out[n * k:n * (k + p)].view(B, p, self.h, self.w),
-                out[n * (k + p):].view(B, 1, self.h, self.w))
+                out[n * (k + p):n * (k + p + 1)].view(B, 1, self.h, self.w))
 
     def __del__(self):
         try:

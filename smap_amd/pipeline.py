@@ -15,6 +15,8 @@ workgroups per launch) batch k+1 streams its HBM-bound high-resolution layers on
 `submit()` returns the records of the batch submitted `depth` calls earlier (None until then);
 `flush()` returns everything still in flight, in order.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -27,12 +29,23 @@ MAXG = 64                       # annotations per frame the registration kernel 
 
 class _Slot:
     def __init__(self, engine, device, n_extra, B):
-        self.out = engine.new_output()
-        self.hms, self.det_d, self.root_d = engine.views(self.out)   # B frames, also with flip-TTA (merged in the schedule)
+        # one output buffer per backbone launch (engine.B frames each); with several launches per batch the maps of the
+        # whole batch are gathered into B-frame tensors behind them
+        self.outs = [engine.new_output() for _ in range(B // engine.B)]
+        self.out = self.outs[0]
+        if len(self.outs) == 1:
+            self.hms, self.det_d, self.root_d = engine.views(self.out)   # B frames, also with flip-TTA (merged in the schedule)
+        else:
+            h, w = engine.h, engine.w
+            self.hms = torch.empty((B, engine.kpt_paf, h, w), dtype=torch.float32, device=device)
+            self.det_d = torch.empty((B, engine.paf, h, w), dtype=torch.float32, device=device)
+            self.root_d = torch.empty((B, 1, h, w), dtype=torch.float32, device=device)
         mk = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         self.host = [dict(p2=mk((B, MAXP, NJ, 4), torch.float32), p3=mk((B, MAXP, NJ, 4), torch.float64),
                           rz=mk((B, MAXP), torch.float64), counts=mk((B,), torch.int32))
                      for _ in range(1 + n_extra)]
+        self.status = engine.out_floats                                      # index of the engine's status word in `out`
+        self.status_host = torch.zeros((1,), dtype=torch.float32).pin_memory()  # its host copy (bit 0: non-finite maps)
         self.p2_f64 = None               # ground-truth modes: the f64 pred_2d (allocated on first use)
         self.ev_bb = torch.cuda.Event()
         self.ev_post = torch.cuda.Event()       # the host waits on this one: PosePipeline._wait
@@ -42,7 +55,7 @@ class _Slot:
 
 class PosePipeline:
     def __init__(self, model, cfg, batch, H, W, device, refine_weights=None, n_extra=0, do_flip=False, depth=1,
-                 record_mode="run_inference", numpy_records=False):
+                 record_mode="run_inference", numpy_records=False, max_frames_per_launch=None):
         """record_mode: test.py's -t: "run_inference" (no ground truth), "generate_result" (one record per frame
         with the annotations attached) or "generate_train" (one record per matched person); the last two need
         `annotations=` in submit()."""
@@ -56,7 +69,21 @@ class PosePipeline:
         # stem reads the mirrored image by index, the head sum merges the mirrored maps (no ATen cat/flip, no merge pass)
         kpt = cfg.DATASET.KEYPOINT.NUM
         self.flip_pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
-        self.engine = model.engine(batch, H, W, self.device, flip_pair=self.flip_pair if do_flip else None)
+        # frames per backbone launch: the whole batch, or the largest divisor of it whose activation arena stays within the conv
+        # kernels' 4 GiB of 32-bit offsets (split precision + flip-TTA at batch 16 = 32 frames of activations does not)
+        from .engine import ArenaTooLarge
+        limit = max_frames_per_launch or int(os.environ.get("SMAP_MAX_FRAMES_PER_LAUNCH", "0")) or batch
+        self.chunk = None
+        for parts in range(1, batch + 1):
+            if batch % parts or batch // parts > limit:
+                continue
+            try:
+                self.engine = model.engine(batch // parts, H, W, self.device, flip_pair=self.flip_pair if do_flip else None)
+                self.chunk = batch // parts
+                break
+            except ArenaTooLarge:
+                if parts == batch:
+                    raise
         self._model, self._generation = model, model.weights_generation      # a reload / .to() after this point makes the
                                                                              # pipeline stale: submit() refuses to run on old weights
         self.refine = refine_weights
@@ -132,7 +159,15 @@ class PosePipeline:
             if time_backbone:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            eng.run(imgs, out=slot.out)
+            if len(slot.outs) == 1:
+                eng.run(imgs, out=slot.out)
+            else:                                      # the batch in engine-sized launches, one after the other on this stream
+                c = eng.B
+                for j, o in enumerate(slot.outs):
+                    hm, dd, rd = eng.run(imgs[j * c:(j + 1) * c], out=o)
+                    slot.hms[j * c:(j + 1) * c].copy_(hm, non_blocking=True)
+                    slot.det_d[j * c:(j + 1) * c].copy_(dd, non_blocking=True)
+                    slot.root_d[j * c:(j + 1) * c].copy_(rd, non_blocking=True)
             if time_backbone:
                 e1.record()
                 self.bb_events.append((e0, e1))
@@ -147,6 +182,9 @@ class PosePipeline:
                 self._post(*a, **k)
                 p1.record()
                 self.post_events.append((tag, p0, p1))
+            st_words = [o[slot.status:slot.status + 1].view(torch.int32) for o in slot.outs]
+            slot.status_host.copy_((st_words[0] if len(st_words) == 1 else torch.stack(st_words).max(0).values).view(torch.float32),
+                                   non_blocking=True)
             timed_post("network", slot, 0, slot.hms, slot.det_d, slot.root_d, cams_d, scale=True, gt=gt)
             for j, (tag, hms, rd, dd) in enumerate(extra):
                 timed_post(tag, slot, 1 + j, hms, slot.det_d if dd is None else dd, rd, cams_d, scale=False)
@@ -182,6 +220,10 @@ class PosePipeline:
 
     def _collect(self, slot):
         self._wait(slot.ev_post)
+        if int(slot.status_host.view(torch.int32)[0]) & 1:
+            slot.busy = False
+            raise RuntimeError("SMAP backbone produced non-finite maps: an activation exceeded the fp16 range (65504) that the "
+                               "engine's arithmetic keeps (INTEGRATION.md section 5); these frames have no valid result")
         tags, extra_tags, annotations = slot.meta
         recs = []
         for idx, h in enumerate(slot.host):

@@ -481,9 +481,11 @@ def test_full_size_properties():
     assert a[0].abs().max().item() > 1e-3
 
 
-def test_full_size_forward_vs_cpu_oracle():
+@pytest.mark.parametrize("precision,tol_max,tol_mean", [("x3", 1e-4, 2e-5), ("f16", 1e-2, 2e-3)])
+def test_full_size_forward_vs_cpu_oracle(precision, tol_max, tol_mean):
     """BASELINE configs[1]: batch=1, 3x512x832, forward only -- HIP engine vs the CPU restatement of the
-    reference forward (oracle/backbone_ref.py, fp32), recipe weights.  Tolerance = fp16 activation storage."""
+    reference forward (oracle/backbone_ref.py, fp32), recipe weights.  Split precision (the default) is held to the
+    fp32-roundoff level SURVEY.md 7 step 4 asks of an fp32-equivalent path; plain fp16 to its storage tolerance."""
     from smap_amd.model.smap import SMAP
     from oracle.backbone_ref import smap_forward
     torch.manual_seed(0)
@@ -494,12 +496,41 @@ def test_full_size_forward_vs_cpu_oracle():
     torch.set_num_threads(min(16, torch.get_num_threads()))
     with torch.no_grad():
         ref = smap_forward(sd, x)
+    net.precision = precision
     out = [t.cpu() for t in net.to(DEV)(x.to(DEV))]
     for a, b, k in zip(out, ref, ("hms", "det_d", "root_d")):
         err = (a - b).abs().max().item() / b.abs().max().item()
-        assert err < 1e-2, (k, err)
+        assert err < tol_max, (k, err)
         # the bulk of the map is far tighter than the worst pixel
-        assert ((a - b).abs().mean() / b.abs().mean()).item() < 2e-3, k
+        assert ((a - b).abs().mean() / b.abs().mean()).item() < tol_mean, k
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 3e3, 1e5])
+def test_split_precision_dynamic_range(small, scale):
+    """Split precision keeps fp16's RANGE: activations around 1e-4 have subnormal lo parts, activations beyond 65504 turn into
+    inf.  Scaling the input image scales every activation of the (bias-free up to BN shifts) early layers; the contract is
+    EITHER maps within 1e-4 of the fp32 reference OR the status word set (RuntimeError from raise_if_nonfinite / PosePipeline)
+    -- never silently wrong maps."""
+    from smap_amd.model.smap import SMAP
+    from oracle.backbone_ref import smap_forward
+    net, sd = small
+    x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(4)) * scale
+    with torch.no_grad():
+        ref = smap_forward(sd, x)
+    net.precision = "x3"
+    eng = net.to(DEV).engine(1, 64, 96, torch.device(DEV))
+    out = eng.new_output()
+    got = [t.cpu() for t in eng.run(x.to(DEV), out=out)]
+    finite = all(torch.isfinite(t).all() for t in got)
+    assert (eng.status(out) & 1) == (0 if finite else 1)                # the kernel-side guard sees exactly what isfinite sees
+    if not finite:
+        with pytest.raises(RuntimeError, match="fp16 range"):
+            eng.raise_if_nonfinite(out)
+        assert scale >= 3e3, "only large activations may overflow"
+        return
+    for a, b, k in zip(got, ref, ("hms", "det_d", "root_d")):
+        err = (a - b).abs().max().item() / b.abs().max().item()
+        assert err < 1e-4, (k, scale, err)
 
 
 def test_graph_replay_equals_direct_launches(small):

@@ -6,8 +6,9 @@
 
 north_star: "peak indices / limb assignments bit-exact, 3D joint coordinates within 1e-3 m" (= 0.1 cm in the reference's
 cm units).  "Bit-exact peak indices" between two floating-point forwards is only defined above the forwards' own resolution
-(benchkit/parity.py, "ties"): the assertion is that NO peak differs whose decision margin in the reference map exceeds 1e-5
-of the map scale (peaks_clear_mismatch == 0), that at most one candidate per thousand is such a near-tie, and that every
+(benchkit/parity.py, "ties"): the assertion is that NO peak differs whose decision margin in the reference map exceeds 1e-6
+of the map scale (peaks_clear_mismatch == 0; observed tie margins: 3e-8 .. 9e-8), that at most 3 candidates per 10 000 are such
+near-ties (two per batch of ~2 800 candidates: 0 - 2 were observed per batch over 64 frames), and that every
 3D joint of every paired skeleton is within 0.1 cm.  On the 16 frames of the seed-1234 batches the peak lists are in fact
 identical; over 24 more frames one near-tie (margin ~1e-6) falls the other way.  Weights are the by-key recipe with calibrated heads (benchkit/workload.py::people_state_dict: ~24 peaks per
 key-point channel, root depth ~3 m), in two flavours: "smooth" maps (coarse heads dominate) and "noise" maps (isolated
@@ -63,7 +64,7 @@ def _dump(name, m):
 def _assert_north_star(m):
     """Same peaks (above floating-point resolution), same skeletons and limbs, 3D joints within 1e-3 m."""
     assert m["peaks_clear_mismatch"] == 0, m                               # no peak differs that was not a floating-point tie
-    assert m["peaks_differing"] <= max(1, m["peaks_ref"] // 1000), m        # ... and such ties are rare
+    assert m["peaks_differing"] <= max(2, 3 * m["peaks_ref"] // 10000), m   # ... and such ties are rare (3 per 10 000)
     assert m["peak_match"] >= 1.0 - 1e-3
     # a flipped near-tie can change the one skeleton it belongs to; everything that is paired must agree
     assert m["person_match"] >= 1.0 - 2.0 * max(m["peaks_differing"], 0) / max(m["persons_ref"], 1) - 1e-12
@@ -135,24 +136,25 @@ def test_split_precision_more_frames(seed):
     _assert_north_star(m)
 
 
-def test_split_precision_flip_tta_end_to_end():
-    """The reference's SHIPPED setting (test.sh: --do_flip 1): HIP engine with the flip-TTA inside its schedule -> association ->
-    lifting vs the reference path with its second, mirrored forward and channel-loop merge (test.py:55-70) on the CPU."""
+@pytest.mark.parametrize("kind", ["smooth", "noise"])
+def test_split_precision_flip_tta_end_to_end(kind):
+    """The reference's SHIPPED setting (test.sh: --do_flip 1) on the full batch of 8 frames, both weight flavours: HIP engine with
+    the flip-TTA inside its schedule (16 frames of activations) -> association -> lifting vs the reference path with its second,
+    mirrored forward and channel-loop merge (test.py:55-70) on the CPU."""
     from benchkit.workload import PEOPLE_CAM
     from exps.stage3_root2.config import cfg
     kpt = cfg.DATASET.KEYPOINT.NUM
     pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
-    net, sd, imgs = _setup("smooth")
-    nb = 4                                           # 4 frames = 8 CPU forwards
+    net, sd, imgs = _setup(kind)
     net.precision = "x3"
     net = net.to(DEV)
-    cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (nb, 1))
-    hip = parity.hip_path(net, imgs[:nb].to(DEV), cams, flip_pair=pair)
-    ref = parity.reference_path(sd, imgs[:nb], cams, threads=min(32, os.cpu_count() or 1), flip_pair=pair)
+    cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (B, 1))
+    hip = parity.hip_path(net, imgs.to(DEV), cams, flip_pair=pair)
+    ref = parity.reference_path(sd, imgs, cams, threads=min(32, os.cpu_count() or 1), flip_pair=pair)     # 16 CPU forwards
     m = parity.compare(hip, ref)
-    m.update(precision="x3", weights="smooth", batch=nb, flip_tta=True)
-    _dump("e2e_parity_x3_flip.json", m)
-    assert m["peaks_ref"] >= 20 * nb                 # the summed key-point maps sit higher: more candidates, capped at 127
+    m.update(precision="x3", weights=kind, batch=B, flip_tta=True)
+    _dump(f"e2e_parity_x3_flip_{kind}.json", m)
+    assert m["peaks_ref"] >= 20 * B                  # the summed key-point maps sit higher: more candidates, capped at 127
     _assert_north_star(m)
 
 

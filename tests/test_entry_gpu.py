@@ -145,8 +145,10 @@ def test_two_stream_pipeline_equals_serial_path():
                     for j, c in enumerate(counts) if c > 0]
             n_people += int(counts.sum())
     assert n_people > 0
-    for depth, flip in ((1, False), (2, False), (3, False), (2, True)):
-        pipe = PosePipeline(net, cfg, B, 64, 96, dev, depth=depth, do_flip=flip)
+    # chunk = frames per backbone launch: 1 < batch exercises the split a 4 GiB arena forces on the shipped test.sh settings
+    for depth, flip, chunk in ((1, False, None), (2, False, None), (3, False, None), (2, True, None), (2, False, 1), (2, True, 1)):
+        pipe = PosePipeline(net, cfg, B, 64, 96, dev, depth=depth, do_flip=flip, max_frames_per_launch=chunk)
+        assert pipe.chunk == (chunk or B)
         got = []
         for rep in range(2):                                  # reuse of slots / arenas across many submits
             for i, x in enumerate(batches):
@@ -156,7 +158,7 @@ def test_two_stream_pipeline_equals_serial_path():
         got += pipe.flush() or []
         have = [(r["image_path"], r["pred_2d"], r["pred_3d"], r["root_d"]) for r in got]
         want = want_flip if flip else want_all
-        assert have == want + want, (depth, flip)             # in order, bit for bit
+        assert have == want + want, (depth, flip, chunk)      # in order, bit for bit
 
 
 def test_device_preprocess_equals_host_dataset(tmp_path):

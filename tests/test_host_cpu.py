@@ -90,6 +90,33 @@ def test_flip_graph_runs_two_B_frames_and_merges_in_the_head_sum(small_sd):
         Graph(small_sd, 3, 64, 96, flip_pair=[0, 1, 2])
 
 
+def test_shipped_launcher_settings_are_plannable():
+    """exps/stage3_root2/test.sh runs --batch_size 16 --do_flip 1 in the default split precision: 32 frames of activations
+    are a 6 GiB arena, beyond the conv kernels' 32-bit input offsets.  The graph must say so in words, and the batch must
+    split into launches that fit (PosePipeline walks the divisors of the batch exactly like this)."""
+    from types import SimpleNamespace as NS
+    from smap_amd.engine import ArenaTooLarge, Graph
+    from smap_amd.model.smap import SMAP
+    sh = open(os.path.join(ROOT, "exps", "stage3_root2", "test.sh")).read()
+    assert "--batch_size 16" in sh and "--do_flip 1" in sh
+    cfg = NS(MODEL=NS(STAGE_NUM=3, UPSAMPLE_CHANNEL_NUM=256), DATASET=NS(KEYPOINT=NS(NUM=15), PAF=NS(NUM=14)),
+             OUTPUT_SHAPE=(128, 208), LOSS=NS(OHKM=True, TOPK=8, COARSE_TO_FINE=True))
+    torch.manual_seed(0)
+    sd = SMAP(cfg).state_dict()
+    fits = {}
+    for B in (16, 8):
+        g = Graph(sd, B, 512, 832, precision="x3", flip_pair=list(range(43)))
+        try:
+            g.allocate()
+            fits[B] = True
+        except ArenaTooLarge as e:
+            fits[B] = False
+            assert "4 GiB" in str(e) and "smaller batch" in str(e)
+    assert fits == {16: False, 8: True}
+    with pytest.raises(ValueError):
+        Graph(sd, 1, 64, 96, flip_pair=[0] * 43)             # not a permutation
+
+
 def test_tile_tables_name_existing_tiles():
     from smap_amd.engine import TILES, X3_TILES, _table_entry
     t16 = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table.json")))
