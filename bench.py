@@ -218,7 +218,7 @@ def dry_run(args):
     collected = []
     if world > 1:
         dist.barrier()
-    t0 = time.perf_counter()
+    t0, cpu0 = time.perf_counter(), time.process_time()
     for _ in range(args.steps):
         collected.extend(pipe.submit() or [])
     collected.extend(pipe.flush() or [])
@@ -227,16 +227,23 @@ def dry_run(args):
         got = [pickle.loads(b) for b in gather_bytes(pickle.dumps(collected, protocol=pickle.HIGHEST_PROTOCOL), "cpu")]
         dist.barrier()
     dt = time.perf_counter() - t0
+    cpu_ms = (time.process_time() - cpu0) / args.steps * 1e3
+    per_rank_cpu = [cpu_ms]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        hc = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]       # host CPU per step of EVERY rank, as the GPU run reports it
+        dist.all_gather(hc, torch.tensor([cpu_ms], dtype=torch.float64))
+        per_rank_cpu = [float(h.item()) for h in hc]
     if rank == 0:
         print(json.dumps({"metric": "dry run (no GPU): control flow only", "value": args.batch * world * args.steps / dt,
                           "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "synthetic",
                           "config": {"workload": "stand-in pipeline", "ranks_in_gather": len(got),
+                                     "host_ms_per_step": {"process_cpu_per_rank": per_rank_cpu},
+                                     "host_cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                                      "records_per_rank": [len(g) for g in got],
                                      "first_paths": [g[0]["image_path"] for g in got],
                                      "last_paths": [g[-1]["image_path"] for g in got]}}), flush=True)

@@ -3,9 +3,9 @@
 Same outputs: (normalised BGR CHW float tensor letter-boxed to 832x512 with 128-grey padding,
 image name, `scale` dict with scale/img_width/img_height/net_width/net_height).
 cv2 and torchvision are not part of this image: decoding uses PIL (converted to BGR like
-cv2.imread) and the resize is a plain fp32 bilinear with half-pixel centres and no anti-aliasing
-(smap_amd.preprocess.resize_bilinear_u8), the sampling rule of cv2.INTER_LINEAR.  uint8 rounding can differ from OpenCV's fixed-point
-path by 1 LSB -- pre-processing is outside the measured hot path.
+cv2.imread) and the resize restates OpenCV's 8-bit INTER_LINEAR from its published algorithm, operation by operation
+(smap_amd.preprocess.resize_linear_u8: 11-bit fixed-point coefficients, (d + 0.5) / f - 0.5 source coordinates, the integer
+vertical pass) -- faithful to the algorithm, unpinned by execution (no cv2 here to run).
 `.npy` files holding an HxWx3 uint8 BGR array are accepted as well.
 Record order: the reference lists jpg, then png, then jpeg files in glob (= directory) order, which is not defined; here
 each extension's files are SORTED (one of the orders the reference may produce, and a reproducible one).  Decoding honours
@@ -51,11 +51,11 @@ class CustomDataset(Dataset):
         return (t - self.mean) / self.std, image_name, scale                    # Normalize
 
     def aug_croppad(self, img):
-        from smap_amd.preprocess import letterbox_geometry, resize_bilinear_u8
+        from smap_amd.preprocess import letterbox_geometry, resize_linear_u8
         crop_x, crop_y = self.net_input_shape
         w0, h0 = self.image_shape
         scale, (nh, nw, top, left) = letterbox_geometry(w0, h0, crop_x, crop_y)   # cv2.resize(fx, fy): dsize = round(src * f)
-        r = resize_bilinear_u8(img, nh, nw)
+        r = resize_linear_u8(img, nh, nw, fx=scale["scale"], fy=scale["scale"])     # cv2.resize(img, (0, 0), fx=s, fy=s)
         out = np.full((crop_y, crop_x, 3), 128, np.uint8)
         hh, ww = min(nh, crop_y - top), min(nw, crop_x - left)
         out[top:top + hh, left:left + ww] = r[:hh, :ww]

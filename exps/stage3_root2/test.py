@@ -67,9 +67,33 @@ class DevicePreprocLoader:
             yield imgs, list(names), scales
 
 
-def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, device, output_dir=""):
+class _DryRunPipeline:
+    """Stand-in for PosePipeline in `--dry_run 1` (no GPU, no checkpoint): the same submit / flush contract -- records of
+    the batch submitted `depth` calls earlier -- with one fake person per frame.  What the rehearsal exercises is everything
+    AROUND the device work: CLI, image listing, the contiguous per-rank split, ragged last batches, the end-of-run gather
+    (gloo instead of RCCL) and the result file; `python -m torch.distributed.run --nproc-per-node 8 test.py --dry_run 1 ...`."""
+
+    def __init__(self, model, cfg, batch, H, W, device, refine_w=None, depth=2, **kw):
+        self.B, self.depth, self.q = batch, max(1, int(depth)), []
+
+    def submit(self, imgs, cams, tags, annotations=None):
+        from smap_amd.records import frame_record
+        p2 = np.zeros((1, 15, 4), np.float32)
+        self.q.append([frame_record(p2, np.zeros((1, 15, 4)), np.full((1,), float(imgs[i].mean())), t, None, as_lists=False)
+                       for i, t in enumerate(tags) if t is not None])
+        return self.q.pop(0) if len(self.q) > self.depth else None
+
+    def flush(self):
+        out = [r for recs in self.q for r in recs]
+        self.q = []
+        return out or None
+
+
+def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, device, output_dir="", pipeline_cls=None):
     os.makedirs(output_dir, exist_ok=True)
-    model.eval()
+    pipeline_cls = pipeline_cls or PosePipeline
+    if model is not None:
+        model.eval()
     refine_w = None
     if refine_model is not None:
         refine_model.eval()
@@ -112,7 +136,7 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
         if pipe is None or pipe.B != len(imgs):
             if pipe is not None:
                 drain(pipe.flush())
-            pipe = PosePipeline(model, cfg, len(imgs), imgs.shape[-2], imgs.shape[-1], device, refine_w,
+            pipe = pipeline_cls(model, cfg, len(imgs), imgs.shape[-2], imgs.shape[-1], device, refine_w,
                                 do_flip=bool(cfg.DO_FLIP), record_mode=cfg.TEST_MODE, numpy_records=True,
                                 depth=int(os.environ.get("SMAP_PIPELINE_DEPTH", 2)))   # two backbones in flight (+19 %)
         with torch.no_grad():
@@ -148,6 +172,9 @@ def main():
     parser.add_argument("--precision", type=str, default="", choices=["", "x3", "f16"],
                         help="(addition) backbone arithmetic: x3 (default) = fp16 hi/lo pairs, three MFMAs per K step -- "
                              "reproduces the reference's fp32 forward; f16 = fp16 storage, ~2x faster, ~1e-3 relative error")
+    parser.add_argument("--dry_run", type=int, default=0,
+                        help="1: rehearse the run without a GPU or a checkpoint (stand-in pipeline, gloo gather): what a "
+                             "multi-rank launch does around the device work -- split, ragged batches, gather, result file")
     parser.add_argument("--device_preprocess", type=int, default=0,
                         help="(addition) 1: resize/pad/normalise on the GPU (smap_preprocess) instead of in the dataset")
     args = parser.parse_args()
@@ -160,17 +187,21 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    dry = bool(args.dry_run)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl")
-    torch.cuda.set_device(local)
+        dist.init_process_group("gloo" if dry else "nccl")
+    if not dry:
+        torch.cuda.set_device(local)
     os.makedirs(cfg.TEST_DIR, exist_ok=True)
     logger = get_logger(cfg.DATASET.NAME, cfg.TEST_DIR, "test_log_{}.txt".format(args.test_mode))
 
-    model = SMAP(cfg, run_efficient=cfg.RUN_EFFICIENT)
-    device = torch.device(cfg.MODEL.DEVICE, local)
-    model.to(device)
-    if args.precision:
-        model.precision = args.precision
+    device = torch.device("cpu") if dry else torch.device(cfg.MODEL.DEVICE, local)
+    model = None
+    if not dry:
+        model = SMAP(cfg, run_efficient=cfg.RUN_EFFICIENT)
+        model.to(device)
+        if args.precision:
+            model.precision = args.precision
 
     if args.test_mode != "run_inference":
         from lib.utils.dataloader import get_test_loader
@@ -191,6 +222,12 @@ def main():
         data_loader = DataLoader(Subset(dataset, indices) if world > 1 else dataset, batch_size=args.batch_size,
                                  shuffle=False)
 
+    if dry:
+        generate_3d_point_pairs(None, None, data_loader, cfg, logger, device, output_dir=os.path.join(cfg.OUTPUT_DIR, "result"),
+                                pipeline_cls=_DryRunPipeline)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     refine_model = RefineNet().to(device) if cfg.REFINE else None
     if os.path.exists(args.SMAP_path):
         state_dict = torch.load(args.SMAP_path, map_location=lambda storage, loc: storage)

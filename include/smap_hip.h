@@ -105,11 +105,13 @@ int smap_refine_gt(const double* pred_2d, const double* pred_3d, const int32_t* 
 int smap_refine_mlp(const float* x, int N, const float* const* wt, const float* const* bs, float* y,
                     void* stream);
 
-/* dataset/custom_dataset.py:27-68 (cv2 resize to fit, centre pad with 128, ToTensor, Normalize) for one
- * image on the device.  src: uint8 [h][w][3] BGR; the resized image is nh x nw and sits at (top,left)
- * of the net_h x net_w canvas; dst: fp32 [3][net_h][net_w]; mean3/std3: HOST pointers to 3 floats. */
+/* dataset/custom_dataset.py:27-68 (cv2.resize(img, (0,0), fx, fy) to fit, centre pad with 128, ToTensor, Normalize) for one
+ * image on the device.  src: uint8 [h][w][3] BGR; the resized image is nh x nw = cvRound(h*fy) x cvRound(w*fx) and sits at
+ * (top,left) of the net_h x net_w canvas; dst: fp32 [3][net_h][net_w]; mean3/std3: HOST pointers to 3 floats.  The resize is
+ * OpenCV's 8-bit INTER_LINEAR restated operation by operation (11-bit fixed-point coefficients, source coordinate
+ * (d + 0.5) / f - 0.5, the >>4 / >>16 / +2 >>2 vertical pass; exact 2x shrink = 2x2 box mean). */
 int smap_preprocess(const unsigned char* src, int h, int w, int nh, int nw, int top, int left, float* dst,
-                    int net_h, int net_w, const float* mean3, const float* std3, void* stream);
+                    int net_h, int net_w, const float* mean3, const float* std3, double fx, double fy, void* stream);
 
 /* ---- backbone: replaces model/smap.py SMAP.forward (eval) ------------------ */
 

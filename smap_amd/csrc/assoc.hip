@@ -739,8 +739,32 @@ __global__ void flip_merge_kernel(float* __restrict__ hms, const float* __restri
 // F.interpolate(align_corners=False)), round to uint8, centre into the net_h x net_w canvas padded
 // with 128, /255, (x - mean) / std.  One thread per canvas pixel, 3 channels; fp32 arithmetic in
 // ATen's operation order so that it matches the host path bit for bit.
-struct PrepArgs { int h, w, nh, nw, top, left, net_h, net_w; float mean[3], stdv[3]; };
+struct PrepArgs { int h, w, nh, nw, top, left, net_h, net_w; float mean[3], stdv[3]; double scale_x, scale_y; };
 
+// One axis of OpenCV's 8-bit INTER_LINEAR (modules/imgproc/src/resize.cpp, cv::resize -> resizeGeneric_ set-up):
+//   fx = (float)((d + 0.5) * scale - 0.5) with scale = 1 / fx_arg (double); s = floor(fx); fx -= s;
+//   s < 0 -> (0, 0);  s >= n - 1 -> (n - 1, 0);  coefficients = cvRound(c * 2048) as shorts (INTER_RESIZE_COEF_BITS = 11).
+struct CvTap { int s0, s1; int c0, c1; };
+__device__ __forceinline__ CvTap cv_tap(int d, double scale, int n)
+{
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= n - 1) { f = 0.f; s = n - 1; }
+    CvTap t;
+    t.s0 = s;
+    t.s1 = s + 1 < n ? s + 1 : s;                        // its coefficient is 0 whenever the clamp applies
+    t.c0 = (int)rintf((1.f - f) * 2048.f);               // saturate_cast<short>(float) = cvRound: half to even
+    t.c1 = (int)rintf(f * 2048.f);
+    return t;
+}
+
+// dataset/custom_dataset.py:41-68 for one image: cv2.resize(img, (0,0), fx=s, fy=s) [INTER_LINEAR, 8-bit fixed point],
+// centre pad with 128, ToTensor, Normalize.  The resize follows OpenCV's published algorithm operation by operation:
+// horizontal pass in 11-bit fixed point (int32), vertical pass ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2
+// (VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>), and the exact 2x shrink as the 2x2 box mean
+// (cv::resize switches INTER_LINEAR to INTER_AREA there).  cv2 is not in this image: parity unpinned by execution.
 __global__ void preprocess_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, PrepArgs p)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -748,21 +772,24 @@ __global__ void preprocess_kernel(const unsigned char* __restrict__ src, float* 
     float v[3] = {128.f, 128.f, 128.f};
     const int ry = y - p.top, rx = x - p.left;
     if ((unsigned)ry < (unsigned)p.nh && (unsigned)rx < (unsigned)p.nw) {
-        const float sh = (float)p.h / (float)p.nh, sw = (float)p.w / (float)p.nw;
-        float fy = sh * ((float)ry + 0.5f) - 0.5f, fx = sw * ((float)rx + 0.5f) - 0.5f;
-        fy = fy < 0.f ? 0.f : fy;
-        fx = fx < 0.f ? 0.f : fx;
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
-        const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-        const unsigned char* r0 = src + ((size_t)y0 * p.w) * 3;
-        const unsigned char* r1 = src + ((size_t)y1 * p.w) * 3;
+        if (p.scale_x == 2.0 && p.scale_y == 2.0) {      // INTER_AREA fast path: (a + b + c + d + 2) >> 2
+            const int y0 = ry * 2 < p.h ? ry * 2 : p.h - 1, y1 = ry * 2 + 1 < p.h ? ry * 2 + 1 : p.h - 1;
+            const int x0 = rx * 2 < p.w ? rx * 2 : p.w - 1, x1 = rx * 2 + 1 < p.w ? rx * 2 + 1 : p.w - 1;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float a = r0[x0 * 3 + c], b = r0[x1 * 3 + c], cc = r1[x0 * 3 + c], d = r1[x1 * 3 + c];
-            float t = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * cc + lx1 * d);
-            t = rintf(t);                                   // torch.round: half to even
-            v[c] = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
+            for (int c = 0; c < 3; ++c)
+                v[c] = (float)((src[((size_t)y0 * p.w + x0) * 3 + c] + src[((size_t)y0 * p.w + x1) * 3 + c] +
+                                src[((size_t)y1 * p.w + x0) * 3 + c] + src[((size_t)y1 * p.w + x1) * 3 + c] + 2) >> 2);
+        } else {
+            const CvTap ty = cv_tap(ry, p.scale_y, p.h), tx = cv_tap(rx, p.scale_x, p.w);
+            const unsigned char* r0 = src + ((size_t)ty.s0 * p.w) * 3;
+            const unsigned char* r1 = src + ((size_t)ty.s1 * p.w) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int h0 = r0[tx.s0 * 3 + c] * tx.c0 + r0[tx.s1 * 3 + c] * tx.c1;
+                const int h1 = r1[tx.s0 * 3 + c] * tx.c0 + r1[tx.s1 * 3 + c] * tx.c1;
+                const int t = (((ty.c0 * (h0 >> 4)) >> 16) + ((ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                v[c] = (float)(t < 0 ? 0 : (t > 255 ? 255 : t));
+            }
         }
     }
 #pragma unroll
@@ -914,11 +941,11 @@ extern "C" int smap_flip_merge(float* hms, const float* hms_flip, const int* pai
 }
 
 extern "C" int smap_preprocess(const unsigned char* src, int h, int w, int nh, int nw, int top, int left, float* dst,
-                               int net_h, int net_w, const float* mean3, const float* std3, void* stream)
+                               int net_h, int net_w, const float* mean3, const float* std3, double fx, double fy, void* stream)
 {
-    if (!src || !dst || !mean3 || !std3 || h <= 0 || w <= 0 || nh <= 0 || nw <= 0 || net_h <= 0 || net_w <= 0)
+    if (!src || !dst || !mean3 || !std3 || h <= 0 || w <= 0 || nh <= 0 || nw <= 0 || net_h <= 0 || net_w <= 0 || !(fx > 0) || !(fy > 0))
         return SMAP_E_ARG;
-    PrepArgs p{h, w, nh, nw, top, left, net_h, net_w, {mean3[0], mean3[1], mean3[2]}, {std3[0], std3[1], std3[2]}};
+    PrepArgs p{h, w, nh, nw, top, left, net_h, net_w, {mean3[0], mean3[1], mean3[2]}, {std3[0], std3[1], std3[2]}, 1.0 / fx, 1.0 / fy};
     hipLaunchKernelGGL(preprocess_kernel, dim3((net_w + 255) / 256, net_h), dim3(256), 0, (hipStream_t)stream, src, dst, p);
     return hip_rc(hipGetLastError());
 }

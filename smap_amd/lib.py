@@ -73,7 +73,7 @@ def load():
     lib.smap_register_gt.argtypes = [vp, vp, vp, vp, ip, ip, vp, vp, vp]
     lib.smap_lift_gt.argtypes = lib.smap_lift.argtypes
     lib.smap_refine_gt.argtypes = lib.smap_refine.argtypes
-    lib.smap_preprocess.argtypes = [vp, ip, ip, ip, ip, ip, ip, vp, ip, ip, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]
+    lib.smap_preprocess.argtypes = [vp, ip, ip, ip, ip, ip, ip, vp, ip, ip, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_double, C.c_double, vp]
     lib.smap_conv_tile_dims.argtypes = [ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.smap_conv_tile_bk.argtypes = [ip, ip]
     lib.smap_plan_create.argtypes = [C.POINTER(SmapOp), ip, C.POINTER(vp)]

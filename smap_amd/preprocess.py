@@ -26,33 +26,54 @@ def letterbox_geometry(w0, h0, net_w=832, net_h=512):
     return scale, (nh, nw, top, left)
 
 
-def resize_bilinear_u8(img, nh, nw):
-    """Host statement of the resize the HIP kernel performs (one rounding per written fp32 operation,
-    no FMA contraction): half-pixel-centre bilinear, the sampling rule of cv2.INTER_LINEAR /
-    F.interpolate(align_corners=False, antialias=False); result rounded half-to-even to uint8."""
+def _cv_axis(n_out, scale, n_in):
+    """OpenCV's per-axis set-up for 8-bit INTER_LINEAR (modules/imgproc/src/resize.cpp, cv::resize): source index and the
+    two 11-bit fixed-point coefficients of every destination index."""
+    f32 = np.float32
+    f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(f32)       # (float)((d + 0.5) * scale - 0.5)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(f32)).astype(f32)
+    lo, hi = s < 0, s >= n_in - 1
+    f = np.where(lo | hi, f32(0), f).astype(f32)
+    s = np.where(lo, 0, np.where(hi, n_in - 1, s))
+    c0 = np.rint((f32(1) - f) * f32(2048)).astype(np.int32)                           # saturate_cast<short>: cvRound, half to even
+    c1 = np.rint(f * f32(2048)).astype(np.int32)
+    return s, np.minimum(s + 1, n_in - 1), c0, c1
+
+
+def resize_linear_u8(img, nh, nw, fx=None, fy=None):
+    """cv2.resize(img, (0, 0), fx=fx, fy=fy) -- INTER_LINEAR on 8-bit images -- restated from OpenCV's published algorithm,
+    operation by operation (cv2 itself is not installed: parity unpinned by execution):
+      * dsize = cvRound(src * f) (the caller's nh, nw); source coordinate (d + 0.5) / f - 0.5 in double, then float;
+      * 11-bit fixed-point coefficients (INTER_RESIZE_COEF_BITS), horizontal pass in int32:  H = S[s] * a0 + S[s+1] * a1;
+      * vertical pass  dst = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2
+        (VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, 22>>);
+      * an exact 2x shrink is the 2x2 box mean (cv::resize turns INTER_LINEAR into INTER_AREA there).
+    fx / fy default to dsize / ssize (what cv2.resize does when dsize, not fx / fy, is given).  The HIP kernel
+    (csrc/assoc.hip::preprocess_kernel) computes the same integers."""
     img = np.ascontiguousarray(img)
     h, w = img.shape[:2]
-    f32 = np.float32
+    sx = 1.0 / (fx if fx is not None else nw / w)
+    sy = 1.0 / (fy if fy is not None else nh / h)
+    if sx == 2.0 and sy == 2.0:
+        y0, x0 = np.minimum(np.arange(nh) * 2, h - 1), np.minimum(np.arange(nw) * 2, w - 1)
+        y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
+        i = img.astype(np.int32)
+        return ((i[y0][:, x0] + i[y0][:, x1] + i[y1][:, x0] + i[y1][:, x1] + 2) >> 2).astype(np.uint8)
+    ys0, ys1, b0, b1 = _cv_axis(nh, sy, h)
+    xs0, xs1, a0, a1 = _cv_axis(nw, sx, w)
+    i = img.astype(np.int32)
+    a0, a1 = a0[None, :, None], a1[None, :, None]
+    h0 = i[ys0][:, xs0] * a0 + i[ys0][:, xs1] * a1
+    h1 = i[ys1][:, xs0] * a0 + i[ys1][:, xs1] * a1
+    b0, b1 = b0[:, None, None], b1[:, None, None]
+    t = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(t, 0, 255).astype(np.uint8)
 
-    def axis(n_in, n_out):
-        scale = f32(n_in) / f32(n_out)
-        src = scale * (np.arange(n_out, dtype=f32) + f32(0.5)) - f32(0.5)
-        src = np.maximum(src, f32(0))
-        i0 = src.astype(np.int64)
-        i1 = i0 + (i0 < n_in - 1)
-        l1 = (src - i0.astype(f32)).astype(f32)
-        return i0, i1, (f32(1) - l1).astype(f32), l1
 
-    y0, y1, ly0, ly1 = axis(h, nh)
-    x0, x1, lx0, lx1 = axis(w, nw)
-    a = img[y0][:, x0].astype(f32)
-    b = img[y0][:, x1].astype(f32)
-    c = img[y1][:, x0].astype(f32)
-    d = img[y1][:, x1].astype(f32)
-    lx0, lx1 = lx0[None, :, None], lx1[None, :, None]
-    ly0, ly1 = ly0[:, None, None], ly1[:, None, None]
-    t = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * c + lx1 * d)
-    return np.clip(np.rint(t), 0, 255).astype(np.uint8)
+def resize_bilinear_u8(img, nh, nw):
+    """Earlier name (dsize-only call)."""
+    return resize_linear_u8(img, nh, nw)
 
 
 def preprocess_batch(images, means, stds, device, net_w=832, net_h=512):
@@ -76,7 +97,8 @@ def preprocess_batch(images, means, stds, device, net_w=832, net_h=512):
             d = t.to(device, non_blocking=True)
             keep.append(d)
             _L.check(lib.smap_preprocess(C.c_void_p(d.data_ptr()), h0, w0, nh, nw, top, left,
-                                         C.c_void_p(out[i].data_ptr()), net_h, net_w, mean, std, st), "smap_preprocess")
+                                         C.c_void_p(out[i].data_ptr()), net_h, net_w, mean, std, scale["scale"], scale["scale"], st),
+                     "smap_preprocess")
             for k in scales:
                 scales[k].append(scale[k])
     return out, scales

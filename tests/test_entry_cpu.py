@@ -110,21 +110,42 @@ def test_two_rank_gloo_gather(tmp_path):
     assert "GATHER_OK 11" in r.stdout
 
 
-def test_host_resize_matches_torch_bilinear_within_one_lsb():
-    """resize_bilinear_u8 is F.interpolate(bilinear, align_corners=False, antialias=False) up to the
-    FMA contraction inside ATen's vectorised CPU kernel: <= 1 LSB on a tiny fraction of pixels."""
+def test_host_resize_is_opencv_fixed_point_linear():
+    """resize_linear_u8 restates OpenCV's 8-bit INTER_LINEAR (11-bit fixed-point coefficients, integer vertical pass).  Checked
+    here against (a) a scalar transcription of the published per-pixel formula on random positions, (b) the float bilinear of
+    the same sampling rule (F.interpolate, align_corners=False): the fixed-point result stays within 1 LSB of it, (c) the
+    identities OpenCV guarantees: same size = copy, exact 2x shrink = 2x2 box mean."""
+    import math
     import torch.nn.functional as F
-    from smap_amd.preprocess import resize_bilinear_u8
+    from smap_amd.preprocess import resize_linear_u8
     rng = np.random.default_rng(2)
-    for (h, w), (nh, nw) in [((300, 1000), (250, 832)), ((900, 400), (512, 228)), ((37, 53), (512, 733)),
-                             ((512, 832), (512, 832))]:
+    for (h, w), f in [((300, 1000), 0.832), ((900, 400), 512 / 900), ((37, 53), 512 / 37), ((480, 640), 1.3), ((1080, 1920), 832 / 1920)]:
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
-        got = resize_bilinear_u8(img, nh, nw).astype(np.int32)
-        t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
-        ref = F.interpolate(t, size=(nh, nw), mode="bilinear", align_corners=False, antialias=False)
-        ref = ref.round().clamp(0, 255)[0].permute(1, 2, 0).numpy().astype(np.int32)
-        diff = np.abs(got - ref)
-        assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, ((h, w), diff.max(), (diff > 0).mean())
+        nh, nw = int(round(h * f)), int(round(w * f))
+        got = resize_linear_u8(img, nh, nw, fx=f, fy=f).astype(np.int32)
+        assert got.shape == (nh, nw, 3)
+        for _ in range(300):                                   # (a) the formula, pixel by pixel
+            dy, dx, c = int(rng.integers(nh)), int(rng.integers(nw)), int(rng.integers(3))
+            def tap(d, n):
+                v = np.float32((d + 0.5) * (1.0 / f) - 0.5)
+                s = math.floor(v)
+                v = np.float32(v - np.float32(s))
+                if s < 0: s, v = 0, np.float32(0)
+                if s >= n - 1: s, v = n - 1, np.float32(0)
+                return s, min(s + 1, n - 1), int(np.rint((np.float32(1) - v) * np.float32(2048))), int(np.rint(v * np.float32(2048)))
+            y0, y1, b0, b1 = tap(dy, h)
+            x0, x1, a0, a1 = tap(dx, w)
+            h0 = int(img[y0, x0, c]) * a0 + int(img[y0, x1, c]) * a1
+            h1 = int(img[y1, x0, c]) * a0 + int(img[y1, x1, c]) * a1
+            assert got[dy, dx, c] == (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2
+        t = torch.from_numpy(img).permute(2, 0, 1)[None].float()    # (b) float bilinear of the same sampling rule
+        ref = F.interpolate(t, size=(nh, nw), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        if abs(nh / h - f) < 1e-3 and abs(nw / w - f) < 1e-3:      # (torch derives its scale from the sizes, OpenCV takes fx)
+            assert np.abs(got - ref).max() <= 1.0 + 0.02 * 255 * abs(nw / w - f) * w / 2
+    img = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    assert np.array_equal(resize_linear_u8(img, 64, 96, fx=1.0, fy=1.0), img)                       # (c)
+    box = (img.astype(np.int32).reshape(32, 2, 48, 2, 3).sum((1, 3)) + 2) >> 2
+    assert np.array_equal(resize_linear_u8(img, 32, 48, fx=0.5, fy=0.5), box.astype(np.uint8))
 
 
 def test_derived_skeleton_tables_equal_reference_constants():
@@ -246,3 +267,48 @@ def test_bench_control_flow_two_ranks_gloo():
     # the gather carries every record of the 5 timed batches of each rank (8 frames each; batches 2..6 after 2 warm-ups)
     assert d["config"]["records_per_rank"] == [40, 40]
     assert d["config"]["first_paths"] == ["r0/b2/f0", "r1/b2/f0"] and d["config"]["last_paths"] == ["r0/b6/f7", "r1/b6/f7"]
+
+
+def test_bench_control_flow_eight_ranks_gloo():
+    """The driver's 8-GPU launch line (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`) with --dry-run: all eight
+    ranks reach the one end-of-run gather, rank order == frame order, every rank's host CPU per step is reported."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "8", "--steps", "5", "--warmup", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["ranks_in_gather"] == 8
+    assert d["config"]["records_per_rank"] == [40] * 8
+    assert d["config"]["first_paths"] == [f"r{k}/b2/f0" for k in range(8)]
+    assert d["config"]["last_paths"] == [f"r{k}/b6/f7" for k in range(8)]
+    assert len(d["config"]["host_ms_per_step"]["process_cpu_per_rank"]) == 8
+
+
+def test_test_py_dry_run_eight_ranks(tmp_path):
+    """exps/stage3_root2/test.py --dry_run 1 under an 8-rank launch: 37 images (not a multiple of ranks x batch) are split in
+    contiguous blocks of ceil(37/8) = 5 (lib/utils/dataloader.py:80-85), ragged last batches are padded and their padding
+    dropped, the gather keeps rank order == image order, rank 0 writes one record per image."""
+    imgs = tmp_path / "images"
+    imgs.mkdir()
+    rng = np.random.default_rng(0)
+    names = [f"im{k:03d}.npy" for k in range(37)]
+    for n in names:
+        np.save(imgs / n, rng.integers(0, 256, (24, 40, 3), dtype=np.uint8))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PROJECT_HOME=str(tmp_path), OMP_NUM_THREADS="1",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29549",
+                        os.path.join(ROOT, "exps", "stage3_root2", "test.py"), "-t", "run_inference", "-d", "test",
+                        "--batch_size", "2", "--dataset_path", str(imgs), "--json_name", "dry", "--dry_run", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = list(tmp_path.rglob("*run_inference_test_dry.json"))
+    assert len(out) == 1, (list(tmp_path.rglob("*.json")), r.stderr[-1000:])
+    res = json.load(open(out[0]))
+    got = [rec["image_path"] for rec in res["3d_pairs"]]
+    assert got == names                                     # every image once, in listing order
+    assert all(len(rec["pred_3d"]) == 1 and len(rec["pred_3d"][0]) == 15 for rec in res["3d_pairs"])

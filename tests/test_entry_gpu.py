@@ -162,13 +162,13 @@ def test_two_stream_pipeline_equals_serial_path():
 
 
 def test_device_preprocess_equals_host_dataset(tmp_path):
-    """smap_preprocess (HIP) == dataset/custom_dataset.py (host: torch bilinear, round, pad 128, normalise),
-    bit for bit, for wide / tall / exact / tiny / odd-sized images."""
+    """smap_preprocess (HIP) == dataset/custom_dataset.py (host: OpenCV's fixed-point INTER_LINEAR restated in numpy, pad 128,
+    normalise), bit for bit, for wide / tall / exact / tiny / odd-sized images and an exact 2x shrink (box-mean path)."""
     from dataset.custom_dataset import CustomDataset
     from exps.stage3_root2.config import cfg
     from smap_amd.preprocess import preprocess_batch
     rng = np.random.default_rng(11)
-    sizes = [(300, 1000), (900, 400), (512, 832), (37, 53), (1080, 1920), (511, 833), (2000, 3001)]
+    sizes = [(300, 1000), (900, 400), (512, 832), (37, 53), (1080, 1920), (511, 833), (2000, 3001), (1024, 1664)]
     for i, (h, w) in enumerate(sizes):
         np.save(tmp_path / f"im{i:02d}.npy", rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
     ds = CustomDataset(cfg, str(tmp_path))
