@@ -339,46 +339,129 @@ __device__ void kv_std_sort(KV* a, int n)
     } else kv_insertion_sort(a, 0, n);
 }
 
-__global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ peaks_all,
+// One limb of the greedy grouping (association.cpp:171-229), run by ONE wave64: persons in depth order (sequential: the
+// ordinal prior), the <= 127 destination candidates two per lane, arg-max by xor-shuffles with the lowest index on ties
+// (== the reference's "first strict maximum" scan).  Reads body[.][src] / remap[src][.] (complete when the limb starts),
+// writes body[.][dst] / remap[dst][.]: every joint is the destination of exactly one limb.
+__device__ __forceinline__ void group_limb(GroupLds& L, const int i, const int P, const int root_idx, const int dist_flag,
+                                           const float* __restrict__ peaks, const float* __restrict__ scores, const int lane)
+{
+    const float dsScale = 4;
+    int src, dst;
+    bool flip = false;
+    if (root_idx == 2 && i == 1) { src = c_pairs[2 * i + 1]; dst = c_pairs[2 * i]; flip = true; }
+    else { src = c_pairs[2 * i]; dst = c_pairs[2 * i + 1]; }
+    const float* dp = peaks + 3 * dst * PSTRIDE;
+    const int nDst = (int)dp[0];
+    if (nDst == 0) return;
+    const float* S = scores + (size_t)i * MAXP * MAXP;
+    // this lane's two candidates
+    const int c0 = lane, c1 = lane + 64;
+    const bool v0 = c0 < nDst, v1 = c1 < nDst;
+    const float d0x = v0 ? dp[3 * (c0 + 1)] : 0.f, d0y = v0 ? dp[3 * (c0 + 1) + 1] : 0.f;
+    const float d1x = v1 ? dp[3 * (c1 + 1)] : 0.f, d1y = v1 ? dp[3 * (c1 + 1) + 1] : 0.f;
+    bool used0 = false, used1 = false;
+    for (int k1 = 0; k1 < P; ++k1) {
+        const float sscore = L.body[k1][src][3];
+        if ((double)sscore < 1e-5) continue;        // wave-uniform
+        const float sx = L.body[k1][src][0], sy = L.body[k1][src][1];
+        const float bone_dist = (float)(1.2 * (double)c_bone_length[i] / (double)L.sdepth[k1]);
+        const int rs = L.remap[src][k1];
+        float best = 0.0f;
+        int bidx = 0x7fffffff;
+        if (v0 && !used0) {
+            float score = flip ? S[c0 * MAXP + rs] : S[rs * MAXP + c0];
+            if (dist_flag && score > 0) {
+                const float ddx = sx - d0x, ddy = sy - d0y;
+                const float limb = (float)sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
+                const float pen = bone_dist / limb / dsScale - 1;
+                score += pen < 0.0f ? pen : 0.0f;
+            }
+            if (score > best) { best = score; bidx = c0; }
+        }
+        if (v1 && !used1) {
+            float score = flip ? S[c1 * MAXP + rs] : S[rs * MAXP + c1];
+            if (dist_flag && score > 0) {
+                const float ddx = sx - d1x, ddy = sy - d1y;
+                const float limb = (float)sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
+                const float pen = bone_dist / limb / dsScale - 1;
+                score += pen < 0.0f ? pen : 0.0f;
+            }
+            if (score > best) { best = score; bidx = c1; }   // c1 > c0: strict > keeps the lower index
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float os = __shfl_xor(best, d);
+            const int oi = __shfl_xor(bidx, d);
+            if (os > best || (os == best && oi < bidx)) { best = os; bidx = oi; }
+        }
+        if (best > 0) {                              // wave-uniform after the butterfly
+            if (lane == 0) {
+                L.body[k1][dst][0] = dp[3 * (bidx + 1)];
+                L.body[k1][dst][1] = dp[3 * (bidx + 1) + 1];
+                L.body[k1][dst][3] = dp[3 * (bidx + 1) + 2];
+                L.remap[dst][k1] = bidx;
+            }
+            if (bidx == c0) used0 = true;
+            if (bidx == c1) used1 = true;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // lane 0's LDS writes before the next limb of this wave reads them
+}
+
+// One WORKGROUP per frame, one wave per chain of the limb tree.  The reference walks the 14 limbs in the order
+// 1, 0, 2, 3, .. 13 (association.cpp:164-170); a limb only reads the joint its source end was assigned by an EARLIER limb
+// (or the root), so with root_idx = 2 (pelvis) the order is a tree:
+//     pelvis -1-> neck -0-> head           wave 0: limb 1, then limb 0
+//                 neck -2-> 9 -3-> 10 -4-> 11     wave 1 (after limb 1)
+//                 neck -5-> 3 -6-> 4 -7-> 5       wave 2 (after limb 1)
+//     pelvis -8-> 12 -9-> 13 -10-> 14             wave 3 (at once)
+//     pelvis -11-> 6 -12-> 7 -13-> 8              wave 4 (at once)
+// Inside a limb nothing changes (persons sequential, lowest candidate index on ties); different limbs write different
+// joints; so the result is the reference's, bit for bit, in 4 limb times instead of 14.  Any other root_idx runs the
+// reference's flat order on wave 0.
+constexpr int GROUP_WAVES = 5;
+__global__ __launch_bounds__(GROUP_WAVES * 64) void group_kernel(const float* __restrict__ peaks_all,
                                                    const float* __restrict__ scores_all,
                                                    const float* __restrict__ rdepth_all, int H, int W,
                                                    int root_idx, int dist_flag,
                                                    float* __restrict__ bodys_all, int* __restrict__ counts)
 {
     __shared__ GroupLds L;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ int neck_done;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NT = GROUP_WAVES * 64;
     const float* peaks = peaks_all + (size_t)b * NJ * PSTRIDE * 3;
     const float* scores = scores_all + (size_t)b * NL * MAXP * MAXP;
     const float* rdepth = rdepth_all + (size_t)b * H * W;
     float* bodys = bodys_all + (size_t)b * MAXP * NJ * 4;
-    const float dsScale = 4;
 
     const float* rp = peaks + 3 * root_idx * PSTRIDE;
     const int P = (int)rp[0];
-    if (lane == 0) counts[b] = P;
+    if (tid == 0) { counts[b] = P; neck_done = 0; }
     float* lb = &L.body[0][0][0];
-    for (int i = lane; i < MAXP * NJ * 4; i += 64) lb[i] = 0.f;
+    for (int i = tid; i < MAXP * NJ * 4; i += NT) lb[i] = 0.f;
     if (P == 0) {
-        for (int i = lane; i < MAXP * NJ * 4; i += 64) bodys[i] = 0.f;
+        for (int i = tid; i < MAXP * NJ * 4; i += NT) bodys[i] = 0.f;
         return;
     }
-    for (int i = lane; i < P; i += 64) {
+    for (int i = tid; i < P; i += NT) {
         L.kv[i].v = rdepth[(int)rp[3 * (i + 1) + 1] * W + (int)rp[3 * (i + 1)]];
         L.kv[i].i = i;
     }
     __syncthreads();
-    if (lane == 0) kv_std_sort(L.kv, P);           // ordinal prior: near persons first
+    if (tid == 0) kv_std_sort(L.kv, P);            // ordinal prior: near persons first
     __syncthreads();
-    for (int i = lane; i < P; i += 64) {
+    for (int i = tid; i < P; i += NT) {
         L.sidx[i] = L.kv[i].i;
         L.sdepth[i] = L.kv[i].v;
     }
     __syncthreads();
-    for (int i = lane; i < NJ * PSTRIDE; i += 64) {
+    for (int i = tid; i < NJ * PSTRIDE; i += NT) {
         const int j = i / PSTRIDE, k = i % PSTRIDE;
         if (k < P) L.remap[j][k] = (j == root_idx) ? L.sidx[k] : k;
     }
-    for (int i = lane; i < P; i += 64) {
+    for (int i = tid; i < P; i += NT) {
         const int s = L.sidx[i];
         L.body[i][root_idx][0] = rp[3 * (s + 1)];
         L.body[i][root_idx][1] = rp[3 * (s + 1) + 1];
@@ -386,69 +469,21 @@ __global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ pea
     }
     __syncthreads();
 
-    for (int j = 0; j < NL; ++j) {
-        const int i = (j == 0) ? 1 : (j == 1) ? 0 : j;
-        int src, dst;
-        bool flip = false;
-        if (root_idx == 2 && i == 1) { src = c_pairs[2 * i + 1]; dst = c_pairs[2 * i]; flip = true; }
-        else { src = c_pairs[2 * i]; dst = c_pairs[2 * i + 1]; }
-        const float* dp = peaks + 3 * dst * PSTRIDE;
-        const int nDst = (int)dp[0];
-        if (nDst == 0) continue;
-        const float* S = scores + (size_t)i * MAXP * MAXP;
-        // this lane's two candidates
-        const int c0 = lane, c1 = lane + 64;
-        const bool v0 = c0 < nDst, v1 = c1 < nDst;
-        const float d0x = v0 ? dp[3 * (c0 + 1)] : 0.f, d0y = v0 ? dp[3 * (c0 + 1) + 1] : 0.f;
-        const float d1x = v1 ? dp[3 * (c1 + 1)] : 0.f, d1y = v1 ? dp[3 * (c1 + 1) + 1] : 0.f;
-        bool used0 = false, used1 = false;
-        for (int k1 = 0; k1 < P; ++k1) {
-            const float sscore = L.body[k1][src][3];
-            if ((double)sscore < 1e-5) continue;        // wave-uniform
-            const float sx = L.body[k1][src][0], sy = L.body[k1][src][1];
-            const float bone_dist = (float)(1.2 * (double)c_bone_length[i] / (double)L.sdepth[k1]);
-            const int rs = L.remap[src][k1];
-            float best = 0.0f;
-            int bidx = 0x7fffffff;
-            if (v0 && !used0) {
-                float score = flip ? S[c0 * MAXP + rs] : S[rs * MAXP + c0];
-                if (dist_flag && score > 0) {
-                    const float ddx = sx - d0x, ddy = sy - d0y;
-                    const float limb = (float)sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
-                    const float pen = bone_dist / limb / dsScale - 1;
-                    score += pen < 0.0f ? pen : 0.0f;
-                }
-                if (score > best) { best = score; bidx = c0; }
-            }
-            if (v1 && !used1) {
-                float score = flip ? S[c1 * MAXP + rs] : S[rs * MAXP + c1];
-                if (dist_flag && score > 0) {
-                    const float ddx = sx - d1x, ddy = sy - d1y;
-                    const float limb = (float)sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
-                    const float pen = bone_dist / limb / dsScale - 1;
-                    score += pen < 0.0f ? pen : 0.0f;
-                }
-                if (score > best) { best = score; bidx = c1; }   // c1 > c0: strict > keeps the lower index
-            }
-            for (int d = 32; d >= 1; d >>= 1) {
-                const float os = __shfl_xor(best, d);
-                const int oi = __shfl_xor(bidx, d);
-                if (os > best || (os == best && oi < bidx)) { best = os; bidx = oi; }
-            }
-            if (best > 0) {                              // wave-uniform after the butterfly
-                if (lane == 0) {
-                    L.body[k1][dst][0] = dp[3 * (bidx + 1)];
-                    L.body[k1][dst][1] = dp[3 * (bidx + 1) + 1];
-                    L.body[k1][dst][3] = dp[3 * (bidx + 1) + 2];
-                    L.remap[dst][k1] = bidx;
-                }
-                if (bidx == c0) used0 = true;
-                if (bidx == c1) used1 = true;
-            }
-        }
-        __syncthreads();   // lane-0 LDS writes visible before the next limb reads them
+    if (root_idx != 2) {                              // no tree known: the reference's flat order on one wave
+        if (wave == 0)
+            for (int j = 0; j < NL; ++j) group_limb(L, (j == 0) ? 1 : (j == 1) ? 0 : j, P, root_idx, dist_flag, peaks, scores, lane);
+    } else if (wave == 0) {
+        group_limb(L, 1, P, root_idx, dist_flag, peaks, scores, lane);
+        if (lane == 0) __hip_atomic_store(&neck_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        group_limb(L, 0, P, root_idx, dist_flag, peaks, scores, lane);
+    } else {
+        const int first = wave == 1 ? 2 : wave == 2 ? 5 : wave == 3 ? 8 : 11;
+        if (wave <= 2)                                // the neck chains wait for limb 1 (wave 0 runs on its own: no deadlock)
+            while (__hip_atomic_load(&neck_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
+        for (int i = first; i < first + 3; ++i) group_limb(L, i, P, root_idx, dist_flag, peaks, scores, lane);
     }
-    for (int i = lane; i < MAXP * NJ * 4; i += 64) bodys[i] = lb[i];
+    __syncthreads();
+    for (int i = tid; i < MAXP * NJ * 4; i += NT) bodys[i] = lb[i];
 }
 
 // ------------------------------------------------------------------- lift --
@@ -840,7 +875,7 @@ int smap_group(const float* peaks, const float* scores, const float* rdepth, int
 {
     if (!peaks || !scores || !rdepth || !bodys || !counts || B <= 0 || root_idx < 0 || root_idx >= NJ)
         return SMAP_E_ARG;
-    hipLaunchKernelGGL(group_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, peaks, scores, rdepth, H, W,
+    hipLaunchKernelGGL(group_kernel, dim3(B), dim3(GROUP_WAVES * 64), 0, (hipStream_t)stream, peaks, scores, rdepth, H, W,
                        root_idx, dist_flag, bodys, counts);
     return hip_rc(hipGetLastError());
 }
