@@ -368,7 +368,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         }
         if (a.relu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < 8; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];       // NaN stays NaN, as torch's ReLU: an overflow must reach the head-sum guard
         }
         if (FULL && a.add1) {
 #pragma unroll

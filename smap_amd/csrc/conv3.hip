@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         if (a.relu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < 8; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];       // NaN stays NaN, as torch's ReLU: an overflow must reach the head-sum guard
         }
         const long long m = ((long long)b * a.Ho + oy) * a.Wo + ox;
         const long long o = m * a.out_stride_c + a.out_c_off + n;

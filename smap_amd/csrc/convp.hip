@@ -462,7 +462,7 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[ni][mi][r] = acc[ni][mi][r] > 0.f ? acc[ni][mi][r] : 0.f;
+                        for (int r = 0; r < 16; ++r) acc[ni][mi][r] = acc[ni][mi][r] < 0.f ? 0.f : acc[ni][mi][r];   // NaN stays NaN (torch's ReLU)
             }
             if (a.add1) add_tensor(a.add1);
             if (a.add2) add_tensor(a.add2);

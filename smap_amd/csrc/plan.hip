@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = X3 ? acc[nt][t][4 * q + e] * acc_scale + bb[e] : acc[nt][t][4 * q + e] + bb[e];
-                    v = v > 0.f ? v : 0.f;
+                    v = v < 0.f ? 0.f : v;                 // NaN stays NaN (torch's ReLU)
                     h[e] = (_Float16)v;
                     l[e] = (_Float16)(v - (float)h[e]);
                 }
@@ -228,10 +228,10 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
                 const float4 bv = *reinterpret_cast<const float4*>(bias + n0);
                 half4 h;
                 float v;
-                v = acc[nt][t][4 * q + 0] + bv.x; h[0] = (_Float16)(live && v > 0.f ? v : 0.f);
-                v = acc[nt][t][4 * q + 1] + bv.y; h[1] = (_Float16)(live && v > 0.f ? v : 0.f);
-                v = acc[nt][t][4 * q + 2] + bv.z; h[2] = (_Float16)(live && v > 0.f ? v : 0.f);
-                v = acc[nt][t][4 * q + 3] + bv.w; h[3] = (_Float16)(live && v > 0.f ? v : 0.f);
+                v = acc[nt][t][4 * q + 0] + bv.x; h[0] = (_Float16)((!live || v < 0.f) ? 0.f : v);
+                v = acc[nt][t][4 * q + 1] + bv.y; h[1] = (_Float16)((!live || v < 0.f) ? 0.f : v);
+                v = acc[nt][t][4 * q + 2] + bv.z; h[2] = (_Float16)((!live || v < 0.f) ? 0.f : v);
+                v = acc[nt][t][4 * q + 3] + bv.w; h[3] = (_Float16)((!live || v < 0.f) ? 0.f : v);
                 *reinterpret_cast<half4*>(s_t + sl * 64 + n0) = h;
             }
     }
@@ -287,10 +287,10 @@ __global__ void maxpool_kernel(const _Float16* __restrict__ in, _Float16* __rest
                 if (X3) {
                     const half8 vl = *reinterpret_cast<const half8*>(ip + C);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e] + (float)vl[e]);
+                    for (int e = 0; e < 8; ++e) { const float x = (float)v[e] + (float)vl[e]; m[e] = (x > m[e] || x != x) ? x : m[e]; }   // ATen's rule: NaN sticks
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+                    for (int e = 0; e < 8; ++e) { const float x = (float)v[e]; m[e] = (x > m[e] || x != x) ? x : m[e]; }
                 }
             }
         }
@@ -337,7 +337,7 @@ __global__ void upadd_kernel(const _Float16* __restrict__ a, const _Float16* __r
             const float up = ly.l0 * (lx.l0 * (float)v00[e] + lx.l1 * (float)v01[e]) +
                              ly.l1 * (lx.l0 * (float)v10[e] + lx.l1 * (float)v11[e]);
             float v = (float)av[e] + up;
-            if (relu) v = v > 0.f ? v : 0.f;
+            if (relu) v = v < 0.f ? 0.f : v;
             r[e] = (_Float16)v;
         }
         *reinterpret_cast<half8*>(out + o) = r;

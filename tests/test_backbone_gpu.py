@@ -505,17 +505,20 @@ def test_full_size_forward_vs_cpu_oracle(precision, tol_max, tol_mean):
         assert ((a - b).abs().mean() / b.abs().mean()).item() < tol_mean, k
 
 
-@pytest.mark.parametrize("scale", [1e-4, 1.0, 3e3, 1e5])
-def test_split_precision_dynamic_range(scale):
-    """Split precision keeps fp16's RANGE: activations around 1e-4 have subnormal lo parts, activations beyond 65504 turn into
-    inf.  Scaling the input image scales every activation of the (bias-free up to BN shifts) early layers; the contract is
-    EITHER maps within 1e-4 of the fp32 reference OR the status word set (RuntimeError from raise_if_nonfinite / PosePipeline)
-    -- never silently wrong maps."""
+@pytest.mark.parametrize("scale,stem_gain", [(1e-4, 1.0), (1.0, 1.0), (3e3, 1.0), (1e5, 1.0), (1.0, 1e-4), (1.0, 1e3), (1.0, 1e5)])
+def test_split_precision_dynamic_range(scale, stem_gain):
+    """Split precision keeps fp16's RANGE: values around 1e-4 have subnormal lo parts, values beyond 65504 turn into inf.
+    `scale` multiplies the input image; `stem_gain` multiplies the folded output of the stem (BN weight and bias of top.conv),
+    i.e. the activations that enter layer1 of every stage-0 block (ReLU and max-pool are homogeneous).  The contract is EITHER
+    maps within 1e-4 of the fp32 reference OR the status word set (RuntimeError from raise_if_nonfinite / PosePipeline) --
+    never silently wrong maps."""
     from smap_amd.model.smap import SMAP
     from oracle.backbone_ref import smap_forward
     torch.manual_seed(0)
     net = SMAP(make_cfg((16, 24))).eval()                  # (its own module: other tests edit the shared fixture's weights)
     sd = recipe_state_dict(net.state_dict())
+    sd["top.conv.bn.weight"] = sd["top.conv.bn.weight"] * stem_gain
+    sd["top.conv.bn.bias"] = sd["top.conv.bn.bias"] * stem_gain
     net.load_state_dict(sd)
     x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(4)) * scale
     with torch.no_grad():
@@ -529,11 +532,11 @@ def test_split_precision_dynamic_range(scale):
     if not finite:
         with pytest.raises(RuntimeError, match="fp16 range"):
             eng.raise_if_nonfinite(out)
-        assert scale >= 3e3, "only large activations may overflow"
+        assert scale >= 3e3 or stem_gain >= 1e3, "only large activations may overflow"
         return
     for a, b, k in zip(got, ref, ("hms", "det_d", "root_d")):
         err = (a - b).abs().max().item() / b.abs().max().item()
-        assert err < 1e-4, (k, scale, err)
+        assert err < 1e-4, (k, scale, stem_gain, err)
 
 
 def test_graph_replay_equals_direct_launches(small):

@@ -65,6 +65,7 @@ def _assert_north_star(m):
     """Same peaks (above floating-point resolution), same skeletons and limbs, 3D joints within 1e-3 m."""
     assert m["peaks_clear_mismatch"] == 0, m                               # no peak differs that was not a floating-point tie
     assert m["peaks_differing"] <= max(2, 3 * m["peaks_ref"] // 10000), m   # ... and such ties are rare (3 per 10 000)
+    assert m["peaks_cap_shifted"] <= 2 * m["peaks_differing"], m           # the 127-cap moves only where a tie moved it
     assert m["peak_match"] >= 1.0 - 1e-3
     # a flipped near-tie can change the one skeleton it belongs to; everything that is paired must agree
     assert m["person_match"] >= 1.0 - 2.0 * max(m["peaks_differing"], 0) / max(m["persons_ref"], 1) - 1e-12

@@ -230,6 +230,15 @@ def test_peak_ties_are_told_from_real_mismatches():
     bad_hip[7, 20, 30] = 0.1                                          # a clear peak lost
     m = parity.compare([frame(bad_hip)], [frame(base)])
     assert m["peaks_differing"] == 1 and m["peaks_clear_mismatch"] == 1 and m["peaks_differing_max_margin"] > 0.1
+    # more than 127 candidates in a channel: a tie near the top of the raster also moves the cap at its end -- one decision
+    # differs (the tie), one perfectly clear peak is swapped in / out as a CONSEQUENCE (counted apart, not a mismatch)
+    crowd = base.copy()
+    ys, xs = np.meshgrid(np.arange(4, 30, 2), np.arange(2, 46, 2), indexing="ij")
+    crowd[9, ys.ravel()[:130], xs.ravel()[:130]] = 0.9                 # 130 isolated clear peaks in channel 9 (rows 4..)
+    c_ref, c_hip = crowd.copy(), crowd.copy()
+    c_ref[9, 1, 8], c_hip[9, 1, 8] = 0.2 + 2e-7, 0.2 - 2e-7           # a tie above them all in raster order
+    m = parity.compare([frame(c_hip)], [frame(c_ref)])
+    assert m["peaks_differing"] == 1 and m["peaks_clear_mismatch"] == 0 and m["peaks_cap_shifted"] == 1
 
 
 def test_people_weights_are_calibrated_data_not_weights():
