@@ -141,7 +141,7 @@ def compare(hip, ref, root_idx=2):
     errs, rz_errs = [], []
     worst_frame = None
     margins = []
-    cap_shifted = 0
+    cap_shifted = n_cand = 0
     maps = {"hms": 0.0, "det_d": 0.0, "root_d": 0.0}
     for f, (a, b) in enumerate(zip(hip, ref)):
         for k in maps:                                                  # backbone: max |d| / max |ref| per output
@@ -152,6 +152,7 @@ def compare(hip, ref, root_idx=2):
             # of the tie, counted separately (peaks_cap_shifted), not a second decision that differs
             ua, ub = peak_pixels(a["hms"][:NJ], cap=False), peak_pixels(b["hms"][:NJ], cap=False)
             margins.extend(decision_margin(b["hms"][:NJ], *p) for p in ua ^ ub)
+            n_cand += len(ub)
             pa, pb = peak_pixels(a["hms"][:NJ]), peak_pixels(b["hms"][:NJ])
             cap_shifted += sum(1 for p in pa ^ pb if p in ua and p in ub)
         for c in range(NJ):
@@ -184,6 +185,7 @@ def compare(hip, ref, root_idx=2):
         "peak_match": m_pk / n_pk if n_pk else 1.0, "peaks_unmatched": int(n_pk - m_pk),
         "peaks_differing": len(margins), "peaks_differing_max_margin": float(max(margins)) if margins else 0.0,
         "peaks_clear_mismatch": int(sum(m > NEAR_TIE for m in margins)), "peaks_cap_shifted": int(cap_shifted),
+        "peak_candidates_ref": int(n_cand),        # every pixel the NMS rule accepts in the reference maps (before the 127-cap)
         "persons_ref": int(sum(len(b["bodys"]) for b in ref)), "person_match": m_pe / n_pe if n_pe else 1.0,
         "limb_match": m_j / n_j if n_j else 1.0, "joints_compared": int(errs.size),
         "mpjpe_cm": float(errs.mean()) if errs.size else 0.0, "max_joint_err_cm": float(errs.max()) if errs.size else 0.0,

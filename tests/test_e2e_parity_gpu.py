@@ -64,7 +64,8 @@ def _dump(name, m):
 def _assert_north_star(m):
     """Same peaks (above floating-point resolution), same skeletons and limbs, 3D joints within 1e-3 m."""
     assert m["peaks_clear_mismatch"] == 0, m                               # no peak differs that was not a floating-point tie
-    assert m["peaks_differing"] <= max(2, 3 * m["peaks_ref"] // 10000), m   # ... and such ties are rare (3 per 10 000)
+    # ... and such ties are rare: 3 per 10 000 of the pixels the NMS rule accepts (before the 127-cap, where the decisions are made)
+    assert m["peaks_differing"] <= max(2, 3 * max(m["peak_candidates_ref"], m["peaks_ref"]) // 10000), m
     assert m["peaks_cap_shifted"] <= 2 * m["peaks_differing"], m           # the 127-cap moves only where a tie moved it
     assert m["peak_match"] >= 1.0 - 1e-3
     # a flipped near-tie can change the one skeleton it belongs to; everything that is paired must agree
@@ -147,6 +148,16 @@ def test_split_precision_flip_tta_end_to_end(kind):
     kpt = cfg.DATASET.KEYPOINT.NUM
     pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
     net, sd, imgs = _setup(kind)
+    # the merge ADDS the key-point maps of the two passes (test.py:62-66: only the PAF channels are halved), which would put
+    # every channel of this workload at the 127-peak cap; halving the key-point heads brings the summed maps back to the
+    # calibrated level (~24 peaks per channel, candidates on both sides of the 0.2 threshold: the regime worth testing)
+    for u in ("up2", "up3", "up4"):
+        for t in ("weight", "bias"):
+            k = f"stage2.upsample.{u}.res_conv2.bn.{t}"
+            v = sd[k].clone()
+            v[:kpt] *= 0.5
+            sd[k] = v
+    net.load_state_dict(sd)
     net.precision = "x3"
     net = net.to(DEV)
     cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (B, 1))
@@ -155,7 +166,7 @@ def test_split_precision_flip_tta_end_to_end(kind):
     m = parity.compare(hip, ref)
     m.update(precision="x3", weights=kind, batch=B, flip_tta=True)
     _dump(f"e2e_parity_x3_flip_{kind}.json", m)
-    assert m["peaks_ref"] >= 20 * B                  # the summed key-point maps sit higher: more candidates, capped at 127
+    assert m["peaks_ref"] >= 20 * B and m["persons_ref"] >= 4 * B
     _assert_north_star(m)
 
 
