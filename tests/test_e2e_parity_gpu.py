@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 B, H, W = 8, 512, 832
 _REF = {}
+KPT_GAIN_FLIP = float(os.environ.get("SMAP_TEST_KPT_GAIN_FLIP", "0.6"))   # see test_split_precision_flip_tta_end_to_end
 
 
 def _setup(kind):
@@ -149,13 +150,13 @@ def test_split_precision_flip_tta_end_to_end(kind):
     pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
     net, sd, imgs = _setup(kind)
     # the merge ADDS the key-point maps of the two passes (test.py:62-66: only the PAF channels are halved), which would put
-    # every channel of this workload at the 127-peak cap; halving the key-point heads brings the summed maps back to the
-    # calibrated level (~24 peaks per channel, candidates on both sides of the 0.2 threshold: the regime worth testing)
+    # every channel of this workload at the 127-peak cap; scaling the key-point heads by 0.6 (sum of two decorrelated passes:
+    # mean x1.2, noise x0.85) brings the summed maps back near the calibrated level: candidates on both sides of the threshold
     for u in ("up2", "up3", "up4"):
         for t in ("weight", "bias"):
             k = f"stage2.upsample.{u}.res_conv2.bn.{t}"
             v = sd[k].clone()
-            v[:kpt] *= 0.5
+            v[:kpt] *= KPT_GAIN_FLIP
             sd[k] = v
     net.load_state_dict(sd)
     net.precision = "x3"
@@ -166,7 +167,7 @@ def test_split_precision_flip_tta_end_to_end(kind):
     m = parity.compare(hip, ref)
     m.update(precision="x3", weights=kind, batch=B, flip_tta=True)
     _dump(f"e2e_parity_x3_flip_{kind}.json", m)
-    assert m["peaks_ref"] >= 20 * B and m["persons_ref"] >= 4 * B
+    assert m["peaks_ref"] >= 20 * B and m["persons_ref"] >= B, m
     _assert_north_star(m)
 
 
