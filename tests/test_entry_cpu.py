@@ -190,7 +190,8 @@ def test_record_builders_reproduce_reference_json(golden_dir):
 
 
 def test_p2p_dataset_matches_reference_golden(golden_dir, tmp_path):
-    from dataset.p2p_dataset import P2PDataset
+    sys.path.insert(0, os.path.join(ROOT, "tools"))                # a test-support reader now: the RefineNet TRAINING data set is out of scope
+    from p2p_dataset import P2PDataset
     z = np.load(f"{golden_dir}/p2p.npz")
     path = tmp_path / "train.json"
     path.write_text(bytes(z["json"]).decode())
