@@ -12,6 +12,7 @@
 #include <new>
 #include <cstdlib>
 #include <vector>
+#include <type_traits>
 #include "smap_hip.h"
 #include "plan.h"
 
@@ -149,27 +150,36 @@ constexpr int SP_PY = 8, SP_PX = 7, SP_SY = 2 * SP_PY + 1, SP_SX = 2 * SP_PX + 1
 constexpr int SP_PH = (SP_SY - 1) * 2 + 7, SP_PW = 40;                                  // input patch rows (39), padded row
 static_assert(SP_SY * SP_SX <= 256 && (SP_SX - 1) * 2 + 8 <= SP_PW, "stem+pool tile");
 
+// X3 / flip_from: as in stem_kernel (hi/lo planes, three MFMAs per K step, mirrored read of frames >= flip_from); the conv
+// tile then stays in LDS as fp32 (the maximum is taken over the exact value, then re-split).
+template <bool X3>
 __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict__ img, const _Float16* __restrict__ wk,
                                                         const float* __restrict__ bias, _Float16* __restrict__ out,
-                                                        int H, int W, int Hs, int Ws, int Ho, int Wo)
+                                                        int H, int W, int Hs, int Ws, int Ho, int Wo, float acc_scale, int flip_from)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 s_w[64 * ST_K];
-    __shared__ __attribute__((aligned(16))) _Float16 s_p[3 * SP_PH * SP_PW];
-    __shared__ __attribute__((aligned(16))) _Float16 s_t[256 * 64];                    // conv tile, [pixel slot][channel]
+    constexpr int NPL = X3 ? 2 : 1;
+    typedef typename std::conditional<X3, float, _Float16>::type tile_t;
+    __shared__ __attribute__((aligned(16))) _Float16 s_w[NPL * 64 * ST_K];
+    __shared__ __attribute__((aligned(16))) _Float16 s_p[NPL * 3 * SP_PH * SP_PW];
+    __shared__ __attribute__((aligned(16))) tile_t s_t[256 * 64];                       // conv tile, [pixel slot][channel]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, py0 = blockIdx.y * SP_PY, px0 = blockIdx.x * SP_PX;
     const int sy0 = py0 * 2 - 1, sx0 = px0 * 2 - 1;                                     // first conv pixel of the tile
-    for (int i = tid; i < 64 * ST_K / 8; i += 256)
+    for (int i = tid; i < NPL * 64 * ST_K / 8; i += 256)
         reinterpret_cast<half8*>(s_w)[i] = reinterpret_cast<const half8*>(wk)[i];
     const int iy0 = sy0 * 2 - 3, ix0 = sx0 * 2 - 3;
+    const bool mirror = flip_from > 0 && b >= flip_from;
+    const int bsrc = mirror ? b - flip_from : b;
     for (int i = tid; i < 3 * SP_PH * SP_PW; i += 256) {
         const int c = i / (SP_PH * SP_PW), r = i - c * SP_PH * SP_PW;
         const int py = r / SP_PW, px = r - py * SP_PW;
         const int iy = iy0 + py, ix = ix0 + px;
         float v = 0.f;
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            v = img[(((size_t)b * 3 + c) * H + iy) * W + ix];
-        s_p[i] = (_Float16)v;
+            v = img[(((size_t)bsrc * 3 + c) * H + iy) * W + (mirror ? W - 1 - ix : ix)];
+        const _Float16 hi = (_Float16)v;
+        s_p[i] = hi;
+        if (X3) s_p[3 * SP_PH * SP_PW + i] = (_Float16)(v - (float)hi);
     }
     __syncthreads();
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -196,24 +206,32 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
         const int gg = g < 21 ? g : 20;
         const int kh = gg / 3, c = gg - kh * 3;
         const int goff = (c * SP_PH + kh) * SP_PW;
-        half8 wf[2], pf[2];
+        half8 wf[NPL][2], pf[NPL][2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            wf[nt] = *reinterpret_cast<const half8*>(s_w + (nt * 32 + l31) * ST_K + g * 8);
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const unsigned* q = reinterpret_cast<const unsigned*>(s_p + pbase[t] + goff);
-            union { unsigned u[4]; half8 h; } cv;
-            cv.u[0] = q[0]; cv.u[1] = q[1]; cv.u[2] = q[2]; cv.u[3] = q[3];
-            pf[t] = cv.h;
+            for (int nt = 0; nt < 2; ++nt)
+                wf[pl][nt] = *reinterpret_cast<const half8*>(s_w + pl * 64 * ST_K + (nt * 32 + l31) * ST_K + g * 8);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned* q = reinterpret_cast<const unsigned*>(s_p + pl * 3 * SP_PH * SP_PW + pbase[t] + goff);
+                union { unsigned u[4]; half8 h; } cv;
+                cv.u[0] = q[0]; cv.u[1] = q[1]; cv.u[2] = q[2]; cv.u[3] = q[3];
+                pf[pl][t] = cv.h;
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], pf[t], acc[nt][t], 0, 0, 0);
+            for (int t = 0; t < 2; ++t) {
+                if (X3) {
+                    acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[NPL - 1][nt], pf[0][t], acc[nt][t], 0, 0, 0);
+                    acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nt], pf[NPL - 1][t], acc[nt][t], 0, 0, 0);
+                }
+                acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nt], pf[0][t], acc[nt][t], 0, 0, 0);
+            }
     }
-    // bias + ReLU -> fp16 conv tile in LDS (zero where the conv pixel lies outside the image)
+    // bias + ReLU -> conv tile in LDS (zero where the conv pixel lies outside the image)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int sl = slot[t];
@@ -226,13 +244,13 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
             for (int q = 0; q < 4; ++q) {
                 const int n0 = nt * 32 + 8 * q + 4 * lhi;
                 const float4 bv = *reinterpret_cast<const float4*>(bias + n0);
-                half4 h;
-                float v;
-                v = acc[nt][t][4 * q + 0] + bv.x; h[0] = (_Float16)((!live || v < 0.f) ? 0.f : v);
-                v = acc[nt][t][4 * q + 1] + bv.y; h[1] = (_Float16)((!live || v < 0.f) ? 0.f : v);
-                v = acc[nt][t][4 * q + 2] + bv.z; h[2] = (_Float16)((!live || v < 0.f) ? 0.f : v);
-                v = acc[nt][t][4 * q + 3] + bv.w; h[3] = (_Float16)((!live || v < 0.f) ? 0.f : v);
-                *reinterpret_cast<half4*>(s_t + sl * 64 + n0) = h;
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = X3 ? acc[nt][t][4 * q + e] * acc_scale + bb[e] : acc[nt][t][4 * q + e] + bb[e];
+                    v = (!live || v < 0.f) ? 0.f : v;          // NaN stays NaN
+                    s_t[sl * 64 + n0 + e] = (tile_t)v;
+                }
             }
     }
     __syncthreads();
@@ -242,17 +260,31 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
         const int py = pp / SP_PX, px = pp - py * SP_PX;
         const int oy = py0 + py, ox = px0 + px;
         if (oy >= Ho || ox >= Wo) continue;
-        half8 m = *reinterpret_cast<const half8*>(s_t + ((2 * py) * SP_SX + 2 * px) * 64 + cg * 8);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (float)s_t[((2 * py) * SP_SX + 2 * px) * 64 + cg * 8 + e];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 if (dy == 0 && dx == 0) continue;
-                const half8 v = *reinterpret_cast<const half8*>(s_t + ((2 * py + dy) * SP_SX + 2 * px + dx) * 64 + cg * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+                for (int e = 0; e < 8; ++e) {
+                    const float x = (float)s_t[((2 * py + dy) * SP_SX + 2 * px + dx) * 64 + cg * 8 + e];
+                    m[e] = (x > m[e] || x != x) ? x : m[e];    // ATen's rule: NaN sticks
+                }
             }
-        *reinterpret_cast<half8*>(out + (((size_t)b * Ho + oy) * Wo + ox) * 64 + cg * 8) = m;
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (_Float16)m[e];
+        _Float16* op = out + (((size_t)b * Ho + oy) * Wo + ox) * (NPL * 64) + cg * 8;
+        *reinterpret_cast<half8*>(op) = h;
+        if (X3) {
+            half8 l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) l[e] = (_Float16)(m[e] - (float)h[e]);
+            *reinterpret_cast<half8*>(op + 64) = l;
+        }
     }
 }
 
@@ -451,8 +483,9 @@ static int validate(const smap_op& o)
 {
     if (o.B <= 0 || o.H <= 0 || o.W <= 0 || o.Ho <= 0 || o.Wo <= 0 || o.Cout <= 0) return SMAP_E_ARG;
     if (o.precision != 0 && o.precision != 1) return SMAP_E_ARG;
-    if (o.precision == 1 && o.kind != SMAP_OP_CONV && o.kind != SMAP_OP_STEM && o.kind != SMAP_OP_MAXPOOL && o.kind != SMAP_OP_HEADSUM)
-        return SMAP_E_ARG;                               // UPADD / STEMPOOL have no split-precision instance
+    if (o.precision == 1 && o.kind != SMAP_OP_CONV && o.kind != SMAP_OP_STEM && o.kind != SMAP_OP_MAXPOOL && o.kind != SMAP_OP_HEADSUM &&
+        o.kind != SMAP_OP_STEMPOOL)
+        return SMAP_E_ARG;                               // UPADD has no split-precision instance
     switch (o.kind) {
         case SMAP_OP_CONV: {
             int bm, bn;
@@ -489,6 +522,7 @@ static int validate(const smap_op& o)
         case SMAP_OP_STEMPOOL: {
             const int hs = (o.H + 6 - 7) / 2 + 1, ws = (o.W + 6 - 7) / 2 + 1;
             if (o.Cin != 3 || o.Cout != 64 || o.Ho != (hs + 2 - 3) / 2 + 1 || o.Wo != (ws + 2 - 3) / 2 + 1) return SMAP_E_ARG;
+            if (o.flip_from < 0 || (o.flip_from > 0 && o.B != 2 * o.flip_from)) return SMAP_E_ARG;
             return 0;
         }
         case SMAP_OP_MAXPOOL:
@@ -622,10 +656,16 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                 if (!input) return SMAP_E_ARG;
                 const int hs = (o.H + 6 - 7) / 2 + 1, ws = (o.W + 6 - 7) / 2 + 1;
                 dim3 grid((o.Wo + SP_PX - 1) / SP_PX, (o.Ho + SP_PY - 1) / SP_PY, o.B);
-                hipLaunchKernelGGL(stem_pool_kernel, grid, dim3(256), 0, st, input,
-                                   reinterpret_cast<const _Float16*>(wb + o.w_off),
-                                   reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, hs, ws,
-                                   o.Ho, o.Wo);
+                if (o.precision)
+                    hipLaunchKernelGGL(stem_pool_kernel<true>, grid, dim3(256), 0, st, input,
+                                       reinterpret_cast<const _Float16*>(wb + o.w_off),
+                                       reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, hs, ws,
+                                       o.Ho, o.Wo, o.acc_scale, o.flip_from);
+                else
+                    hipLaunchKernelGGL(stem_pool_kernel<false>, grid, dim3(256), 0, st, input,
+                                       reinterpret_cast<const _Float16*>(wb + o.w_off),
+                                       reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, hs, ws,
+                                       o.Ho, o.Wo, 1.f, o.flip_from);
                 e = hipGetLastError();
                 break;
             }

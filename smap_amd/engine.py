@@ -418,7 +418,7 @@ class Graph:
         H4, W4 = (H2 + 2 - 3) // 2 + 1, (W2 + 2 - 3) // 2 + 1
         self.flops += 2 * B * H2 * W2 * 64 * 147
         stem_p = dict(w_off=self._add_w(wk), bias_off=self._add_w(b.to(torch.float32)), w_ref=w, b_ref=b, acc_scale=stem_scale)
-        if self.x3 or self.flip_pair is not None or not os.environ.get("SMAP_STEMPOOL"):         # default: conv and max-pool as two kernels (the fused kernel below is
+        if not os.environ.get("SMAP_STEMPOOL"):         # default: conv and max-pool as two kernels (the fused kernel below is
             t = self.tensor("top.conv", H2, W2, 64)     # bit-identical but no faster inside the two-batch pipeline)
             self.ops.append(Op(OP_STEM, out=t, p=stem_p))
             x = self.tensor("top.pool", H4, W4, 64)

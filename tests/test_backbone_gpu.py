@@ -557,24 +557,27 @@ def test_graph_replay_equals_direct_launches(small):
             assert all(torch.equal(a, b) for a, b in zip(got, w))
 
 
+@pytest.mark.parametrize("precision,flip", [("f16", False), ("x3", False), ("x3", True)])
 @pytest.mark.parametrize("hw", [(64, 96), (96, 160), (512, 832)])
-def test_stem_pool_fusion_is_bit_exact(small, monkeypatch, hw):
+def test_stem_pool_fusion_is_bit_exact(small, monkeypatch, hw, precision, flip):
     """ResNet_top as one kernel (stem_pool_kernel: conv tile in LDS, 3x3 s2 max from there) writes the same pooled tensor
-    as stem_kernel + maxpool_kernel, bit for bit, including ragged pooled tiles and image borders."""
+    as stem_kernel + maxpool_kernel, bit for bit, including ragged pooled tiles and image borders -- in both precisions and
+    with the mirrored half of a flip-TTA batch."""
     from smap_amd.engine import BackboneEngine, OP_STEMPOOL
     _, sd = small
     H, W = hw
     x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(H)).to(DEV) * 2
+    fp = list(range(43)) if flip else None
     monkeypatch.setenv("SMAP_STEMPOOL", "1")
-    eng = BackboneEngine(sd, 1, H, W, DEV, reuse=False)
+    eng = BackboneEngine(sd, 1, H, W, DEV, reuse=False, precision=precision, flip_pair=fp)
     assert eng.graph.ops[0].kind == OP_STEMPOOL
     eng.run(x, first=0, count=1)
     got = eng.read_tensor("top.pool").clone()
     monkeypatch.delenv("SMAP_STEMPOOL")
-    ref = BackboneEngine(sd, 1, H, W, DEV, reuse=False)
+    ref = BackboneEngine(sd, 1, H, W, DEV, reuse=False, precision=precision, flip_pair=fp)
     ref.run(x, first=0, count=2)
     want = ref.read_tensor("top.pool")
     torch.cuda.synchronize()
-    assert got.shape == want.shape == (1, H // 4, W // 4, 64)
+    assert got.shape == want.shape == (2 if flip else 1, H // 4, W // 4, 64)
     assert torch.equal(got, want)
     assert want.abs().max() > 0
