@@ -163,4 +163,10 @@ class SMAP(nn.Module):
         eng = self.engine(B, H, W, imgs.device)
         # a fresh output buffer per call (caching allocator: no device copy), so the caller owns what it gets back --
         # the reference returns new tensors too -- while the engine's arena is reused by the next forward
-        return eng.run(imgs.float(), out=eng.new_output())
+        out = eng.new_output()
+        res = eng.run(imgs.float(), out=out)
+        # the engine's arithmetic keeps fp16's RANGE: an activation beyond 65504 ends as NaN in the maps and sets the status word
+        # behind them.  Checking it costs a host sync, so direct callers opt in (PosePipeline checks every batch it collects anyway).
+        if os.environ.get("SMAP_CHECK_FINITE"):
+            eng.raise_if_nonfinite(out)
+        return res

@@ -9,7 +9,7 @@ import csv
 import json
 import sys
 
-CONV = ("conv_igemm", "conv3x3_halo", "conv1x1_ws")
+CONV = ("conv_igemm", "conv3x3_halo", "conv1x1_ws", "convp_kernel")
 
 
 def total(path, counter):
