@@ -148,7 +148,8 @@ typedef struct smap_op {
                                          [n tile][K tile][plane][BN rows][16-byte slots]
                                        BN = the N extent of `tile` (smap_conv_tile_dims), K tile = smap_conv_tile_bk(tile,
                                        precision) halves in K order, slot s of row r = K granule s ^ ((r>>1)&7) (64-half
-                                       tiles) or s ^ ((r>>2)&3) (32-half tiles); halo tiles 30..39: blocks ordered
+                                       tiles) or s ^ ((r>>2)&3) (32-half tiles; with w_pairs = 1 those are stored in PAIRS,
+                                       [n tile][pair][plane][BN rows][tile 2p (64 B) | tile 2p+1 (64 B)]: 128-byte rows); halo tiles 30..39: blocks ordered
                                        [n tile][channel chunk][tap], 128-byte rows of 64 channels (precision 1: of 32
                                        channels as granules 0..3 = hi, 4..7 = lo), slot s = granule s ^ ((r>>1)&7).
                                        Reference packer: smap_amd/engine.py::pack_conv_weights.  + fp32 bias [cout_pad].
@@ -176,6 +177,8 @@ typedef struct smap_op {
                                        are merged into frame b: out[b,c,y,x] = v[b,c,y,x] + s_c * v[b+flip_from, pair[c], y,
                                        W-1-x], s_c = -1 on PAF-x channels (c >= in_c_off, (c - in_c_off) even), then
                                        channels >= in_c_off are halved; pair = int32[Cout] at w_off in the weight blob. */
+    int32_t w_pairs;                /* CONV, 32-half K tiles only: 1 = the weight blob stores them in pairs (see w_off), 0 = one
+                                       contiguous block per K tile */
     int32_t status_off;             /* HEADSUM: byte offset (> 0) in the fp32 output buffer of an int32 STATUS word, or 0 = none.
                                        smap_plan_run clears it, the head sum ORs in 1 when a value it writes is not finite:
                                        split precision keeps fp16's RANGE, an activation beyond 65504 turns into inf / NaN

@@ -44,7 +44,7 @@ def run_graph(g, imgs, quantize, keep=False):
                 K = k * k * cin
                 from smap_amd.engine import unpack_conv_weights      # the blob holds pre-tiled weight blocks
                 wk = unpack_conv_weights(blob[p["w_off"]:p["w_off"] + p["cout_pad"] * K * 2].view(torch.float16), p["tile"], False,
-                                         k, cin, p["cout_pad"])[0]
+                                         k, cin, p["cout_pad"], pairs=p["w_pairs"])[0]
                 w = wk[:cout].float().view(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()
                 b = blob[p["bias_off"]:p["bias_off"] + p["cout_pad"] * 4].view(torch.float32)[:cout].clone()
             else:

@@ -111,15 +111,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     // (smap_amd/engine.py::pack_conv_weights), so a wave-wide LDS-DMA reads ONE contiguous KiB -- strided 64-byte row
     // segments of a [cout][K] matrix stream from L2 at half that rate (tools/ubench/lds_dma_rows.hip).  The weight half of
     // K tile 0 goes out at once: it does not depend on the pixel arithmetic below, its L2 latency overlaps the set-up.
-    constexpr int WBLK = NPL * BN * ROWB;                       // bytes of one packed weight tile
-    const unsigned w_lane = (unsigned)((wave * RPW) * ROWB + lane * 16);
-    const char* __restrict__ wt_tile = wt + (long long)n_tile * (a.K / BK) * WBLK;
+    // (uniform 64-bit base in SGPRs) + (32-bit per-lane offset in one VGPR), like the activation side: no per-lane 64-bit math.
+    // BK = 32 tiles are packed in PAIRS of K tiles (128-byte rows = [tile 2p | tile 2p+1]): the line fetched for one K tile
+    // already holds the next one's bytes -- what the latency-bound small launches (batch 1) live on.
+    const bool wpair = BK == 32 && a.w_pairs;                   // wave-uniform
+    const int wrow = wpair ? 128 : ROWB;                        // bytes of a packed weight row
+    const int wblk = NPL * BN * wrow;                           // bytes of one packed block (pairs: two K tiles)
+    unsigned w_off[NPL * LB];
+#pragma unroll
+    for (int j = 0; j < NPL * LB; ++j) w_off[j] = (unsigned)((j * RPR + wave * RPW + lrow) * wrow + lslot * 16);
+    const char* __restrict__ wt_tile = wt + (long long)n_tile * (wpair ? a.K / 64 : a.K / BK) * wblk;
     auto issue_b = [&](int buf, int it) {
         char* sB = smem + buf * STAGE + NPL * BM * ROWB;
-        const char* gB = wt_tile + (long long)it * WBLK + w_lane;
+        const char* gB = wpair ? wt_tile + (long long)(it >> 1) * wblk + (it & 1) * 64 : wt_tile + (long long)it * wblk;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < NPL * LB; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + j * RPR * ROWB), (lds_void*)(sB + (j * RPR + wave * RPW) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + w_off[j]), (lds_void*)(sB + (j * RPR + wave * RPW) * ROWB), 16, 0, 0);
     };
     if (!(SMAP_ABLATE & 1)) issue_b(0, 0);
 

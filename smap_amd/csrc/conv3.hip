@@ -101,14 +101,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
 
     // weight tiles: one contiguous, pre-swizzled block per (n tile, chunk, tap) (smap_amd/engine.py::pack_conv_weights)
     const int w_chunks = a.Cin / CH;
-    const char* __restrict__ wt_tile = wt + (long long)n_tile * w_chunks * 9 * B_BYTES + (wave * 8) * ROWB + lane * 16;
+    const char* __restrict__ wt_tile = wt + (long long)n_tile * w_chunks * 9 * B_BYTES;           // wave-uniform
+    unsigned w_off[LB];                                         // per-lane 32-bit offsets inside a block
+#pragma unroll
+    for (int i = 0; i < LB; ++i) w_off[i] = (unsigned)((i * 32 + wave * 8) * ROWB + lane * 16);
     auto issue_b = [&](int buf, int blk) {                      // blk = cc * 9 + tap
         char* sB = smem + NA * A_BYTES + buf * B_BYTES;
         const char* gB = wt_tile + (long long)blk * B_BYTES;
         if (SMAP_ABLATE & 1) return;
 #pragma unroll
         for (int i = 0; i < LB; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + i * 32 * ROWB), (lds_void*)(sB + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + w_off[i]), (lds_void*)(sB + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
     };
     issue_b(0, 0);                                              // weights of (cc 0, tap 0): no pixel math needed
 

@@ -191,24 +191,29 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
             constexpr int NB = NLA > 0 ? P_NLW - NLA : 1;
             constexpr int RPRB = NB * P_RPW, LB2 = BN / RPRB, LPTB = NPL * LB2;
             static_assert(BN % RPRB == 0 && (STAGES - 2) * LPTB <= 63, "weight loader split");
-            constexpr int WBLK = NPL * BN * P_ROWB;
+            const bool wpair = P_BK == 32 && a.w_pairs;
+            const int WROW = wpair ? 128 : P_ROWB;
+            const int WBLK = NPL * BN * WROW;
             const int wi = lw - NLA;
-            const unsigned w_lane = (unsigned)((wi * P_RPW) * P_ROWB + lane * 16);
+            const int lrow = lane / P_SPR, lslot = lane % P_SPR;
+            unsigned w_off[NPL * LB2];
+#pragma unroll
+            for (int j = 0; j < NPL * LB2; ++j) w_off[j] = (unsigned)((j * RPRB + wi * P_RPW + lrow) * WROW + lslot * 16);
             int s_tile = 0, s_it = 0;
             const char* __restrict__ wt_tile = wt;
             auto setup_tile = [&]() {
                 const int logical = t_begin + s_tile;
                 const int n_tile = logical % a.n_tiles;
-                wt_tile = wt + (long long)n_tile * kt_per_tile * WBLK + w_lane;
+                wt_tile = wt + (long long)n_tile * (wpair ? kt_per_tile / 2 : kt_per_tile) * WBLK;
                 s_it = 0;
             };
             auto issue = [&](int buf) {
                 if (!(SMAP_CONVP_ABLATE & (1 | 32))) {
                     char* sB = smem + buf * STAGE + NPL * BM * P_ROWB;
-                    const char* gB = wt_tile + (long long)s_it * WBLK;
+                    const char* gB = wpair ? wt_tile + (long long)(s_it >> 1) * WBLK + (s_it & 1) * 64 : wt_tile + (long long)s_it * WBLK;
 #pragma unroll
                     for (int j = 0; j < NPL * LB2; ++j)
-                        __builtin_amdgcn_global_load_lds((gbl_void*)(gB + j * RPRB * P_ROWB), (lds_void*)(sB + (j * RPRB + wi * P_RPW) * P_ROWB), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((gbl_void*)(gB + w_off[j]), (lds_void*)(sB + (j * RPRB + wi * P_RPW) * P_ROWB), 16, 0, 0);
                 }
                 if (++s_it == kt_per_tile && ++s_tile < t_count) setup_tile();
             };
@@ -236,9 +241,13 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
         unsigned a_off[LA], a_mask[LA], a_cur[LA];
         int s_kh = 0, s_kw = 0, s_cc = 0, s_tile = 0;             // issue cursor (wave-uniform)
         int s_it = 0;                                             // K tile inside the tile
-        constexpr int WBLK = NPL * BN * P_ROWB;                   // one packed weight tile (engine.py::pack_conv_weights)
-        const unsigned w_lane = (unsigned)((lw * P_RPW) * P_ROWB + lane * 16);
-        const char* __restrict__ wt_tile = wt;
+        const bool wpair = P_BK == 32 && a.w_pairs;               // packed weight rows: BK = 32 tiles in pairs [tile 2p | tile 2p+1]
+        const int WROW = wpair ? 128 : P_ROWB;
+        const int WBLK = NPL * BN * WROW;                         // one packed block (engine.py::pack_conv_weights)
+        unsigned w_off[NPL * LB];                                 // per-lane 32-bit offsets inside a packed weight tile
+#pragma unroll
+        for (int j = 0; j < NPL * LB; ++j) w_off[j] = (unsigned)((j * P_RPR + lw * P_RPW + lrow) * WROW + lslot * 16);
+        const char* __restrict__ wt_tile = wt;                    // wave-uniform
         auto set_tap = [&]() {
             const unsigned tap_off = (unsigned)((s_kh * a.W + s_kw) * a.in_stride_c * 2);
             const unsigned bit = 1u << (s_kh * a.ksize + s_kw);
@@ -249,7 +258,7 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
             const int logical = t_begin + s_tile;
             const int m_tile = logical / a.n_tiles, n_tile = logical - m_tile * a.n_tiles;
             const int m0 = m_tile * BM;
-            wt_tile = wt + (long long)n_tile * kt_per_tile * WBLK + w_lane;
+            wt_tile = wt + (long long)n_tile * (wpair ? kt_per_tile / 2 : kt_per_tile) * WBLK;
             int m = m0 + srow;
             int b = m / HoWo, rem = m - b * HoWo;
             int oy = rem / a.Wo, ox = rem - oy * a.Wo;
@@ -291,10 +300,10 @@ __global__ __launch_bounds__((WM * WN + P_NLW) * 64) void convp_kernel(const Con
             }
             if (!(SMAP_CONVP_ABLATE & (1 | 32))) {                // the weight tile: one contiguous block, already in LDS order
                 char* sB = sbase + NPL * BM * P_ROWB;
-                const char* gB = wt_tile + (long long)s_it * WBLK;
+                const char* gB = wpair ? wt_tile + (long long)(s_it >> 1) * WBLK + (s_it & 1) * 64 : wt_tile + (long long)s_it * WBLK;
 #pragma unroll
                 for (int j = 0; j < NPL * LB; ++j)
-                    __builtin_amdgcn_global_load_lds((gbl_void*)(gB + j * P_RPR * P_ROWB), (lds_void*)(sB + (j * P_RPR + lw * P_RPW) * P_ROWB), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(gB + w_off[j]), (lds_void*)(sB + (j * P_RPR + lw * P_RPW) * P_ROWB), 16, 0, 0);
             }
             ++s_it;
             if (++s_cc == cchunks) {

@@ -25,6 +25,7 @@ struct ConvArgs {
     int out_lo;              // same for the output tensor (fp16 outputs only)
     long long w_lo;          // bytes from the hi weight matrix to the lo weight matrix
     float acc_scale;         // accumulator multiplier undoing the power-of-two weight pre-scale
+    int w_pairs;             // 32-half K tiles of the packed weights come in pairs (128-byte rows [tile 2p | tile 2p+1])
 #ifdef SMAP_TRACE
     long long* dbg;          // diagnostics build only (tools/build_ablate.py --trace): per-workgroup phase stamps
 #endif

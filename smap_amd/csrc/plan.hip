@@ -497,6 +497,7 @@ static int validate(const smap_op& o)
                 if (o.in_c_off + o.Cin > o.in_stride_c / 2) return SMAP_E_ARG;
             }
             if (o.ksize != 1 && o.ksize != 3) return SMAP_E_ARG;
+            if (o.w_pairs != 0 && o.w_pairs != 1) return SMAP_E_ARG;
             if (o.tile >= 30 && o.tile < 40 && (o.ksize != 3 || o.stride != 1 || o.pad != 1 || o.res_off >= 0 || o.add1_off >= 0 ||
                                  o.add2_off >= 0 || o.aux_off[0] >= 0))
                 return SMAP_E_ARG;                       // halo-tiled kernel: plain 3x3 stride-1 convs only
@@ -629,6 +630,7 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                 a.out_lo = o.out_stride_c / 2;
                 a.w_lo = (long long)o.cout_pad * a.K * 2;
                 a.acc_scale = o.acc_scale;
+                a.w_pairs = o.w_pairs;
                 int bm, bn;
                 smap_conv_tile_dims(o.tile, &bm, &bn);
                 a.m_tiles = (a.M + bm - 1) / bm;

@@ -145,7 +145,17 @@ def tile_bk(tile, x3):
     return 32 if tile in (20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 53, 54, 55) else 64
 
 
-def pack_conv_weights(w2, tile, x3, ksize, cin):
+# 32-half K tiles of the packed weights are stored in PAIRS (128-byte rows [tile 2p | tile 2p+1]) for SMALL schedules (<= 2 frames of
+# 512x832 worth of pixels): every launch of those is latency-bound and lives on the L1 hit the second half of each fetched line
+# gives the next K tile (batch 1: 226 vs 195 frames/s); larger schedules are bandwidth-bound and prefer one contiguous block
+# per K tile (batch 8: 751 vs 738).  A per-launch rule (pairs for <= 512 workgroups) sits in between on both (226 / 745):
+# profiles/r3_ab_wpairs*.log.  SMAP_WPAIRS=0|1 forces one layout.
+def use_w_pairs(frames, H, W):
+    forced = os.environ.get("SMAP_WPAIRS", "")
+    return int(forced) if forced in ("0", "1") else int(frames * H * W <= 2 * 512 * 832)
+
+
+def pack_conv_weights(w2, tile, x3, ksize, cin, pairs=True):
     """fp16 [planes][cout_pad][K] (K = (kh, kw, cin), planes = hi | lo in split precision) -> the byte image the conv kernels'
     LDS-DMA reads, as ONE CONTIGUOUS BLOCK PER STAGED WEIGHT TILE: [n tile][K tile][plane][row][16-byte slot], the slot
     order already carrying the kernels' XOR swizzle -- a weight tile is then BN x row-bytes of consecutive addresses, i.e.
@@ -153,7 +163,8 @@ def pack_conv_weights(w2, tile, x3, ksize, cin):
     stream from L2 at half the rate: profiles/r3_v3_ubench_lds_dma_rows.log; weight tiles are re-streamed by every M tile
     and were the larger half of the L2 -> LDS traffic.)
       igemm / persist (csrc/conv.hip, convp.hip): K tile = BK halves in (kh, kw, cin) order; slot s of row r holds granule
-        s ^ ((r >> 1) & 7) (BK = 64) or s ^ ((r >> 2) & 3) (BK = 32);
+        s ^ ((r >> 1) & 7) (BK = 64) or s ^ ((r >> 2) & 3) (BK = 32); 32-half tiles come in pairs [n tile][pair][plane][row]
+        [tile 2p | tile 2p+1]: 128-byte rows again, the second half of every fetched cache line is the next K tile;
       halo (csrc/conv3.hip): tiles ordered [channel chunk][tap]; 128-byte rows of 64 channels, or in split precision of
         32 channels as logical granules 0..3 = hi, 4..7 = lo; slot s of row r holds logical granule s ^ ((r >> 1) & 7)."""
     planes, cout_pad, K = w2.shape
@@ -180,14 +191,20 @@ def pack_conv_weights(w2, tile, x3, ksize, cin):
     rows = w2.reshape(planes, nt, bn, kt, spr, 8).permute(1, 3, 0, 2, 4, 5)          # [nt][kt][plane][row][granule][8]
     swz = ((r >> 1) & 7) if bk == 64 else ((r >> 2) & 3)
     idx = torch.arange(spr)[None, :] ^ swz[:, None]
-    return rows[:, :, :, r[:, None], idx, :].contiguous()
+    tiles = rows[:, :, :, r[:, None], idx, :]                                        # slot order of the LDS image
+    if bk == 32 and pairs:
+        # 32-half K tiles are stored in PAIRS: a 128-byte row = [K tile 2p (64 B) | K tile 2p+1 (64 B)], so that the cache line
+        # a K tile's load brings in also serves the next K tile (small launches are latency-bound: the L1 hit matters there)
+        assert kt % 2 == 0
+        tiles = tiles.reshape(nt, kt // 2, 2, planes, bn, spr, 8).permute(0, 1, 3, 4, 2, 5, 6)   # [nt][pair][plane][row][half][4][8]
+    return tiles.contiguous()
 
 
-def unpack_conv_weights(packed, tile, x3, ksize, cin, cout_pad):
+def unpack_conv_weights(packed, tile, x3, ksize, cin, cout_pad, pairs=True):
     """Inverse of pack_conv_weights: the flat fp16 image -> [planes][cout_pad][K] (oracle/graph_interp.py, tests)."""
     planes, K = (2 if x3 else 1), ksize * ksize * cin
     perm = pack_conv_weights(torch.arange(planes * cout_pad * K, dtype=torch.int64).reshape(planes, cout_pad, K),
-                             tile, x3, ksize, cin).reshape(-1)
+                             tile, x3, ksize, cin, pairs=pairs).reshape(-1)
     out = torch.empty(planes * cout_pad * K, dtype=packed.dtype)
     out[perm] = packed.reshape(-1)
     return out.reshape(planes, cout_pad, K)
@@ -319,6 +336,7 @@ class Graph:
             B = 2 * B                         # frames of every activation tensor
         assert H % 32 == 0 and W % 32 == 0, "input must be a multiple of 32 (5 stride-2 levels)"
         self.sd, self.B, self.H, self.W = sd, B, H, W
+        self.w_pairs = use_w_pairs(B, H, W)                  # layout of the packed 32-half weight tiles (whole schedule)
         self.ops, self.tensors = [], []
         self.wchunks, self.woff = [], 0
         self.stage_num, self.chl, self.kpt_paf, self.paf = stage_num, chl, kpt_paf, paf
@@ -387,7 +405,8 @@ class Graph:
             wk[0, :cout] = w.permute(0, 2, 3, 1).reshape(cout, K).to(torch.float16)
             if not torch.isfinite(wk).all():
                 raise ValueError(f"{name}: folded weights exceed the fp16 range (max |w| = {float(w.abs().max()):.3g})")
-        wk = pack_conv_weights(wk, tile, self.x3, ksize, cin)          # one contiguous block per staged weight tile
+        w_pairs = self.w_pairs
+        wk = pack_conv_weights(wk, tile, self.x3, ksize, cin, pairs=w_pairs)   # one contiguous block per staged weight tile (pair)
         bk = torch.zeros((cout_pad,), dtype=torch.float32)
         bk[:cout] = b.to(torch.float32)
         out = self.tensor(name, Ho, Wo, _rup(cout, 8), 4 if out_fp32 else 2)
@@ -395,7 +414,7 @@ class Graph:
         self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, aux=[up] if up is not None else [], p=dict(
             Cin=cin, in_c_off=in_c_off, Cout=cout, ksize=ksize, stride=stride, pad=pad, relu=int(relu),
             cout_pad=cout_pad, tile=tile, out_fp32=int(out_fp32), w_off=self._add_w(wk), bias_off=self._add_w(bk),
-            acc_scale=acc_scale, frames=nfr,
+            acc_scale=acc_scale, frames=nfr, w_pairs=w_pairs,
             w_ref=w if self.keep_ref else None, b_ref=b if self.keep_ref else None)))
         return out
 
@@ -582,6 +601,7 @@ class Graph:
                 o.ksize, o.stride, o.pad, o.relu = p["ksize"], p["stride"], p["pad"], p["relu"]
                 o.cout_pad, o.out_stride_c, o.out_c_off = p["cout_pad"], y.C * y.planes, 0
                 o.acc_scale = p["acc_scale"]
+                o.w_pairs = p["w_pairs"]
                 o.out_fp32, o.tile = p["out_fp32"], p["tile"]
                 o.in_off, o.out_off, o.w_off, o.bias_off = x.off, y.off, p["w_off"], p["bias_off"]
                 for nm in ("res", "add1", "add2"):

@@ -37,7 +37,7 @@ class SmapOp(C.Structure):
         ("aux_off", C.c_int64 * 3), ("aux_h", C.c_int32 * 3), ("aux_w", C.c_int32 * 3),
         ("ext_off", C.c_int64),
         ("precision", C.c_int32), ("acc_scale", C.c_float),
-        ("flip_from", C.c_int32), ("status_off", C.c_int32),
+        ("flip_from", C.c_int32), ("w_pairs", C.c_int32), ("status_off", C.c_int32), ("pad_", C.c_int32),
     ]
 
 

@@ -55,8 +55,9 @@ def _run_single_conv(B, H, W, Cin, Cout, k, stride, tile, relu, use_res, use_add
         wk = torch.zeros(1, cout_pad, K, dtype=torch.float16)
         wk[0, :Cout] = w.permute(0, 2, 3, 1).reshape(Cout, K)
     from smap_amd.engine import pack_conv_weights, tile_family
+    w_pairs = seed % 2                                     # both layouts of the 32-half K tiles get exercised
     if tile in TILES and not (tile_family(tile) == "halo" and k != 3):     # (ops the plan must reject keep any bytes)
-        wk = pack_conv_weights(wk, tile, x3, k, Cin)       # weight tiles as contiguous, pre-swizzled blocks (the conv ABI)
+        wk = pack_conv_weights(wk, tile, x3, k, Cin, pairs=w_pairs)   # weight tiles as contiguous, pre-swizzled blocks (the conv ABI)
     bk = torch.zeros(cout_pad)
     bk[:Cout] = bias
     # weight blob: [wk | bias]; arena: [x | res | a1 | a2 | out]
@@ -86,6 +87,7 @@ def _run_single_conv(B, H, W, Cin, Cout, k, stride, tile, relu, use_res, use_add
     op.in_off, op.out_off, op.w_off, op.bias_off = offs[0], out_off, 0, w_bytes
     op.res_off, op.add1_off, op.add2_off = offs[1], offs[2], offs[3]
     op.precision, op.acc_scale = int(x3), acc_scale
+    op.w_pairs = w_pairs
     for i in range(3):
         op.aux_off[i] = -1
     op.ext_off = -1

@@ -161,6 +161,43 @@ def test_weight_packing_is_a_permutation_and_inverts():
         assert torch.equal(unpack_conv_weights(p.reshape(-1), tile, x3, k, cin, cout_pad), w)
 
 
+def test_weight_packing_matches_the_kernels_address_arithmetic():
+    """pack_conv_weights against the byte addresses the kernels compute (csrc/conv.hip issue_b, conv3.hip, convp.hip): element
+    (plane, n, k) must sit where lane (row, slot) of the LDS-DMA that stages its K tile reads it."""
+    import random
+    from smap_amd.engine import TILES, pack_conv_weights, tile_bk, tile_family
+    random.seed(0)
+    for tile, x3, ks, cin, cout_pad in ((0, False, 3, 128, 256), (0, True, 1, 256, 256), (20, True, 3, 64, 128), (22, True, 1, 256, 256),
+                                        (52, True, 1, 128, 256), (31, True, 3, 128, 256), (31, False, 3, 128, 256), (36, True, 3, 64, 64),
+                                        (38, False, 3, 256, 32), (60, True, 1, 64, 512), (62, False, 3, 64, 256), (69, True, 1, 128, 128)):
+        planes, K, bn = (2 if x3 else 1), ks * ks * cin, TILES[tile][1]
+        w2 = torch.arange(planes * cout_pad * K, dtype=torch.float32).reshape(planes, cout_pad, K)
+        for pairs in (True, False):
+          P = pack_conv_weights(w2, tile, x3, ks, cin, pairs=pairs).reshape(-1)
+          for _ in range(300):
+              n = random.randrange(cout_pad)
+              nt, r = n // bn, n % bn
+              if tile_family(tile) == "halo":
+                  ch = 32 if x3 else 64
+                  cch = cin // ch
+                  cc, tap, s, e = random.randrange(cch), random.randrange(9), random.randrange(8), random.randrange(8)
+                  gl = s ^ ((r >> 1) & 7)
+                  pl, g = ((gl >> 2), (gl & 3)) if x3 else (0, gl)
+                  k = tap * cin + cc * ch + g * 8 + e
+                  off = ((((nt * cch + cc) * 9 + tap) * bn + r) * 8 + s) * 8 + e
+              else:
+                  bk = tile_bk(tile, x3)
+                  spr, KT = bk // 8, K // bk
+                  it, pl, s, e = random.randrange(KT), random.randrange(planes), random.randrange(spr), random.randrange(8)
+                  g = s ^ (((r >> 1) & 7) if bk == 64 else ((r >> 2) & 3))
+                  k = it * bk + g * 8 + e
+                  if bk == 64 or not pairs:        # byte = (nt*KT + it)*WBLK + (pl*BN + r)*ROWB + s*16
+                      off = ((((nt * KT + it) * planes + pl) * bn + r) * spr + s) * 8 + e
+                  else:               # pairs: byte = (nt*KT/2 + it/2)*WBLK + (it&1)*64 + (pl*BN + r)*128 + s*16
+                      off = (((((nt * (KT // 2) + it // 2) * planes + pl) * bn + r) * 2 + (it & 1)) * 4 + s) * 8 + e
+              assert P[off] == w2[pl, n, k], (tile, x3, off)
+
+
 def test_lazy_records_equal_eager_records():
     from smap_amd.records import frame_record, to_jsonable, train_records
     rng = np.random.default_rng(0)

@@ -67,6 +67,7 @@ def build(B, H, W, Cin, Cout, k, s, tile, res, dev, x3=False, up=0):
     op.Ho, op.Wo, op.Cout, op.ksize, op.stride, op.pad, op.relu = Ho, Wo, Cout, k, s, pad, 1
     op.cout_pad, op.out_stride_c, op.out_c_off, op.out_fp32, op.tile = cout_pad, c8 * pl, 0, 0, tile
     op.precision, op.acc_scale = int(x3), 1.0
+    op.w_pairs = int(os.environ.get("SMAP_WPAIRS", "0"))          # random weights: only the address pattern differs
     op.in_off, op.out_off, op.w_off, op.bias_off = 16384, 16384 + x_b + o_b, 0, w_b
     op.res_off = 16384 + x_b if res else -1
     op.add1_off = op.add2_off = op.ext_off = -1
