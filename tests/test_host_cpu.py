@@ -127,7 +127,7 @@ def test_tile_tables_name_existing_tiles():
         B, H, W, cin, cout, k, s = map(int, key.split(",")[:7])              # optional 8th field: "up" (ops with a fused bilinear add)
         assert key.split(",")[7:] in ([], ["up"])
         for t in _table_entry(v):
-            assert B in (8, 16) and (t < 30 or t >= 40 or (k == 3 and s == 1))   # (16 = the flip-TTA schedule of batch 8); halo tiles: plain 3x3 stride 1 only
+            assert B in (1, 8, 16) and (t < 30 or t >= 40 or (k == 3 and s == 1))   # (1 = configs[1], 16 = the flip-TTA schedule of batch 8); halo tiles: plain 3x3 stride 1 only
             assert cout > 32 or t in (3, 38, 39)
         assert not 60 <= _table_entry(v)[-1] < 80                            # a ranked list ends on a tile that takes every op
 
