@@ -112,6 +112,15 @@ def pick_tile_x3(M, cout, key=None):
         path = os.environ.get("SMAP_TILE_TABLE_X3") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table_x3.json")
         _TILE_TABLE_X3 = json.load(open(path)) if os.path.exists(path) and not os.environ.get("SMAP_NO_TILE_TABLE") else {}
     keys = [key] if isinstance(key, str) else list(key or [])          # several keys: most specific first
+    # a batch size the table was not tuned for borrows the entries of the nearest tuned one (same layer shape, M within 2x-4x):
+    # closer to the optimum than the block-count heuristic (tuned tables: +8 % at batch 8, +7 % at 16, +19 % at 1)
+    tuned = sorted({int(k.split(",")[0]) for k in _TILE_TABLE_X3})
+    if keys and tuned:
+        f = int(keys[0].split(",")[0])
+        if f not in tuned:
+            import math
+            near = min(tuned, key=lambda b: abs(math.log(b / f)))
+            keys = keys + [",".join([str(near)] + k.split(",")[1:]) for k in keys]
     cands = [t for k in keys if k in _TILE_TABLE_X3 for t in _table_entry(_TILE_TABLE_X3[k])]
     if cout <= 32:
         return cands + [3]
