@@ -217,7 +217,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             const int idx = p * NT + tid;
             const int row = idx / CG, cg = idx - row * CG;
             const int m = m0 + row, n = n0 + cg * 8;
-            const long long dense = (m < a.M && n < a.Cout8) ? (long long)m * (NPL * a.Cout8) + n : 0;
+            const unsigned dense = (m < a.M && n < a.Cout8) ? (unsigned)m * (unsigned)(NPL * a.Cout8) + (unsigned)n : 0u;   // < 2^31 elements per tensor
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl)
                 rres[p][pl] = *reinterpret_cast<const half8*>(a.res + dense + pl * a.Cout8);
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     // ---- epilogue 2: 8 consecutive channels of one pixel per thread.  Software-pipelined over the
     //      passes: the global loads of pass p+1 (bilinear taps, post-ReLU addends) are issued before the
     //      arithmetic + store of pass p, so one memory round trip is exposed per tile, not per pass.
-    struct Extra { half8 t00[NPL], t01[NPL], t10[NPL], t11[NPL], a1[NPL], a2[NPL]; float ly0, ly1, lx0, lx1; bool ok; long long o; int row, cg; };
+    struct Extra { half8 t00[NPL], t01[NPL], t10[NPL], t11[NPL], a1[NPL], a2[NPL]; float ly0, ly1, lx0, lx1; bool ok; unsigned o; int row, cg; };
     constexpr int TS = NPL;                                        // pixel stride multiplier of the dense split tensors
     auto val = [](const half8 (&h)[NPL], int e) -> float {       // hi (+ lo) -> fp32, exact
         return X3 ? (float)h[0][e] + (float)h[NPL - 1][e] : (float)h[0][e];
@@ -329,21 +329,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         const int m = m0 + x.row, n = n0 + x.cg * 8;
         x.ok = m < a.M && n < a.Cout8 && !((SMAP_ABLATE & 4) && a.M != 7);
         const int ms = x.ok ? m : 0, ns = x.ok ? n : 0;            // clamped: loads stay in bounds
-        const long long dense = (long long)ms * (TS * a.Cout8) + ns;     // res/add tensors are dense [M][Cout8] (x planes)
-        x.o = (long long)ms * a.out_stride_c + a.out_c_off + ns;
+        // 32-bit element offsets from the (uniform, 64-bit) tensor bases: a tensor has < 2^31 elements (plan.hip::validate)
+        const unsigned dense = (unsigned)ms * (unsigned)(TS * a.Cout8) + (unsigned)ns;     // res/add tensors are dense [M][Cout8] (x planes)
+        x.o = (unsigned)ms * (unsigned)a.out_stride_c + (unsigned)(a.out_c_off + ns);
         if (FULL && a.up) {
             const int b = (SMAP_ABLATE & 64) ? 0 : ms / HoWo, rem = ms - b * HoWo;
             const int oy = (SMAP_ABLATE & 64) ? (ms & 63) : rem / a.Wo, ox = (SMAP_ABLATE & 64) ? (ms & 127) : rem - oy * a.Wo;
             Lerp ly = lerp_index(oy, a.up_h, a.Ho), lx = lerp_index(ox, a.up_w, a.Wo);
             if (SMAP_ABLATE & 64) { ly.i0 = oy >> 1; ly.i1 = ly.i0; ly.l0 = 0.5f; ly.l1 = 0.5f; lx.i0 = ox >> 1; lx.i1 = lx.i0; lx.l0 = 0.5f; lx.l1 = 0.5f; }
             const int us = TS * a.Cout8;
-            const _Float16* tb = a.up + (long long)b * a.up_h * a.up_w * us + ns;
+            const unsigned tb0 = (unsigned)b * (unsigned)(a.up_h * a.up_w) * (unsigned)us + (unsigned)ns;
+            const _Float16* __restrict__ tb = a.up;
 #pragma unroll
             for (int pl = 0; pl < ((SMAP_ABLATE & 32) ? 0 : NPL); ++pl) {
-                x.t00[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i0) * us + pl * a.Cout8);
-                x.t01[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i0 * a.up_w + lx.i1) * us + pl * a.Cout8);
-                x.t10[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i0) * us + pl * a.Cout8);
-                x.t11[pl] = *reinterpret_cast<const half8*>(tb + ((long long)ly.i1 * a.up_w + lx.i1) * us + pl * a.Cout8);
+                x.t00[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i0 * a.up_w + lx.i0) * (unsigned)us + (unsigned)(pl * a.Cout8)));
+                x.t01[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i0 * a.up_w + lx.i1) * (unsigned)us + (unsigned)(pl * a.Cout8)));
+                x.t10[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i1 * a.up_w + lx.i0) * (unsigned)us + (unsigned)(pl * a.Cout8)));
+                x.t11[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i1 * a.up_w + lx.i1) * (unsigned)us + (unsigned)(pl * a.Cout8)));
             }
             x.ly0 = ly.l0; x.ly1 = ly.l1; x.lx0 = lx.l0; x.lx1 = lx.l1;
         }

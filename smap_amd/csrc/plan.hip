@@ -511,6 +511,9 @@ static int validate(const smap_op& o)
             // conv A-operand addresses are 32-bit byte offsets from the arena base
             if (o.in_off + (int64_t)o.B * o.H * o.W * o.in_stride_c * 2 > ((int64_t)1 << 32)) return SMAP_E_ARG;
             if ((int64_t)o.cout_pad * o.ksize * o.ksize * o.Cin * 2 * (1 + o.precision) > ((int64_t)1 << 32)) return SMAP_E_ARG;
+            // epilogues address outputs / residuals / addends / the low-res tensor with 32-bit ELEMENT offsets from their bases
+            if ((int64_t)o.B * o.Ho * o.Wo * o.out_stride_c >= ((int64_t)1 << 31)) return SMAP_E_ARG;
+            if ((int64_t)o.B * o.Ho * o.Wo * ((o.Cout + 7) & ~7) * (1 + o.precision) >= ((int64_t)1 << 31)) return SMAP_E_ARG;
             if (o.Ho != (o.H + 2 * o.pad - o.ksize) / o.stride + 1) return SMAP_E_ARG;
             if (o.Wo != (o.W + 2 * o.pad - o.ksize) / o.stride + 1) return SMAP_E_ARG;
             return 0;
