@@ -89,7 +89,9 @@ class PosePipeline:
         self.refine = refine_weights
         self.depth = max(1, int(depth))
         self.engines = [self.engine] + [self.engine.sibling() for _ in range(self.depth - 1)]
-        self.s_bbs = [torch.cuda.Stream(self.device) for _ in range(self.depth)]
+        prio = [int(x) for x in os.environ.get("SMAP_BB_STREAM_PRIORITIES", "").split(",") if x.strip()]     # experiment hook
+        self.s_bbs = [torch.cuda.Stream(self.device, priority=prio[i % len(prio)]) if prio else torch.cuda.Stream(self.device)
+                      for i in range(self.depth)]
         self.s_bb = self.s_bbs[0]
         self.s_post = torch.cuda.Stream(self.device)
         self.s_comm = torch.cuda.Stream(self.device)      # result gather (RCCL) never queues behind compute

@@ -7,6 +7,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2
 timeout 300 python bench.py 2>&1 | tail -1 > $O/r3_final_bench_x3.json; cut -c1-300 $O/r3_final_bench_x3.json
 timeout 300 python bench.py --precision f16 --no-cpu-baseline 2>&1 | tail -1 > $O/r3_final_bench_f16.json; cut -c1-200 $O/r3_final_bench_f16.json
 {
