@@ -84,8 +84,10 @@ torch.manual_seed(0)
 sd = people_state_dict(SMAP(make_cfg((128, 208))).state_dict(), "smooth")
 x = torch.randn(8, 3, 512, 832, generator=torch.Generator().manual_seed(seed))[:frames]
 cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (frames, 1))
-cfg = make_cfg((128, 208))
-fp = (list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [cfg.DATASET.KEYPOINT.NUM + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]) if flip else None
+fp = None
+if flip:                                                       # the reference's mirror tables (dataset/data_settings.py:22,33-34)
+    from exps.stage3_root2.config import cfg
+    fp = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [cfg.DATASET.KEYPOINT.NUM + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
 parity.reference_path(sd, x[:1], cams[:1], flip_pair=fp)       # warm-up (oneDNN primitive cache, page faults)
 t0 = time.time()
 ref = parity.reference_path(sd, x, cams, flip_pair=fp)         # --flip: the reference's two forwards + channel loop (test.py:55-70)

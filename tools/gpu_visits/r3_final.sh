@@ -47,6 +47,7 @@ conv = [i for i in seg if any(k in by[i]['name'] for k in ('conv_igemm', 'conv3x
 mf = sum(by[i].get('SQ_VALU_MFMA_BUSY_CYCLES', 0) for i in conv)
 ga = sum(by[i].get('GRBM_GUI_ACTIVE', 0) for i in conv)
 print('x3 depth 1: launches', len(seg), 'conv', len(conv), 'MFMA busy cycles (sum over SIMDs) %.4g' % mf, 'GRBM_GUI_ACTIVE over conv kernels %.4g' % ga)
-print('   MFMA pipe utilisation over the conv kernels = busy / (GUI_ACTIVE x 1024 SIMDs) = %.3f' % (mf / (ga * 1024)))
+print('   (this rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs: %.4g / 8 = %.4g cycles = %.2f ms at 2.4 GHz, the serial conv time of one forward)' % (ga, ga / 8, ga / 8 / 2.4e6))
+print('   MFMA pipe utilisation over the conv kernels = busy / (GUI_ACTIVE / 8 x 1024 SIMDs) = %.3f' % (mf / (ga / 8 * 1024)))
 PY
 rm -rf $O/prof_r3 $O/pmc_fetch_r3 $O/pmc_write_r3 $O/pmc_mfma_r3
