@@ -42,6 +42,7 @@ import torch.distributed as dist  # noqa: E402
 
 ALG_GFLOP_PER_FRAME = 300.628      # SURVEY.md 8d / BASELINE.md 3: inference-live conv FLOPs (2*MAC)
 PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0             # HBM3E (same guide); the measured ceilings are lower and reported beside it
 H, W = 512, 832
 
 
@@ -460,6 +461,8 @@ def main():
         else:
             achieved = ALG_GFLOP_PER_FRAME * B / bb / 1e3        # TFLOP/s over the whole backbone schedule
         x3 = args.precision == "x3"
+        step_s = dt / args.steps if args.depth > 1 else bb
+        alg_bytes = pipe.engine.alg_bytes_per_batch * (B // pipe.chunk)     # launches per step x bytes per launch schedule
         traffic, traffic_src = None, None                        # HBM bytes per batch from committed PMC passes
         tj = os.path.join(ROOT, "profiles", "hbm_traffic_x3.json" if x3 else "hbm_traffic.json")
         if os.path.exists(tj) and B == 8:
@@ -498,6 +501,12 @@ def main():
                                    "below, rate = algorithmic FLOPs of the timed region / its duration when depth > 1)",
                          "mfma_flops_executed_per_algorithmic_flop": 3 if x3 else 1,
                          "mfma_pipe_frac": (3 if x3 else 1) * achieved / PEAK_F16_TFLOPS,
+                         # the same schedule against the other roof (the launches are bound by the CU's memory
+                         # path, not by the MFMA pipe): unfused algorithmic bytes of the conv launches / time per batch
+                         "memory_path": {"algorithmic_bytes_per_batch": alg_bytes, "achieved_GBps": alg_bytes / step_s / 1e9,
+                                         "peak_GBps": PEAK_HBM_GBPS, "frac_of_hbm_peak": alg_bytes / step_s / 1e9 / PEAK_HBM_GBPS,
+                                         "measured_ceilings_GBps": {"hbm_read": 5300, "hbm_write": 6200, "hbm_mixed": 5200,
+                                                                    "source": "profiles/r2_v17_ubench_hbm_read_write_mix.log"}},
                          "backbone_ms_per_batch": bb * 1e3,
                          "backbone_stream_idle_ms_between_batches": float(np.mean(gap_ms)) if gap_ms else None,
                          "algorithmic_gflop_per_frame": ALG_GFLOP_PER_FRAME},

@@ -190,6 +190,10 @@ def compare(hip, ref, root_idx=2):
         "limb_match": m_j / n_j if n_j else 1.0, "joints_compared": int(errs.size),
         "mpjpe_cm": float(errs.mean()) if errs.size else 0.0, "max_joint_err_cm": float(errs.max()) if errs.size else 0.0,
         "p99_joint_err_cm": float(np.percentile(errs, 99)) if errs.size else 0.0,
+        # a joint beyond 0.01 cm with identical 2D pixel is a DISCRETE event of the lifter, not accumulated rounding: one of the
+        # ten np.round(linspace) sample positions of its limb (test_util.py:74-76) sat within ~1e-6 px of .5 (sub-pixel peak
+        # coordinates differ by that much) and landed on the neighbouring depth pixel.  Counted, like the near-tie peaks.
+        "joints_over_0.01cm": int((errs > 1e-2).sum()) if errs.size else 0,
         "root_z_max_err_cm": float(max(rz_errs)) if rz_errs else 0.0,
         "root_z_mean_cm": float(np.mean([r for b in ref for r in b["rz"]])) if any(len(b["rz"]) for b in ref) else 0.0,
         "map_rel_err_max": maps,

@@ -183,6 +183,15 @@ typedef struct smap_op {
                                        smap_plan_run clears it, the head sum ORs in 1 when a value it writes is not finite:
                                        split precision keeps fp16's RANGE, an activation beyond 65504 turns into inf / NaN
                                        downstream; the host checks the word when it collects the maps. */
+    int32_t tail_cout;              /* CONV, tile ids 80..89 only (else 0): the op is a Bottleneck TAIL in one launch
+                                       (smap.py:48-77) -- a 3x3 stride-1 conv Cin -> Cout (= the tile's N extent, bias + ReLU,
+                                       never stored) followed by a 1x1 conv Cout -> tail_cout whose bias / res_off / relu /
+                                       add1_off / add2_off / out_* fields are this op's: the output tensor has tail_cout
+                                       channels (multiple of 8).  0 = a plain conv. */
+    int32_t tail_cout_pad;          /* rows of the padded 1x1 weight matrix: multiple of smap_conv_tile_tail_bn(tile) */
+    float tail_acc_scale;           /* precision 1: 2^-s of the 1x1 weights */
+    int64_t tail_w_off;             /* weight-blob byte offsets of the 1x1: blocks [n chunk][k chunk][BN2 rows][128 B], rows */
+    int64_t tail_bias_off;          /* in the halo tiles' format (64 channels, or hi32 | lo32); fp32 bias [tail_cout_pad] */
 } smap_op;
 
 /* sizeof(smap_op) as compiled: lets a foreign-language binding verify its struct mirror. */
@@ -191,6 +200,9 @@ int smap_sizeof_op(void);
  * unknown id) and the halves per staged K tile for `precision` (0 for an unknown id). */
 int smap_conv_tile_dims(int tile, int* bm, int* bn);
 int smap_conv_tile_bk(int tile, int precision);
+/* Tile ids 80..89 (3x3 + fused 1x1 tail): output channels per chunk of the tail (its weight rows are padded to a multiple); 0 for
+ * every other id. */
+int smap_conv_tile_tail_bn(int tile);
 
 typedef struct smap_plan smap_plan;
 

@@ -50,6 +50,18 @@ def run_graph(g, imgs, quantize, keep=False):
             else:
                 w, b = p["w_ref"].to(dt), p["b_ref"].to(dt)
             y = F.conv2d(x, w.to(dev), b.to(dev), stride=p["stride"], padding=p["pad"])
+            if "tail" in p:                              # fused Bottleneck tail (csrc/convf.hip): relu(3x3) -> 1x1; the 3x3's
+                tl = p["tail"]                           # output is rounded like a stored activation (hi|lo split = exact here)
+                y = _q(F.relu(y), quantize)
+                if quantize:
+                    from smap_amd.engine import unpack_halo_rows, TAIL_BN
+                    wk = unpack_halo_rows(blob[tl["w_off"]:tl["w_off"] + tl["cout_pad"] * cout * 2].view(torch.float16), TAIL_BN[p["tile"]],
+                                          1, cout, tl["cout_pad"], False)[0]
+                    w1 = wk[:tl["cout"]].float().view(tl["cout"], cout, 1, 1)
+                    b1 = blob[tl["bias_off"]:tl["bias_off"] + tl["cout_pad"] * 4].view(torch.float32)[:tl["cout"]].clone()
+                else:
+                    w1, b1 = tl["w_ref"].to(dt), tl["b_ref"].to(dt)
+                y = F.conv2d(y, w1.to(dev), b1.to(dev))
             if op.res is not None:
                 y = y + T[op.res.name]
             if op.aux:                                   # fused relu(u_skip(x) + bilinear(up_conv@low))

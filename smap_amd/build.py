@@ -21,6 +21,7 @@ SOURCES = [
     ("conv.hip", []),
     ("conv3.hip", []),
     ("convp.hip", []),
+    ("convf.hip", []),
     ("plan.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),

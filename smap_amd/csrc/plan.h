@@ -26,6 +26,12 @@ struct ConvArgs {
     long long w_lo;          // bytes from the hi weight matrix to the lo weight matrix
     float acc_scale;         // accumulator multiplier undoing the power-of-two weight pre-scale
     int w_pairs;             // 32-half K tiles of the packed weights come in pairs (128-byte rows [tile 2p | tile 2p+1])
+    // fused 1x1 tail (convf.hip, tile ids 80..89): out / res / add1 / add2 / relu then belong to the TAIL's output
+    const _Float16* w2;      // packed [n2 chunk][k chunk][BN2 rows][128 B] weights of the 1x1, or null
+    const float* bias2;      // [tail cout_pad] fp32
+    int tail_cout8;          // channels the tail writes (multiple of 8)
+    int tail_chunks;         // tail cout_pad / BN2
+    float tail_acc_scale;
 #ifdef SMAP_TRACE
     long long* dbg;          // diagnostics build only (tools/build_ablate.py --trace): per-workgroup phase stamps
 #endif
@@ -60,6 +66,8 @@ int smap_conv3_tile_dims(int tile, int* bm, int* bn);                       // c
 hipError_t smap_launch_conv3(const ConvArgs& a, int tile, hipStream_t st);
 int smap_convp_tile_dims(int tile, int* bm, int* bn);                       // convp.hip (tile ids 60..69, persistent wave-specialised GEMM)
 hipError_t smap_launch_convp(const ConvArgs& a, int tile, hipStream_t st);
+int smap_convf_tile_dims(int tile, int* bm, int* bn, int* bn2);             // convf.hip (tile ids 80..89, 3x3 + fused 1x1 tail)
+hipError_t smap_launch_convf(const ConvArgs& a, int tile, hipStream_t st);
 
 #ifdef SMAP_TIMELINE
 // every workgroup of a conv kernel calls these two (first / last statement): 100 MHz device-wide clock

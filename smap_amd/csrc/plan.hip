@@ -501,6 +501,17 @@ static int validate(const smap_op& o)
             if (o.tile >= 30 && o.tile < 40 && (o.ksize != 3 || o.stride != 1 || o.pad != 1 || o.res_off >= 0 || o.add1_off >= 0 ||
                                  o.add2_off >= 0 || o.aux_off[0] >= 0))
                 return SMAP_E_ARG;                       // halo-tiled kernel: plain 3x3 stride-1 convs only
+            if ((o.tile >= 80 && o.tile < 90) != (o.tail_cout > 0)) return SMAP_E_ARG;
+            if (o.tile >= 80 && o.tile < 90) {           // 3x3 + fused 1x1 tail: the op's Cout is the tile's whole N extent
+                const int bn2 = smap_conv_tile_tail_bn(o.tile);
+                if (o.ksize != 3 || o.stride != 1 || o.pad != 1 || o.out_fp32 || o.aux_off[0] >= 0 || o.Cout != bn || o.cout_pad != bn)
+                    return SMAP_E_ARG;
+                if (o.tail_cout % 8 || o.tail_cout_pad % bn2 || o.tail_cout_pad < o.tail_cout || o.tail_w_off < 0 || o.tail_bias_off < 0)
+                    return SMAP_E_ARG;
+                if (o.precision == 1 && !(o.tail_acc_scale > 0.f)) return SMAP_E_ARG;
+                if (o.out_stride_c < o.tail_cout) return SMAP_E_ARG;
+                if ((int64_t)o.B * o.Ho * o.Wo * o.tail_cout * (1 + o.precision) >= ((int64_t)1 << 31)) return SMAP_E_ARG;
+            }
             if (o.tile >= 60 && o.tile < 80 && (o.out_fp32 || o.aux_off[0] >= 0 || o.Cout % 8 || o.cout_pad > 2048))
                 return SMAP_E_ARG;                       // persistent kernel: register epilogue, fp16 outputs, no fused bilinear add, bias table of 2048 channels in LDS
             if (o.in_stride_c % 8 || o.in_c_off % 8 || o.out_stride_c % 8 || o.out_c_off % 8) return SMAP_E_ARG;
@@ -634,6 +645,11 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                 a.w_lo = (long long)o.cout_pad * a.K * 2;
                 a.acc_scale = o.acc_scale;
                 a.w_pairs = o.w_pairs;
+                a.w2 = o.tail_cout > 0 ? reinterpret_cast<const _Float16*>(wb + o.tail_w_off) : nullptr;
+                a.bias2 = o.tail_cout > 0 ? reinterpret_cast<const float*>(wb + o.tail_bias_off) : nullptr;
+                a.tail_cout8 = o.tail_cout;
+                a.tail_chunks = o.tail_cout > 0 ? o.tail_cout_pad / smap_conv_tile_tail_bn(o.tile) : 0;
+                a.tail_acc_scale = o.tail_acc_scale;
                 int bm, bn;
                 smap_conv_tile_dims(o.tile, &bm, &bn);
                 a.m_tiles = (a.M + bm - 1) / bm;

@@ -47,7 +47,11 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          55: (128, 128), 56: (128, 128), 57: (128, 128),
          # 60..62: csrc/convp.hip, persistent workgroups with loader waves and a register epilogue (no fused bilinear add, no fp32 out)
          60: (128, 256), 61: (256, 128), 62: (128, 128), 63: (128, 64), 64: (128, 64), 65: (128, 64),
-         66: (128, 256), 68: (128, 128), 69: (128, 128), 70: (128, 128)}
+         66: (128, 256), 68: (128, 128), 69: (128, 128), 70: (128, 128),
+         # 80..82: csrc/convf.hip, a Bottleneck's 3x3 (BN = all of its planes) with the following 1x1 fused in (TAIL_BN)
+         80: (128, 64), 81: (128, 64), 82: (128, 128)}
+TAIL_DEFAULT = {}                          # Bottleneck planes -> fused tile id (empty: every block runs c2 and c3 as two launches)
+TAIL_BN = {80: 64, 81: 128, 82: 64}      # output channels per chunk of the fused 1x1 (csrc/convf.hip::smap_convf_tile_dims)
 # (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
 #  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)
 
@@ -96,6 +100,8 @@ def tile_legal(tile, *, cout, cout_pad=None, plain3=True, up=False, out_fp32=Fal
     """Can tile id `tile` run an op with these properties?  Mirrors csrc/plan.hip::validate."""
     if 30 <= tile < 40:
         return plain3
+    if 80 <= tile < 90:
+        return False                     # only Graph.conv_tail builds these
     if 60 <= tile < 80:
         cp = cout_pad if cout_pad is not None else _rup(cout, TILES[tile][1])
         return not up and not out_fp32 and cout % 8 == 0 and cp <= 2048
@@ -136,8 +142,9 @@ def pick_tile_x3(M, cout, key=None):
 
 
 def tile_family(tile):
-    """Which kernel a tile id selects: "halo" (csrc/conv3.hip), "persist" (csrc/convp.hip) or "igemm" (csrc/conv.hip)."""
-    return "halo" if 30 <= tile < 40 else "persist" if 60 <= tile < 80 else "igemm"
+    """Which kernel a tile id selects: "halo" (csrc/conv3.hip; csrc/convf.hip = the same 3x3 with a fused 1x1 tail),
+    "persist" (csrc/convp.hip) or "igemm" (csrc/conv.hip)."""
+    return "halo" if (30 <= tile < 40 or 80 <= tile < 90) else "persist" if 60 <= tile < 80 else "igemm"
 
 
 def tile_bk(tile, x3):
@@ -184,15 +191,7 @@ def pack_conv_weights(w2, tile, x3, ksize, cin, pairs=True):
     r = torch.arange(bn)
     if tile_family(tile) == "halo":
         assert ksize == 3
-        ch = 32 if x3 else 64
-        cch = cin // ch
-        w = w2.reshape(planes, nt, bn, 9, cch, ch // 8, 8)
-        if x3:       # logical granule = plane * 4 + g
-            rows = w.permute(1, 4, 3, 2, 0, 5, 6).reshape(nt, cch, 9, bn, 8, 8)
-        else:
-            rows = w[0].permute(0, 3, 2, 1, 4, 5)
-        idx = torch.arange(8)[None, :] ^ ((r[:, None] >> 1) & 7)
-        return rows[:, :, :, r[:, None], idx, :].contiguous()
+        return pack_halo_rows(w2, bn, 9, cin, x3)
     bk = tile_bk(tile, x3)
     spr = bk // 8
     kt = K // bk
@@ -207,6 +206,33 @@ def pack_conv_weights(w2, tile, x3, ksize, cin, pairs=True):
         assert kt % 2 == 0
         tiles = tiles.reshape(nt, kt // 2, 2, planes, bn, spr, 8).permute(0, 1, 3, 4, 2, 5, 6)   # [nt][pair][plane][row][half][4][8]
     return tiles.contiguous()
+
+
+def pack_halo_rows(w2, bn, taps, cin, x3):
+    """[planes][cout_pad][K = (tap, cin)] -> blocks [n tile][channel chunk][tap][bn rows][8 slots][8 halves] of 128-byte rows
+    (csrc/conv3.hip; taps = 1: the fused 1x1 of csrc/convf.hip, bn = its chunk of output channels)."""
+    planes, cout_pad, K = w2.shape
+    assert K == taps * cin and cout_pad % bn == 0
+    nt = cout_pad // bn
+    ch = 32 if x3 else 64
+    cch = cin // ch
+    assert cch * ch == cin
+    r = torch.arange(bn)
+    w = w2.reshape(planes, nt, bn, taps, cch, ch // 8, 8)
+    if x3:       # logical granule = plane * 4 + g
+        rows = w.permute(1, 4, 3, 2, 0, 5, 6).reshape(nt, cch, taps, bn, 8, 8)
+    else:
+        rows = w[0].permute(0, 3, 2, 1, 4, 5)
+    idx = torch.arange(8)[None, :] ^ ((r[:, None] >> 1) & 7)
+    return rows[:, :, :, r[:, None], idx, :].contiguous()
+
+
+def unpack_halo_rows(packed, bn, taps, cin, cout_pad, x3):
+    planes, K = (2 if x3 else 1), taps * cin
+    perm = pack_halo_rows(torch.arange(planes * cout_pad * K, dtype=torch.int64).reshape(planes, cout_pad, K), bn, taps, cin, x3).reshape(-1)
+    out = torch.empty(planes * cout_pad * K, dtype=packed.dtype)
+    out[perm] = packed.reshape(-1)
+    return out.reshape(planes, cout_pad, K)
 
 
 def unpack_conv_weights(packed, tile, x3, ksize, cin, cout_pad, pairs=True):
@@ -350,6 +376,7 @@ class Graph:
         self.wchunks, self.woff = [], 0
         self.stage_num, self.chl, self.kpt_paf, self.paf = stage_num, chl, kpt_paf, paf
         self.flops = 0
+        self.alg_bytes = 0                    # unfused per-launch traffic: input + output + weights + residual / skip adds / taps
         self._build()
 
     # -- helpers
@@ -420,11 +447,54 @@ class Graph:
         bk[:cout] = b.to(torch.float32)
         out = self.tensor(name, Ho, Wo, _rup(cout, 8), 4 if out_fp32 else 2)
         self.flops += 2 * M * cout * K
+        self.alg_bytes += (nfr * x.H * x.W * cin * 2 * x.planes + nfr * Ho * Wo * out.C * out.esize * out.planes
+                           + wk.numel() * 2 + sum(t.nbytes * nfr // self.B for t in (res, add1, add2, up) if t is not None))
         self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, aux=[up] if up is not None else [], p=dict(
             Cin=cin, in_c_off=in_c_off, Cout=cout, ksize=ksize, stride=stride, pad=pad, relu=int(relu),
             cout_pad=cout_pad, tile=tile, out_fp32=int(out_fp32), w_off=self._add_w(wk), bias_off=self._add_w(bk),
             acc_scale=acc_scale, frames=nfr, w_pairs=w_pairs,
             w_ref=w if self.keep_ref else None, b_ref=b if self.keep_ref else None)))
+        return out
+
+    def conv_tail(self, name, pre3, pre1, x, tile, res=None, add1=None, add2=None):
+        """A Bottleneck's 3x3 stride-1 conv (prefix pre3, bias + ReLU) and the 1x1 behind it (prefix pre1, + res, ReLU, + add1,
+        + add2) as ONE launch (csrc/convf.hip, tile ids 80..89): the 3x3's output never leaves the CU."""
+        w3, b3 = fold_conv_bn(self.sd, pre3)
+        w1, b1 = fold_conv_bn(self.sd, pre1)
+        P, cin = w3.shape[0], w3.shape[1]
+        cout = w1.shape[0]
+        bn2 = TAIL_BN[tile]
+        assert TILES[tile][1] == P == w1.shape[1] and cin == x.C and w3.shape[2] == 3 and w1.shape[2] == 1 and cout % 8 == 0
+        cout_pad = _rup(cout, bn2)
+        M = self.B * x.H * x.W
+        K3 = 9 * cin
+        sc3 = sc1 = 1.0
+        if self.x3:
+            hi, lo, sc3 = split_f16(w3.permute(0, 2, 3, 1).reshape(P, K3))
+            wk3 = torch.stack([hi, lo])
+            hi, lo, sc1 = split_f16(w1.reshape(cout, P))
+            wk1 = torch.zeros((2, cout_pad, P), dtype=torch.float16)
+            wk1[0, :cout], wk1[1, :cout] = hi, lo
+        else:
+            wk3 = w3.permute(0, 2, 3, 1).reshape(1, P, K3).to(torch.float16)
+            wk1 = torch.zeros((1, cout_pad, P), dtype=torch.float16)
+            wk1[0, :cout] = w1.reshape(cout, P).to(torch.float16)
+            if not (torch.isfinite(wk3).all() and torch.isfinite(wk1).all()):
+                raise ValueError(f"{name}: folded weights exceed the fp16 range")
+        wk3 = pack_halo_rows(wk3, P, 9, cin, self.x3)
+        wk1 = pack_halo_rows(wk1, bn2, 1, P, self.x3)
+        bk1 = torch.zeros((cout_pad,), dtype=torch.float32)
+        bk1[:cout] = b1.to(torch.float32)
+        out = self.tensor(name, x.H, x.W, cout)
+        self.flops += 2 * M * (P * K3 + cout * P)
+        self.alg_bytes += (x.nbytes + out.nbytes + (wk3.numel() + wk1.numel()) * 2
+                           + sum(t.nbytes for t in (res, add1, add2) if t is not None))
+        self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, p=dict(
+            Cin=cin, in_c_off=0, Cout=P, ksize=3, stride=1, pad=1, relu=1, cout_pad=P, tile=tile, out_fp32=0,
+            w_off=self._add_w(wk3), bias_off=self._add_w(b3.to(torch.float32)), acc_scale=sc3, frames=self.B, w_pairs=0,
+            tail=dict(cout=cout, cout_pad=cout_pad, w_off=self._add_w(wk1), bias_off=self._add_w(bk1), acc_scale=sc1,
+                      w_ref=w1 if self.keep_ref else None, b_ref=b1 if self.keep_ref else None),
+            w_ref=w3 if self.keep_ref else None, b_ref=b3 if self.keep_ref else None)))
         return out
 
     # -- the network (smap.py:313-353 structure, :403-419 data flow)
@@ -464,8 +534,20 @@ class Graph:
         # Bottleneck (smap.py:48-77): stride on the 3x3, shortcut 1x1 stride-s when shape changes
         idn = self.conv(pre + ".downsample", [pre + ".downsample"], x, 1, stride, relu=False) if has_ds else x
         y = self.conv(pre + ".c1", [pre + ".conv_bn_relu1"], x, 1, 1, relu=True)
+        tail = self.tail_tile(planes, stride)
+        if tail is not None:        # c2 + c3 in one launch (csrc/convf.hip)
+            return self.conv_tail(pre + ".c3", pre + ".conv_bn_relu2", pre + ".conv_bn_relu3", y, tail, res=idn, add1=add1, add2=add2)
         y = self.conv(pre + ".c2", [pre + ".conv_bn_relu2"], y, 3, stride, relu=True)
         return self.conv(pre + ".c3", [pre + ".conv_bn_relu3"], y, 1, 1, relu=True, res=idn, add1=add1, add2=add2)
+
+    def tail_tile(self, planes, stride):
+        """Tile id of the fused 3x3 + 1x1 launch for a Bottleneck of this width, or None = two launches.
+        SMAP_TAIL="64:80,128:82" chooses per width (A/B hook); default: see TAIL_DEFAULT."""
+        if stride != 1:
+            return None
+        spec = os.environ.get("SMAP_TAIL")
+        table = TAIL_DEFAULT if spec is None else {int(k): int(v) for k, v in (kv.split(":") for kv in spec.split(",") if ":" in kv)}
+        return table.get(planes)
 
     def _stage(self, s, x, skip1, skip2, gen_skip, heads):
         pre = f"stage{s}."
@@ -612,6 +694,10 @@ class Graph:
                 o.acc_scale = p["acc_scale"]
                 o.w_pairs = p["w_pairs"]
                 o.out_fp32, o.tile = p["out_fp32"], p["tile"]
+                if "tail" in p:
+                    tl = p["tail"]
+                    o.tail_cout, o.tail_cout_pad, o.tail_acc_scale = tl["cout"], tl["cout_pad"], tl["acc_scale"]
+                    o.tail_w_off, o.tail_bias_off = tl["w_off"], tl["bias_off"]
                 o.in_off, o.out_off, o.w_off, o.bias_off = x.off, y.off, p["w_off"], p["bias_off"]
                 for nm in ("res", "add1", "add2"):
                     t = getattr(op, nm)
@@ -690,6 +776,7 @@ class BackboneEngine:
         self.out = self.new_output()                      # default output buffer
         self.hms, self.det_d, self.root_d = self.views(self.out)
         self.flops_per_batch = g.flops
+        self.alg_bytes_per_batch = g.alg_bytes            # conv launches only (stem / pool / head sums are < 3 % more)
 
     def sibling(self):
         """A second executor of the same schedule with its own arena (weights and plan shared), so that

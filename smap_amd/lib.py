@@ -17,7 +17,7 @@ SO_PATH = os.environ.get("SMAP_HIP_LIB") or os.path.join(HERE, "libsmap_hip.so")
 # every symbol include/smap_hip.h declares
 SYMBOLS = [
     "smap_version", "smap_scale_hms", "smap_flip_merge", "smap_nms", "smap_paf_score", "smap_group", "smap_lift",
-    "smap_refine", "smap_register_gt", "smap_lift_gt", "smap_refine_gt", "smap_refine_mlp", "smap_preprocess", "smap_sizeof_op", "smap_conv_tile_dims", "smap_conv_tile_bk", "smap_plan_create", "smap_plan_destroy", "smap_plan_run", "smap_plan_run_range",
+    "smap_refine", "smap_register_gt", "smap_lift_gt", "smap_refine_gt", "smap_refine_mlp", "smap_preprocess", "smap_sizeof_op", "smap_conv_tile_dims", "smap_conv_tile_bk", "smap_conv_tile_tail_bn", "smap_plan_create", "smap_plan_destroy", "smap_plan_run", "smap_plan_run_range",
 ]
 
 
@@ -37,7 +37,9 @@ class SmapOp(C.Structure):
         ("aux_off", C.c_int64 * 3), ("aux_h", C.c_int32 * 3), ("aux_w", C.c_int32 * 3),
         ("ext_off", C.c_int64),
         ("precision", C.c_int32), ("acc_scale", C.c_float),
-        ("flip_from", C.c_int32), ("w_pairs", C.c_int32), ("status_off", C.c_int32), ("pad_", C.c_int32),
+        ("flip_from", C.c_int32), ("w_pairs", C.c_int32), ("status_off", C.c_int32),
+        ("tail_cout", C.c_int32), ("tail_cout_pad", C.c_int32), ("tail_acc_scale", C.c_float),
+        ("tail_w_off", C.c_int64), ("tail_bias_off", C.c_int64),
     ]
 
 
@@ -76,6 +78,7 @@ def load():
     lib.smap_preprocess.argtypes = [vp, ip, ip, ip, ip, ip, ip, vp, ip, ip, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_double, C.c_double, vp]
     lib.smap_conv_tile_dims.argtypes = [ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.smap_conv_tile_bk.argtypes = [ip, ip]
+    lib.smap_conv_tile_tail_bn.argtypes = [ip]
     lib.smap_plan_create.argtypes = [C.POINTER(SmapOp), ip, C.POINTER(vp)]
     lib.smap_plan_destroy.argtypes = [vp]
     lib.smap_plan_destroy.restype = None

@@ -260,6 +260,117 @@ def test_single_conv_split_precision(case):
     assert not got[..., cout:].any()
 
 
+def _run_tail(B, H, W, Cin, P, Cout, tile, relu, use_res, use_adds, x3, seed=0):
+    """One fused Bottleneck-tail op (csrc/convf.hip): 3x3 Cin -> P (bias, ReLU) then 1x1 P -> Cout (+ res, ReLU, + adds)."""
+    from smap_amd import lib as L
+    from smap_amd.engine import TAIL_BN, TILES, ZERO_PAGE, pack_halo_rows, split_f16
+    lib = L.load()
+    g = torch.Generator().manual_seed(seed)
+    bn2 = TAIL_BN[tile]
+    cout_pad = (Cout + bn2 - 1) // bn2 * bn2
+    q = (lambda t: t) if x3 else (lambda t: t.half())
+    x = q(torch.randn(B, H, W, Cin, generator=g))
+    w3 = q(torch.randn(P, Cin, 3, 3, generator=g) * (1.0 / (9 * Cin)) ** 0.5)
+    b3 = torch.randn(P, generator=g) * 0.5
+    w1 = q(torch.randn(Cout, P, 1, 1, generator=g) * (1.0 / P) ** 0.5)
+    b1 = torch.randn(Cout, generator=g)
+    res = q(torch.randn(B, H, W, Cout, generator=g)) if use_res else None
+    a1 = q(torch.randn(B, H, W, Cout, generator=g)) if use_adds else None
+    a2 = q(torch.randn(B, H, W, Cout, generator=g)) if use_adds else None
+    sc3 = sc1 = 1.0
+    if x3:
+        hi, lo, sc3 = split_f16(w3.permute(0, 2, 3, 1).reshape(P, 9 * Cin).double())
+        wk3 = torch.stack([hi, lo])
+        hi, lo, sc1 = split_f16(w1.reshape(Cout, P).double())
+        wk1 = torch.zeros(2, cout_pad, P, dtype=torch.float16)
+        wk1[0, :Cout], wk1[1, :Cout] = hi, lo
+    else:
+        wk3 = w3.permute(0, 2, 3, 1).reshape(1, P, 9 * Cin)
+        wk1 = torch.zeros(1, cout_pad, P, dtype=torch.float16)
+        wk1[0, :Cout] = w1.reshape(Cout, P)
+    wk3, wk1 = pack_halo_rows(wk3, P, 9, Cin, x3), pack_halo_rows(wk1, bn2, 1, P, x3)
+    bk1 = torch.zeros(cout_pad)
+    bk1[:Cout] = b1
+    al = lambda n: (n + 255) // 256 * 256
+    chunks, woffs, cur = [wk3.view(torch.uint8).reshape(-1), b3.view(torch.uint8).reshape(-1), wk1.view(torch.uint8).reshape(-1),
+                          bk1.view(torch.uint8).reshape(-1)], [], 0
+    for c in chunks:
+        woffs.append(cur)
+        cur += al(c.numel())
+    blob = torch.zeros(cur, dtype=torch.uint8)
+    for c, o in zip(chunks, woffs):
+        blob[o:o + c.numel()] = c
+    store = _split if x3 else (lambda t: t)
+    parts, offs, cur = [x, res, a1, a2], [], ZERO_PAGE
+    stored = [store(t) if t is not None else None for t in parts]
+    for t in stored:
+        offs.append(cur if t is not None else -1)
+        cur += al(t.numel() * 2) if t is not None else 0
+    out_off = cur
+    npl = 2 if x3 else 1
+    arena = torch.zeros(out_off + al(B * H * W * Cout * 2 * npl) + 256, dtype=torch.uint8)
+    for t, o in zip(stored, offs):
+        if t is not None:
+            arena[o:o + t.numel() * 2] = t.contiguous().view(torch.uint8).reshape(-1)
+    op = L.SmapOp()
+    op.kind, op.B, op.H, op.W, op.Cin, op.in_stride_c, op.in_c_off = 0, B, H, W, Cin, Cin * npl, 0
+    op.Ho, op.Wo, op.Cout, op.ksize, op.stride, op.pad, op.relu = H, W, P, 3, 1, 1, int(relu)
+    op.cout_pad, op.out_stride_c, op.out_c_off, op.out_fp32, op.tile = P, Cout * npl, 0, 0, tile
+    op.in_off, op.out_off, op.w_off, op.bias_off = offs[0], out_off, woffs[0], woffs[1]
+    op.res_off, op.add1_off, op.add2_off = offs[1], offs[2], offs[3]
+    op.precision, op.acc_scale = int(x3), sc3
+    op.tail_cout, op.tail_cout_pad, op.tail_acc_scale, op.tail_w_off, op.tail_bias_off = Cout, cout_pad, sc1, woffs[2], woffs[3]
+    for i in range(3):
+        op.aux_off[i] = -1
+    op.ext_off = -1
+    h = C.c_void_p()
+    L.check(lib.smap_plan_create(C.byref(op), 1, C.byref(h)), "create")
+    arena_d, blob_d = arena.to(DEV), blob.to(DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.smap_plan_run(h, None, C.c_void_p(arena_d.data_ptr()), C.c_void_p(blob_d.data_ptr()), None, st), "run")
+    torch.cuda.synchronize()
+    lib.smap_plan_destroy(h)
+    raw = arena_d[out_off:out_off + B * H * W * Cout * 2 * npl].cpu()
+    if x3:
+        got = raw.view(torch.float16).view(B, H, W, 2, Cout).float()
+        got = got[..., 0, :] + got[..., 1, :]
+    else:
+        got = raw.view(torch.float16).view(B, H, W, Cout).float()
+    y = F.relu(F.conv2d(x.double().permute(0, 3, 1, 2), w3.double(), b3.double(), padding=1))
+    if not x3:
+        y = y.half().double()                                  # the 3x3's output is an fp16 activation in that mode
+    y = F.conv2d(y, w1.double(), b1.double()).permute(0, 2, 3, 1)
+    if use_res:
+        y = y + res.double()
+    if relu:
+        y = F.relu(y)
+    if use_adds:
+        y = y + a1.double() + a2.double()
+    return got, y.float()
+
+
+TAIL_CASES = [
+    # B, H,  W,  Cin, P,  Cout, tile, relu, res, adds
+    (2, 16, 32, 64, 64, 256, 80, True, True, False),
+    (1, 13, 52, 64, 64, 256, 80, True, True, True),          # ragged pixel tiles in both directions
+    (3, 10, 14, 128, 64, 192, 80, False, False, False),      # Cout not a chunk multiple, two input chunks
+    (2, 16, 32, 64, 64, 256, 81, True, True, True),
+    (1, 9, 40, 192, 64, 320, 81, True, True, False),
+    (2, 16, 32, 128, 128, 512, 82, True, True, False),
+    (1, 13, 52, 128, 128, 448, 82, True, True, True),
+]
+
+
+@pytest.mark.parametrize("x3", [False, True], ids=["f16", "x3"])
+@pytest.mark.parametrize("case", TAIL_CASES, ids=lambda c: "x".join(map(str, c[:7])))
+def test_fused_bottleneck_tail(case, x3):
+    got, ref = _run_tail(*case, x3=x3, seed=hash(case) % 1000)
+    err = (got - ref).abs()
+    assert torch.isfinite(got).all()
+    tol = 3e-6 * ref.abs().max().item() + 1e-6 if x3 else 2e-3 * ref.abs().max().item() + 1e-3
+    assert err.max().item() < tol, (err.max().item(), tol, np.unravel_index(err.argmax().item(), err.shape))
+
+
 def test_split_precision_keeps_fp16_subnormal_lo_parts():
     """Activations around 2^-6: their lo parts (~2^-18) are SUBNORMAL fp16 numbers.  The split scheme relies on the matrix
     cores taking subnormal fp16 inputs as they are; flushing them would cost 2^-12 relative error on such values."""
@@ -397,6 +508,37 @@ def test_small_schedule_split_precision_with_halo_kernel(golden_dir, small, monk
     outs = [o.cpu() for o in eng.run(torch.from_numpy(z["x"]).to(DEV))]
     for a, k in zip(outs, ("hms", "det_d", "root_d")):
         assert np.abs(a.numpy() - z[k]).max() < 2e-5 * np.abs(z[k]).max(), k
+
+
+@pytest.mark.parametrize("precision,tol", [("x3", 2e-5), ("f16", 1e-2)])
+@pytest.mark.parametrize("spec", ["64:80", "64:81,128:82"])
+def test_small_schedule_with_fused_bottleneck_tails(golden_dir, small, monkeypatch, spec, precision, tol):
+    """Stride-1 Bottlenecks with c2 + c3 as one launch (csrc/convf.hip): every stored tensor against the f64 interpretation of
+    the SAME schedule, and the outputs against the golden outputs of the reference model."""
+    from smap_amd.engine import BackboneEngine, Graph
+    from oracle.graph_interp import run_graph
+    _, sd = small
+    z = np.load(f"{golden_dir}/backbone_small.npz")
+    x = torch.from_numpy(z["x"])
+    monkeypatch.setenv("SMAP_TAIL", spec)
+    eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision=precision)
+    n_tail = sum(1 for op in eng.graph.ops if op.kind == 0 and "tail" in op.p)
+    assert n_tail == 3 * (3 if spec == "64:80" else 3 + 3) and not any(t.name.endswith(".c2") for t in eng.graph.tensors if ".layer1.1" in t.name)
+    outs = [o.cpu() for o in eng.run(x.to(DEV))]
+    torch.cuda.synchronize()
+    g = Graph(sd, 2, 64, 96, keep_ref=True)
+    with torch.no_grad():
+        *ref, T = run_graph(g, x.double(), quantize=False, keep=True)
+    worst = []
+    for t in eng.graph.tensors:
+        got = eng.read_tensor(t.name).cpu().double().permute(0, 3, 1, 2)
+        want = T[t.name].double()
+        c = want.shape[1]
+        worst.append(((got[:, :c] - want).abs().max().item() / (want.abs().max().item() + 1e-6), t.name))
+    worst.sort(reverse=True)
+    assert worst[0][0] < tol, worst[:5]
+    for a, k in zip(outs, ("hms", "det_d", "root_d")):
+        assert np.abs(a.numpy() - z[k]).max() < tol * np.abs(z[k]).max(), k
 
 
 @pytest.mark.parametrize("env", [{"SMAP_HALO3": "16"}, {"SMAP_HALO3": "32", "SMAP_HALO3_DEEP": "1"}], ids=["halo16", "halo32deep"])

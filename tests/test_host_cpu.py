@@ -138,7 +138,9 @@ def test_tile_geometry_tables_agree_with_the_library():
     from smap_amd import lib as L
     from smap_amd.engine import TILES, tile_bk
     lib = L.load()
-    for t in range(0, 80):
+    from smap_amd.engine import TAIL_BN
+    for t in range(0, 100):
+        assert lib.smap_conv_tile_tail_bn(t) == TAIL_BN.get(t, 0), t
         bm, bn = C.c_int(), C.c_int()
         rc = lib.smap_conv_tile_dims(t, C.byref(bm), C.byref(bn))
         assert (rc == 0) == (t in TILES), t
@@ -196,6 +198,44 @@ def test_weight_packing_matches_the_kernels_address_arithmetic():
                   else:               # pairs: byte = (nt*KT/2 + it/2)*WBLK + (it&1)*64 + (pl*BN + r)*128 + s*16
                       off = (((((nt * (KT // 2) + it // 2) * planes + pl) * bn + r) * 2 + (it & 1)) * 4 + s) * 8 + e
               assert P[off] == w2[pl, n, k], (tile, x3, off)
+
+
+def test_fused_bottleneck_tail_schedule_on_cpu(small_sd, monkeypatch):
+    """SMAP_TAIL routes stride-1 Bottlenecks to the one-launch 3x3 + 1x1 op (csrc/convf.hip): the op list shrinks by one launch
+    per such block, the torch interpretation of the fused schedule equals the unfused one bit for bit in both its modes (the
+    quantised mode reads the weights back out of the packed blob: the 1x1's chunk blocks invert), the plan accepts the ops
+    and rejects inconsistent ones."""
+    import ctypes as C
+    from oracle.graph_interp import run_graph
+    from smap_amd import lib as L
+    from smap_amd.engine import Graph, OP_CONV, TAIL_BN, pack_halo_rows, unpack_halo_rows
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(3))
+    g0 = Graph(small_sd, 2, 64, 96, keep_ref=True)
+    want, want_q = run_graph(g0, x.double(), quantize=False), run_graph(g0, x, quantize=True)
+    monkeypatch.setenv("SMAP_TAIL", "64:80,128:82")
+    for prec in ("f16", "x3"):
+        g = Graph(small_sd, 2, 64, 96, keep_ref=True, precision=prec)
+        tails = [op for op in g.ops if op.kind == OP_CONV and "tail" in op.p]
+        assert len(tails) == 18 and len(g.ops) == len(g0.ops) - 18            # layer1: 3 blocks, layer2: 3 stride-1 blocks, x 3 stages
+        assert all(op.res is not None and op.p["Cout"] * 4 == op.p["tail"]["cout"] for op in tails)
+        assert all(torch.equal(a, b) for a, b in zip(run_graph(g, x.double(), quantize=False), want))
+        if prec == "f16":
+            assert all(torch.equal(a, b) for a, b in zip(run_graph(g, x, quantize=True), want_q))
+        g.allocate()
+        ops = g.emit()
+        h = C.c_void_p()
+        assert L.load().smap_plan_create(ops, len(g.ops), C.byref(h)) == 0
+        L.load().smap_plan_destroy(h)
+        i = next(k for k, op in enumerate(g.ops) if op.kind == OP_CONV and "tail" in op.p)
+        for field, bad in (("tail_cout", 0), ("tail_cout", 100), ("tail_cout_pad", 32), ("stride", 2), ("tile", 36), ("tail_w_off", -1)):
+            keep = getattr(ops[i], field)
+            setattr(ops[i], field, bad)
+            assert L.load().smap_plan_create(ops, len(g.ops), C.byref(h)) != 0, field
+            setattr(ops[i], field, keep)
+    for x3 in (False, True):
+        w = torch.randn(2 if x3 else 1, 256, 64).half()
+        p = pack_halo_rows(w, TAIL_BN[80], 1, 64, x3)
+        assert p.shape[:3] == (4, 2 if x3 else 1, 1) and torch.equal(unpack_halo_rows(p.reshape(-1), 64, 1, 64, 256, x3), w)
 
 
 def test_lazy_records_equal_eager_records():
