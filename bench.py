@@ -294,6 +294,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU reference pass (no cpu_baseline, no config.e2e_parity): kernel experiments only")
+    ap.add_argument("--launch-frames", type=int, default=16,
+                    help="frames per backbone launch the pipeline aims for: consecutive steps' batches are coalesced up to it "
+                         "(0 = one launch per step)")
     ap.add_argument("--depth", type=int, default=2,
                     help="backbones in flight per GPU (2 = two streams/arenas: batch k+1 fills the CUs that batch k's "
                          "low-resolution layers leave idle)")
@@ -345,7 +348,7 @@ def main():
     args.cdev = cdev
     if args.forward_only:
         return forward_only(args, dev, rank, world, B)
-    from smap_amd.pipeline import PosePipeline
+    from smap_amd.pipeline import make_pipeline
     from exps.stage3_root2.config import cfg as run_cfg
     torch.manual_seed(0)
     net = SMAP(make_cfg((128, 208))).eval()
@@ -376,8 +379,9 @@ def main():
         fp = (list(run_cfg.DATASET.KEYPOINT.FLIP_ORDER) + [run_cfg.DATASET.KEYPOINT.NUM + c for c in run_cfg.DATASET.PAF.FLIP_CHANNEL]) if args.flip else None
         hip_frames = parity.hip_path(net, imgs[:nref] if B == nref else imgs, cams, flip_pair=fp)[:nref] if B >= nref else None
 
-    pipe = PosePipeline(net, run_cfg, B, H, W, dev, refine_weights=refine_w, n_extra=1, depth=args.depth, numpy_records=True,
-                        do_flip=args.flip)
+    # batches of <= 8 frames are run two (or more) to a backbone launch: --launch-frames (smap_amd/pipeline.py::make_pipeline)
+    pipe = make_pipeline(net, run_cfg, B, H, W, dev, launch_frames=args.launch_frames, refine_weights=refine_w, n_extra=1,
+                         depth=args.depth, numpy_records=True, do_flip=args.flip)
     KS = (0, 2, 8, 20)               # synthetic scenes, person count rotating over the steps
     synth = {}
     for K in KS:
@@ -459,10 +463,11 @@ def main():
         if args.depth > 1:       # backbones overlap: rate = algorithmic work of the timed region / its duration
             achieved = ALG_GFLOP_PER_FRAME * B * args.steps / dt / 1e3
         else:
-            achieved = ALG_GFLOP_PER_FRAME * B / bb / 1e3        # TFLOP/s over the whole backbone schedule
+            achieved = ALG_GFLOP_PER_FRAME * pipe.frames_per_launch / bb / 1e3        # TFLOP/s over the whole backbone schedule
         x3 = args.precision == "x3"
-        step_s = dt / args.steps if args.depth > 1 else bb
-        alg_bytes = pipe.engine.alg_bytes_per_batch * (B // pipe.chunk)     # launches per step x bytes per launch schedule
+        step_s = dt / args.steps if args.depth > 1 else bb * B / pipe.frames_per_launch
+        fpl = pipe.frames_per_launch                                             # input frames per backbone launch
+        alg_bytes = pipe.engine.alg_bytes_per_batch * B / fpl                    # bytes per launch schedule x launches per step
         traffic, traffic_src = None, None                        # HBM bytes per batch from committed PMC passes
         tj = os.path.join(ROOT, "profiles", "hbm_traffic_x3.json" if x3 else "hbm_traffic.json")
         if os.path.exists(tj) and B == 8:
@@ -488,8 +493,12 @@ def main():
                                           "(e2e_parity below); f16: ~2x the frames/s, ~0.36 cm mean / 1.06 cm max joint error at 3 m "
                                           "(profiles/r2_final_bench_f16.json) -- not within the 1e-3 m of the north star",
                        "pipeline": f"post-processing of batch k overlaps later backbones; {args.depth} backbone(s) in flight; "
-                                   f"one end-of-run gather of the records",
-                       "association_lift_us_per_batch": {k: float(np.median(v)) for k, v in sorted(post_us.items())},
+                                   f"{pipe.frames_per_launch} frames per backbone launch"
+                                   + (f" (= {pipe.frames_per_launch // B} consecutive steps' batches coalesced; --launch-frames 0: one launch "
+                                      f"per step)" if pipe.frames_per_launch > B else "")
+                                   + "; one end-of-run gather of the records",
+                       "frames_per_launch": pipe.frames_per_launch,
+                       "association_lift_us_per_launch": {k: float(np.median(v)) for k, v in sorted(post_us.items())},
                        "host_ms_per_step": {"submit_wall": host["submit"] / args.steps * 1e3, "process_cpu_per_rank": per_rank_host,
                                             "threads": host_threads,
                                             "busiest_threads_cpu_ms": [[n, round(v, 2)] for n, v in busiest]},
@@ -507,7 +516,7 @@ def main():
                                          "peak_GBps": PEAK_HBM_GBPS, "frac_of_hbm_peak": alg_bytes / step_s / 1e9 / PEAK_HBM_GBPS,
                                          "measured_ceilings_GBps": {"hbm_read": 5300, "hbm_write": 6200, "hbm_mixed": 5200,
                                                                     "source": "profiles/r2_v17_ubench_hbm_read_write_mix.log"}},
-                         "backbone_ms_per_batch": bb * 1e3,
+                         "backbone_ms_per_launch": bb * 1e3,
                          "backbone_stream_idle_ms_between_batches": float(np.mean(gap_ms)) if gap_ms else None,
                          "algorithmic_gflop_per_frame": ALG_GFLOP_PER_FRAME},
         }

@@ -32,7 +32,7 @@ from model.refinenet import RefineNet
 from dataset.custom_dataset import CustomDataset
 from smap_amd.dist import gather_records, shard_range
 from exps.stage3_root2.config import cfg
-from smap_amd.pipeline import PosePipeline
+from smap_amd.pipeline import PosePipeline, make_pipeline
 from exps.stage3_root2.test_util import default_cams
 from smap_amd.records import annotation_camera, kept_annotations, to_jsonable
 
@@ -91,7 +91,8 @@ class _DryRunPipeline:
 
 def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, device, output_dir="", pipeline_cls=None):
     os.makedirs(output_dir, exist_ok=True)
-    pipeline_cls = pipeline_cls or PosePipeline
+    if pipeline_cls is None:       # batches of <= 8 frames share a backbone launch (smap_amd/pipeline.py::make_pipeline, SMAP_LAUNCH_FRAMES)
+        pipeline_cls = lambda m, c, b, h, w, d, rw, **kw: make_pipeline(m, c, b, h, w, d, refine_weights=rw, **kw)
     if model is not None:
         model.eval()
     refine_w = None

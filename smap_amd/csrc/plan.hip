@@ -384,27 +384,39 @@ constexpr int HS_PX = 32;
 
 // ((s0 + up(s1)) + up(s2)) for four consecutive channels of pixel (b, y, x): the value the reference's
 // `res4 + res3 + res2` (smap.py:417) has there.  A source at the output resolution is its own bilinear image.
-__device__ __forceinline__ float4 head_value4(const HeadSrc& s, const Lerp* ly, int b, int y, int x, int c, int Ho, int Wo, int Cs)
+// Written with the source index k as a COMPILE-TIME constant (unrolled, `k < s.n` as a predicate): a run-time index into
+// the by-value argument struct makes the compiler re-read the kernel arguments with scalar loads inside the pixel loop and park
+// the Lerp array in LDS; neither belongs in a kernel whose results must not depend on what else is running (EXPERIMENTS R3.6).
+template <int K>
+__device__ __forceinline__ float4 head_source4(const HeadSrc& s, const Lerp& ly, int b, int y, int x, int c, int Ho, int Wo, int Cs)
 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < s.n; ++k) {
-        const float* base = s.p[k] + (size_t)b * s.h[k] * s.w[k] * Cs + c;
-        float4 up;
-        if (s.h[k] == Ho && s.w[k] == Wo) {
-            up = *reinterpret_cast<const float4*>(base + ((size_t)y * Wo + x) * Cs);
-        } else {
-            const Lerp lx = lerp_index(x, s.w[k], Wo);
-            const float4 v00 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i0 * s.w[k] + lx.i0) * Cs);
-            const float4 v01 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i0 * s.w[k] + lx.i1) * Cs);
-            const float4 v10 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i1 * s.w[k] + lx.i0) * Cs);
-            const float4 v11 = *reinterpret_cast<const float4*>(base + ((size_t)ly[k].i1 * s.w[k] + lx.i1) * Cs);
-            up.x = ly[k].l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly[k].l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
-            up.y = ly[k].l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly[k].l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
-            up.z = ly[k].l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly[k].l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
-            up.w = ly[k].l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly[k].l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
-        }
-        if (k == 0) v = up;
-        else { v.x += up.x; v.y += up.y; v.z += up.z; v.w += up.w; }
+    const int sh = s.h[K], sw = s.w[K];
+    const float* base = s.p[K] + (size_t)b * sh * sw * Cs + c;
+    if (sh == Ho && sw == Wo) return *reinterpret_cast<const float4*>(base + ((size_t)y * Wo + x) * Cs);
+    const Lerp lx = lerp_index(x, sw, Wo);
+    const float4 v00 = *reinterpret_cast<const float4*>(base + ((size_t)ly.i0 * sw + lx.i0) * Cs);
+    const float4 v01 = *reinterpret_cast<const float4*>(base + ((size_t)ly.i0 * sw + lx.i1) * Cs);
+    const float4 v10 = *reinterpret_cast<const float4*>(base + ((size_t)ly.i1 * sw + lx.i0) * Cs);
+    const float4 v11 = *reinterpret_cast<const float4*>(base + ((size_t)ly.i1 * sw + lx.i1) * Cs);
+    float4 up;
+    up.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
+    up.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
+    up.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
+    up.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+    return up;
+}
+
+__device__ __forceinline__ float4 head_value4(const HeadSrc& s, const Lerp& ly0, const Lerp& ly1, const Lerp& ly2, int b, int y, int x,
+                                              int c, int Ho, int Wo, int Cs)
+{
+    float4 v = head_source4<0>(s, ly0, b, y, x, c, Ho, Wo, Cs);
+    if (s.n > 1) {
+        const float4 u = head_source4<1>(s, ly1, b, y, x, c, Ho, Wo, Cs);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (s.n > 2) {
+        const float4 u = head_source4<2>(s, ly2, b, y, x, c, Ho, Wo, Cs);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
     return v;
 }
@@ -424,21 +436,21 @@ __global__ __launch_bounds__(256) void headsum_kernel(HeadSrc s, float* __restri
     __shared__ float tile[(FLIP ? 2 : 1) * 48 * (HS_PX + 1)];
     float* tile2 = tile + 48 * (HS_PX + 1);
     const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * HS_PX, tid = threadIdx.x;
-    Lerp ly[3];
-    for (int k = 0; k < s.n; ++k) ly[k] = lerp_index(y, s.h[k], Ho);
+    const Lerp ly0 = lerp_index(y, s.h[0], Ho);
+    const Lerp ly1 = lerp_index(y, s.n > 1 ? s.h[1] : Ho, Ho), ly2 = lerp_index(y, s.n > 2 ? s.h[2] : Ho, Ho);
     // four channels per thread (16-byte loads; Cs is a multiple of 8)
     const int G = Cs >> 2;
     for (int idx = tid; idx < HS_PX * G; idx += 256) {
         const int px = idx / G, c = (idx - px * G) * 4;
         const int x = x0 + px;
         if (x >= Wo || c >= C) continue;
-        const float4 v = head_value4(s, ly, b, y, x, c, Ho, Wo, Cs);
+        const float4 v = head_value4(s, ly0, ly1, ly2, b, y, x, c, Ho, Wo, Cs);
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (c + e < C) tile[(c + e) * (HS_PX + 1) + px] = vv[e];
         if (FLIP) {
-            const float4 m = head_value4(s, ly, b + flip_from, y, Wo - 1 - x, c, Ho, Wo, Cs);
+            const float4 m = head_value4(s, ly0, ly1, ly2, b + flip_from, y, Wo - 1 - x, c, Ho, Wo, Cs);
             const float mm[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)

@@ -97,6 +97,7 @@ class PosePipeline:
         self.s_comm = torch.cuda.Stream(self.device)      # result gather (RCCL) never queues behind compute
         self.nslots = self.depth + 1
         self.slots = [_Slot(self.engine, self.device, n_extra, batch) for _ in range(self.nslots)]
+        self.frames_per_launch = self.chunk
         self.k = 0
         self.bb_events = []              # (start, end) HIP events of timed backbone runs
         self.post_events = []            # (tag, start, end) HIP events of timed association+lifting passes (time_backbone=True)
@@ -183,7 +184,7 @@ class PosePipeline:
                 p0.record()
                 self._post(*a, **k)
                 p1.record()
-                self.post_events.append((tag, p0, p1))
+                self.post_events.append((tag if isinstance(tag, str) else "+".join(sorted(set(tag))), p0, p1))
             st_words = [o[slot.status:slot.status + 1].view(torch.int32) for o in slot.outs]
             slot.status_host.copy_((st_words[0] if len(st_words) == 1 else torch.stack(st_words).max(0).values).view(torch.float32),
                                    non_blocking=True)
@@ -237,7 +238,8 @@ class PosePipeline:
                 P = int(P)
                 if P == 0 or tags[i] is None:                                   # tag None = padding frame of a ragged last batch
                     continue                                                    # test.py:81-82,131-132
-                name = tags[i] if idx == 0 else f"{extra_tags[idx - 1]}/{tags[i]}"
+                pref = extra_tags[idx - 1] if idx else None                     # one prefix, or one per frame (coalesced batches)
+                name = tags[i] if idx == 0 else f"{pref if isinstance(pref, str) else pref[i]}/{tags[i]}"
                 if gt_mode and self.record_mode == "generate_train":            # test.py:142-143
                     recs.extend(train_records(p2[i, :P], p3[i, :P], rz[i, :P], np.asarray(annotations[i]),
                                               self.cfg.DATASET.ROOT_IDX, as_lists=self.as_lists))
@@ -246,3 +248,83 @@ class PosePipeline:
                                              np.asarray(annotations[i]) if gt_mode else None, as_lists=self.as_lists))
         slot.busy = False
         return recs
+
+
+class CoalescedPipeline:
+    """PosePipeline for callers with SMALL batches: `group` consecutive submit() calls run as ONE backbone launch of
+    group * batch frames.  The low-resolution layers of the backbone have 100-200 workgroups per launch at 8 frames and are
+    bound by what ONE workgroup per CU can stream from L2 into LDS; at 16 frames per launch the same layers fill the chip
+    (790 vs 747 frames/s at batch 8, profiles/r3_frames_per_launch.log).  Same protocol as PosePipeline -- submit() returns
+    the records of earlier batches (whole groups at a time, in submission order) or None, flush() everything outstanding;
+    a trailing incomplete group runs through a `batch`-sized pipeline built on first need.  Costs latency (a batch waits
+    for its group), never order or results: frames are independent."""
+
+    def __init__(self, model, cfg, batch, H, W, device, group, **kw):
+        assert group >= 2
+        self.B, self.group = batch, group
+        self.inner = PosePipeline(model, cfg, batch * group, H, W, device, **kw)
+        self._small_args = (model, cfg, batch, H, W, device, kw)
+        self._small = None
+        self._pending = []
+        self._timed = False
+
+    # what callers read off a pipeline
+    engine = property(lambda self: self.inner.engine)
+    chunk = property(lambda self: self.inner.chunk)
+    depth = property(lambda self: self.inner.depth)
+    s_comm = property(lambda self: self.inner.s_comm)
+    bb_events = property(lambda self: self.inner.bb_events)          # one entry per LAUNCH (group * batch frames)
+    post_events = property(lambda self: self.inner.post_events)
+    frames_per_launch = property(lambda self: self.inner.chunk)
+
+    @staticmethod
+    def _merge(pending):
+        imgs = torch.cat([p[0] for p in pending])
+        cams = np.concatenate([np.asarray(p[1]) for p in pending])
+        tags = [t for p in pending for t in p[2]]
+        extra = []
+        for j in range(len(pending[0][3])):
+            parts = [p[3][j] for p in pending]
+            assert all((q[3] is None) == (parts[0][3] is None) for q in parts)
+            prefixes = [q[0] for q, p in zip(parts, pending) for _ in p[2]]
+            extra.append((prefixes if len(set(prefixes)) > 1 else prefixes[0], torch.cat([q[1] for q in parts]),
+                          torch.cat([q[2] for q in parts]), None if parts[0][3] is None else torch.cat([q[3] for q in parts])))
+        ann = None if pending[0][4] is None else [a for p in pending for a in p[4]]
+        return imgs, cams, tags, extra, ann
+
+    def submit(self, imgs, cams, tags, extra=(), time_backbone=False, annotations=None):
+        assert len(tags) == self.B and all(len(extra) == len(p[3]) for p in self._pending)
+        self._pending.append((imgs, cams, list(tags), list(extra), annotations))
+        self._timed = self._timed or time_backbone
+        if len(self._pending) < self.group:
+            return None
+        imgs, cams, tags, extra, ann = self._merge(self._pending)
+        self._pending, timed, self._timed = [], self._timed, False
+        return self.inner.submit(imgs, cams, tags, extra=extra, time_backbone=timed, annotations=ann)
+
+    def flush(self):
+        out = self.inner.flush()
+        if self._pending:                                # an incomplete group: after everything older, batch by batch
+            if self._small is None:
+                model, cfg, batch, H, W, device, kw = self._small_args
+                self._small = PosePipeline(model, cfg, batch, H, W, device, **kw)
+            for imgs, cams, tags, extra, ann in self._pending:
+                r = self._small.submit(imgs, cams, tags, extra=extra, annotations=ann)
+                if r:
+                    out = r if out is None else out + r
+            self._pending, self._timed = [], False
+            r = self._small.flush()
+            if r:
+                out = r if out is None else out + r
+        return out
+
+
+def make_pipeline(model, cfg, batch, H, W, device, launch_frames=None, **kw):
+    """PosePipeline, or CoalescedPipeline when the caller's batch (x2 with flip-TTA) is at most half of `launch_frames`
+    (default 16, env SMAP_LAUNCH_FRAMES; 0 / 1 = one launch per submitted batch)."""
+    lf = int(os.environ.get("SMAP_LAUNCH_FRAMES", "16")) if launch_frames is None else int(launch_frames)
+    per = batch * (2 if kw.get("do_flip") else 1)
+    group = lf // per if per > 0 else 0
+    if group >= 2 and kw.get("record_mode", "run_inference") == "run_inference":
+        return CoalescedPipeline(model, cfg, batch, H, W, device, group, **kw)
+    return PosePipeline(model, cfg, batch, H, W, device, **kw)

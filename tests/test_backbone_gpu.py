@@ -683,6 +683,37 @@ def test_split_precision_dynamic_range(scale, stem_gain):
         assert err < 1e-4, (k, scale, stem_gain, err)
 
 
+@pytest.mark.parametrize("B,flip,precision", [(2, True, "x3"), (8, False, "x3"), (1, True, "f16")])
+def test_overlapping_executors_are_deterministic(B, flip, precision):
+    """Two executors of one schedule on two streams, many launches queued back to back (what PosePipeline(depth=2) does at
+    512x832): every output must equal the serial result bit for bit.  Until round 3 the head-sum kernel indexed its by-value
+    argument struct at run time; the compiler turned that into scalar loads of the kernel arguments inside the pixel loop and an
+    LDS-resident private array addressed through the dispatch packet, and 10-30 % of OVERLAPPED forwards came back with ~15
+    wrong map values (never a serial one: every other test in this file is serial)."""
+    from exps.stage3_root2.config import cfg
+    from smap_amd.engine import BackboneEngine
+    from smap_amd.model.smap import SMAP
+    torch.manual_seed(0)
+    sd = recipe_state_dict(SMAP(make_cfg((128, 208))).state_dict())
+    fp = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [cfg.DATASET.KEYPOINT.NUM + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
+    eng = BackboneEngine(sd, B, 512, 832, DEV, precision=precision, flip_pair=fp if flip else None)
+    engs = [eng, eng.sibling()]
+    streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    imgs = torch.randn(B, 3, 512, 832, generator=torch.Generator().manual_seed(3)).to(DEV)
+    ref = eng.new_output()
+    eng.run(imgs, out=ref)
+    torch.cuda.synchronize()
+    N = 24
+    outs = [eng.new_output() for _ in range(N)]
+    torch.cuda.synchronize()
+    for i in range(N):
+        with torch.cuda.stream(streams[i % 2]):
+            engs[i % 2].run(imgs, out=outs[i])
+    torch.cuda.synchronize()
+    bad = [i for i in range(N) if not torch.equal(outs[i], ref)]
+    assert not bad, bad
+
+
 def test_graph_replay_equals_direct_launches(small):
     """BackboneEngine.capture: the schedule replayed as one HIP graph writes the same bytes as the launch-by-launch run,
     for fresh inputs and repeated replays."""

@@ -166,6 +166,22 @@ def test_two_stream_pipeline_equals_serial_path():
         have = [(r["image_path"], r["pred_2d"], r["pred_3d"], r["root_d"]) for r in got]
         want = want_flip if flip else want_all
         assert have == want + want, (depth, flip, chunk)      # in order, bit for bit
+    # coalesced launches (make_pipeline): `group` submitted batches per backbone launch; 8 submits with group 3 leave an
+    # incomplete group for flush() -- the same records, in the same order, from 6-frame launches + two 2-frame ones
+    from smap_amd.pipeline import CoalescedPipeline, make_pipeline
+    assert not isinstance(make_pipeline(net, cfg, B, 64, 96, dev, launch_frames=0), CoalescedPipeline)
+    for launch_frames, flip in ((4, False), (6, False), (8, True), (16, False)):
+        pipe = make_pipeline(net, cfg, B, 64, 96, dev, launch_frames=launch_frames, depth=2, do_flip=flip)
+        assert isinstance(pipe, CoalescedPipeline) and pipe.B == B and pipe.frames_per_launch == pipe.group * B
+        assert pipe.group == launch_frames // (B * (2 if flip else 1))
+        got = []
+        for rep in range(2):
+            for i, x in enumerate(batches):
+                got += pipe.submit(x, cams, [f"b{i}/{j}" for j in range(B)]) or []
+        got += pipe.flush() or []
+        have = [(r["image_path"], r["pred_2d"], r["pred_3d"], r["root_d"]) for r in got]
+        want = want_flip if flip else want_all
+        assert have == want + want, (launch_frames, flip)
 
 
 def test_device_preprocess_equals_host_dataset(tmp_path):
