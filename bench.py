@@ -475,6 +475,13 @@ def main():
             traffic = t["hbm_read_bytes_per_batch"] + t["hbm_write_bytes_per_batch"]
             traffic_src = t["source"]
         n_rec = len(collected) if gathered is None else sum(len(pickle.loads(b)) for b in gathered)
+        # every timed step runs the SAME frames (and one of four synthetic scenes): records with one image_path must be identical, bit
+        # for bit, whatever ran next to them on the GPU -- a guard the overlapped pipeline lacked until round 3 (EXPERIMENTS R3.6)
+        groups = {}
+        for r in collected:
+            key = (np.asarray(r["pred_2d"]).tobytes(), np.asarray(r["pred_3d"]).tobytes(), np.asarray(r["root_d"]).tobytes())
+            groups.setdefault(r["image_path"], set()).add(key)
+        identical = all(len(v) == 1 for v in groups.values())
         out = {
             "metric": "frames/sec at 3x512x832 (SMAP backbone + depth-aware association + 3D lifting)",
             "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -484,6 +491,9 @@ def main():
                                    f"+ lifting{' + RefineNet (configs[4])' if args.refine else ''}{' + flip-TTA' if args.flip else ''} "
                                    f"(BASELINE configs[2]; configs[3] when n_gpus=8)",
                        "frames_per_step": B * world, "records_in_run": n_rec,
+                       "timed_steps_reproduce": {"identical_records_per_frame_across_steps": identical, "frames_checked": len(groups),
+                                                 "records_checked": len(collected),
+                                                 "frames_with_variants": sorted(k for k, v in groups.items() if len(v) > 1)[:8]},
                        "arithmetic": ("backbone: fp16 hi/lo pairs (22 significant bits), three fp16 MFMAs per K step, fp32 "
                                       "accumulate = the reference's fp32 results to ~3e-6 relative" if x3 else
                                       "backbone: fp16 storage / fp32 MFMA accumulate (~2e-3 relative on the maps)") +

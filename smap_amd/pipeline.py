@@ -158,6 +158,10 @@ class PosePipeline:
         if gt is not None:
             gt[0].record_stream(self.s_post)
             gt[1].record_stream(self.s_post)
+        for _, e_hms, e_rd, e_dd in extra:               # the caller may drop its references (CoalescedPipeline passes temporaries)
+            for t in (e_hms, e_rd, e_dd):
+                if t is not None:
+                    t.record_stream(self.s_post)
         with torch.cuda.stream(s_bb):
             if time_backbone:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

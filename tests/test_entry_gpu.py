@@ -182,6 +182,26 @@ def test_two_stream_pipeline_equals_serial_path():
         have = [(r["image_path"], r["pred_2d"], r["pred_3d"], r["root_d"]) for r in got]
         want = want_flip if flip else want_all
         assert have == want + want, (launch_frames, flip)
+    # `extra` maps (bench only) through coalesced launches: the caller's per-batch tensors are concatenated into temporaries the
+    # post stream must keep alive, and every frame keeps the prefix of ITS batch.  Extra = the network's own scaled maps of
+    # that batch, so "again<i>/<tag>" must carry exactly the record of <tag>.
+    from smap_amd.dapalib import scale_hms_
+    ex = []
+    for x in batches:
+        h, d, rd = net(x)
+        h = scale_hms_(h.clone().contiguous())          # the pipeline's own scaling kernel (test.py:111-112)
+        ex.append((h, rd.clone(), d.clone()))
+    pipe = make_pipeline(net, cfg, B, 64, 96, dev, launch_frames=6, depth=2, n_extra=1)
+    got = []
+    for i, x in enumerate(batches):
+        got += pipe.submit(x, cams, [f"b{i}/{j}" for j in range(B)], extra=[(f"again{i}", *ex[i])]) or []
+    got += pipe.flush() or []
+    by = {r["image_path"]: (r["pred_2d"], r["pred_3d"], r["root_d"]) for r in got}
+    assert len(by) == len(got) == 2 * len(want_all)
+    for name, p2, p3, rz in want_all:
+        i = name[1:name.index("/")]
+        assert by[name] == (p2, p3, rz), name
+        assert by[f"again{i}/{name}"] == (p2, p3, rz), "again/" + name
 
 
 def test_device_preprocess_equals_host_dataset(tmp_path):

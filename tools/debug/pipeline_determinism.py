@@ -10,7 +10,7 @@ from helpers import make_cfg
 from recipe import recipe_state_dict
 from model.smap import SMAP
 from exps.stage3_root2.config import cfg
-from smap_amd.pipeline import PosePipeline
+from smap_amd.pipeline import PosePipeline, make_pipeline
 
 B, flip, depth, N = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 dev = "cuda:0"
@@ -25,15 +25,16 @@ net = net.to(dev)
 g = torch.Generator().manual_seed(3)
 imgs = torch.randn(B, 3, 512, 832, generator=g).to(dev)
 cams = np.tile(np.array([0.5, 832, 512, 416, 256, 832, 832, 416, 256], np.float64), (B, 1))
-pipe = PosePipeline(net, cfg, B, 512, 832, dev, depth=depth, do_flip=bool(flip))
-outs = []
+LF = int(sys.argv[5]) if len(sys.argv) > 5 else 0          # frames per launch (coalesced pipeline) or 0
+pipe = make_pipeline(net, cfg, B, 512, 832, dev, launch_frames=LF, depth=depth, do_flip=bool(flip))
+allr = []
 for i in range(N):
-    r = pipe.submit(imgs, cams, [f"f{j}" for j in range(B)])
-    if r is not None:
-        outs.append(r)
-rest = pipe.flush() or []
-per = len(outs[0]) if outs else len(rest)
-outs += [rest[i:i + per] for i in range(0, len(rest), per)]
+    allr += pipe.submit(imgs, cams, [f"f{j}" for j in range(B)]) or []
+allr += pipe.flush() or []
+names = [r["image_path"] for r in allr]
+per = names.index(names[0], 1) if names.count(names[0]) > 1 else len(names)      # records per submitted batch
+outs = [allr[i:i + per] for i in range(0, len(allr), per)]
+print("pipeline:", type(pipe).__name__, "frames per launch", pipe.frames_per_launch)
 key = lambda recs: [(r["image_path"], np.asarray(r["pred_2d"]).tobytes(), np.asarray(r["pred_3d"]).tobytes(), np.asarray(r["root_d"]).tobytes()) for r in recs]
 ref = key(outs[0])
 bad = [i for i, o in enumerate(outs) if key(o) != ref]
