@@ -313,3 +313,60 @@ def test_test_py_dry_run_eight_ranks(tmp_path):
     got = [rec["image_path"] for rec in res["3d_pairs"]]
     assert got == names                                     # every image once, in listing order
     assert all(len(rec["pred_3d"]) == 1 and len(rec["pred_3d"][0]) == 15 for rec in res["3d_pairs"])
+
+
+def test_coalesced_pipeline_protocol_without_a_gpu(monkeypatch):
+    """smap_amd/pipeline.py::CoalescedPipeline on CPU, the device pipeline replaced by a recorder: `group` submitted batches reach
+    the inner pipeline as ONE concatenated batch (frames, cameras, tags, per-frame prefixes of the extra maps, annotations, in
+    submission order), records come back in order, an incomplete trailing group goes through a batch-sized pipeline at
+    flush(), and make_pipeline picks the group size from the frames per launch (x2 with flip-TTA)."""
+    import smap_amd.pipeline as P
+
+    class Recorder:
+        built = []
+
+        def __init__(self, model, cfg, batch, H, W, device, **kw):
+            self.B, self.kw, self.calls, self.q = batch, kw, [], []
+            self.chunk = self.frames_per_launch = batch
+            self.engine = self.depth = self.s_comm = None
+            self.bb_events, self.post_events = [], []
+            Recorder.built.append(self)
+
+        def submit(self, imgs, cams, tags, extra=(), time_backbone=False, annotations=None):
+            assert len(imgs) == len(cams) == len(tags) == self.B
+            self.calls.append((imgs.clone(), np.asarray(cams).copy(), list(tags), [(t, h.clone(), r.clone(), d) for t, h, r, d in extra],
+                               time_backbone, annotations))
+            self.q.append([{"image_path": t, "v": float(imgs[i].sum())} for i, t in enumerate(tags)])
+            return self.q.pop(0) if len(self.q) > 1 else None
+
+        def flush(self):
+            out = [r for b in self.q for r in b]
+            self.q = []
+            return out or None
+
+    monkeypatch.setattr(P, "PosePipeline", Recorder)
+    B = 2
+    pipe = P.make_pipeline(None, None, B, 8, 8, "cpu", launch_frames=6, depth=2)
+    assert isinstance(pipe, P.CoalescedPipeline) and pipe.group == 3 and pipe.B == B and pipe.frames_per_launch == 6
+    got = []
+    for i in range(8):                                   # 8 batches = 2 full groups + 2 left over
+        imgs = torch.full((B, 3, 8, 8), float(i))
+        cams = np.full((B, 9), float(i))
+        ex = [(f"K{i % 2}", torch.full((B, 43, 2, 2), 10.0 + i), torch.full((B, 1, 2, 2), 20.0 + i), None)]
+        got += pipe.submit(imgs, cams, [f"b{i}/{j}" for j in range(B)], extra=ex, time_backbone=(i == 4)) or []
+    got += pipe.flush() or []
+    assert [r["image_path"] for r in got] == [f"b{i}/{j}" for i in range(8) for j in range(B)]       # every frame once, in order
+    assert [r["v"] for r in got] == [float(i) * 3 * 64 for i in range(8) for _ in range(B)]
+    big, small = Recorder.built[0], Recorder.built[1]
+    assert big.B == 6 and small.B == 2 and len(big.calls) == 2 and len(small.calls) == 2
+    imgs, cams, tags, extra, timed, ann = big.calls[1]                                               # batches 3, 4, 5
+    assert imgs[:, 0, 0, 0].tolist() == [3, 3, 4, 4, 5, 5] and cams[:, 0].tolist() == [3, 3, 4, 4, 5, 5] and timed and ann is None
+    assert tags == [f"b{i}/{j}" for i in (3, 4, 5) for j in range(B)]
+    assert extra[0][0] == ["K1", "K1", "K0", "K0", "K1", "K1"] and extra[0][1][:, 0, 0, 0].tolist() == [13, 13, 14, 14, 15, 15]
+    assert extra[0][2][:, 0, 0, 0].tolist() == [23, 23, 24, 24, 25, 25] and extra[0][3] is None
+    assert not big.calls[0][4]                                                                       # no timed batch in group 0
+    # group size from the launch size; flip-TTA doubles the frames of a batch; ground-truth modes and large batches are not coalesced
+    assert P.make_pipeline(None, None, 8, 8, 8, "cpu", launch_frames=16).group == 2
+    assert P.make_pipeline(None, None, 4, 8, 8, "cpu", launch_frames=16, do_flip=True).group == 2
+    for kw in (dict(launch_frames=0), dict(launch_frames=16, do_flip=True), dict(launch_frames=16, record_mode="generate_result")):
+        assert isinstance(P.make_pipeline(None, None, 8, 8, 8, "cpu", **kw), Recorder), kw
