@@ -384,9 +384,10 @@ constexpr int HS_PX = 32;
 
 // ((s0 + up(s1)) + up(s2)) for four consecutive channels of pixel (b, y, x): the value the reference's
 // `res4 + res3 + res2` (smap.py:417) has there.  A source at the output resolution is its own bilinear image.
-// Written with the source index k as a COMPILE-TIME constant (unrolled, `k < s.n` as a predicate): a run-time index into
-// the by-value argument struct makes the compiler re-read the kernel arguments with scalar loads inside the pixel loop and park
-// the Lerp array in LDS; neither belongs in a kernel whose results must not depend on what else is running (EXPERIMENTS R3.6).
+// Written with the source index k as a COMPILE-TIME constant (unrolled, `k < s.n` as a predicate).  The round-1/2 version looped
+// over k with a private `Lerp ly[3]`; the compiler promoted that array to LDS (indexed through the dispatch packet) and the kernel
+// returned ~15 wrong values in 10-30 % of the launches that overlapped another stream's kernels -- never alone (EXPERIMENTS
+// R3.6, tools/experiments/headsum_runtime_index_repro.hip).  No run-time-indexed private arrays in this library's kernels.
 template <int K>
 __device__ __forceinline__ float4 head_source4(const HeadSrc& s, const Lerp& ly, int b, int y, int x, int c, int Ho, int Wo, int Cs)
 {

@@ -686,10 +686,9 @@ def test_split_precision_dynamic_range(scale, stem_gain):
 @pytest.mark.parametrize("B,flip,precision", [(2, True, "x3"), (8, False, "x3"), (1, True, "f16")])
 def test_overlapping_executors_are_deterministic(B, flip, precision):
     """Two executors of one schedule on two streams, many launches queued back to back (what PosePipeline(depth=2) does at
-    512x832): every output must equal the serial result bit for bit.  Until round 3 the head-sum kernel indexed its by-value
-    argument struct at run time; the compiler turned that into scalar loads of the kernel arguments inside the pixel loop and an
-    LDS-resident private array addressed through the dispatch packet, and 10-30 % of OVERLAPPED forwards came back with ~15
-    wrong map values (never a serial one: every other test in this file is serial)."""
+    512x832): every output must equal the serial result bit for bit.  Until round 3 the head-sum kernel kept a run-time-indexed
+    private array; the compiler promoted it to LDS (a per-thread slot addressed through the dispatch packet) and 10-30 % of
+    OVERLAPPED forwards came back with ~15 wrong map values (never a serial one: every other test in this file is serial)."""
     from exps.stage3_root2.config import cfg
     from smap_amd.engine import BackboneEngine
     from smap_amd.model.smap import SMAP
