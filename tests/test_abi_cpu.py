@@ -74,3 +74,31 @@ def test_product_never_imports_oracle():
             if re.search(r"^\s*(from|import)\s+(oracle|benchkit)\b|oracle_lib|smap_oracle", open(f).read(), flags=re.M):
                 bad.append(f)
     assert not bad, bad
+
+
+def test_no_kernel_reads_the_dispatch_packet_or_uses_scratch(tmp_path):
+    """A rule this code base learned the hard way (EXPERIMENTS.md R3.6): a run-time-indexed private array in a kernel is promoted
+    to LDS by the compiler and addressed through the AQL dispatch packet -- the head sum written that way returned wrong values
+    in 10-30 % of the launches that overlapped another stream's kernels, and never in a serial test.  Checked on the compiled
+    code of EVERY kernel of the library (device-only assembly, hipcc cross-compiles without a GPU): no dispatch-packet
+    pointer, no scratch, no dynamic stack."""
+    import re
+    import subprocess
+    from smap_amd import build as B
+    procs = []
+    for src, extra in B.SOURCES:
+        out = tmp_path / (src + ".s")
+        cmd = [B._hipcc()] + [f for f in B.COMMON if f not in ("-fPIC",)] + extra + ["-S", "--cuda-device-only", os.path.join(B.CSRC, src), "-o", str(out)]
+        procs.append((src, out, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    n = 0
+    for src, out, p in procs:
+        _, err = p.communicate(timeout=1200)
+        assert p.returncode == 0, (src, err[-2000:])
+        txt = out.read_text()
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S):
+            name, body = m.group(1), m.group(2)
+            for field in ("amdhsa_user_sgpr_dispatch_ptr", "amdhsa_private_segment_fixed_size", "amdhsa_uses_dynamic_stack"):
+                v = re.search(r"\.%s (\d+)" % field, body)
+                assert v is not None and int(v.group(1)) == 0, (src, name, field, v and v.group(1))
+            n += 1
+    assert n >= 100          # conv.hip alone instantiates ~90 kernels
