@@ -14,6 +14,10 @@ weights): while batch k sits in its low-resolution, latency-bound layers (layer3
 workgroups per launch) batch k+1 streams its HBM-bound high-resolution layers on the idle CUs.
 `submit()` returns the records of the batch submitted `depth` calls earlier (None until then);
 `flush()` returns everything still in flight, in order.
+
+`make_pipeline` puts a `CoalescedPipeline` in front when the caller's batches are small: consecutive batches are run as ONE
+backbone launch of up to 16 frames (the 32x52 and 16x26 levels of the network have too few workgroups per launch at 8 frames
+to fill 256 CUs), same protocol, same records, same order.
 """
 import os
 
