@@ -276,6 +276,7 @@ class CoalescedPipeline:
         self._small = PosePipeline(model, cfg, batch, H, W, device, **kw)
         self._pending = []
         self._timed = False
+        self.remainder_records = 0                       # set by flush()
 
     # what callers read off a pipeline
     engine = property(lambda self: self.inner.engine)
