@@ -286,6 +286,29 @@ def pin_host_threads(local, world):
     return n
 
 
+def spawn_or_check_world(args):
+    """--gpus N is the contract, WORLD_SIZE is what a launcher set.  `python bench.py --gpus 8` without a launcher re-executes
+    itself under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1); a launcher whose world size
+    disagrees with --gpus is an error -- a line that says n_gpus: 1 for a --gpus 8 request would be worse than no line."""
+    world = os.environ.get("WORLD_SIZE")
+    if world is None and args.gpus > 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: --gpus %d without a launcher: re-executing as %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
+    if int(world or 1) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world or 1}: launch with --nproc-per-node {args.gpus} "
+                         f"(or drop the launcher: bench.py spawns its own ranks)")
+    if not args.dry_run and not os.environ.get("SMAP_BENCH_SHARE_GPU"):
+        import torch as _t
+        if _t.cuda.is_available() and _t.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {_t.cuda.device_count()} GPU(s) are visible")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,6 +341,7 @@ def main():
                     help="no GPU: the same control flow (pipeline protocol, end-of-run gather, MAX over ranks, one JSON line on "
                          "rank 0) with a stand-in pipeline and the gloo backend -- what the multi-rank CPU test runs")
     args = ap.parse_args()
+    spawn_or_check_world(args)
     if args.dry_run:
         return dry_run(args)
 
@@ -448,6 +472,33 @@ def main():
     post_us = {}
     for tag, p0, p1 in pipe.post_events:
         post_us.setdefault(tag, []).append(p0.elapsed_time(p1) * 1e3)
+    # ---- what the TIMED launches produced (pipelined, depth `--depth`, coalesced): the maps of the last timed launch are still
+    #      in its output buffers; association + lifting re-run on them outside the timed region give the per-frame data the
+    #      parity block compares with the CPU reference (and must reproduce the timed records bit for bit)
+    timed_frames = None
+    if want_ref:
+        maps = pipe.last_maps()
+        if maps is not None:
+            nfr = min(nref, maps[0].shape[0])
+            timed_frames = parity.frames_from_maps(maps[0][:nfr], maps[1][:nfr], maps[2][:nfr], cams[:nfr], refine=refine_w)
+    # ---- the same configuration with ONE backbone launch per step (--launch-frames 0), timed in the same process
+    fps_lf0 = None
+    small = getattr(pipe, "_small", None)
+    if world == 1 and small is not None and not os.environ.get("SMAP_BENCH_NO_LF0"):
+        def step0():
+            K = KS[step_no[0] % len(KS)]
+            step_no[0] += 1
+            small.submit(imgs, cams, tags, extra=[(f"synthK{K}", synth[K][0], synth[K][1], None)])
+        for _ in range(args.warmup):
+            step0()
+        small.flush()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step0()
+        small.flush()
+        torch.cuda.synchronize()
+        fps_lf0 = B * args.steps / (time.perf_counter() - t1)
     per_rank_host = [cpu_ms_per_step]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -456,6 +507,7 @@ def main():
         hc = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
         dist.all_gather(hc, torch.tensor([cpu_ms_per_step], dtype=torch.float64, device=cdev))
         per_rank_host = [float(h.item()) for h in hc]
+    rc = 0
     if rank == 0:
         frames = B * world * args.steps
         fps = frames / dt
@@ -509,6 +561,11 @@ def main():
                                       f"per step)" if pipe.frames_per_launch > B else "")
                                    + "; one end-of-run gather of the records",
                        "frames_per_launch": pipe.frames_per_launch,
+                       # the same steps with ONE backbone launch per step (no coalescing: a batch's records are not held
+                       # back for its group), timed in this process right after the headline region
+                       "value_launch_frames_0": fps_lf0 if fps_lf0 is not None else (fps if pipe.frames_per_launch == B * (2 if args.flip else 1) else None),
+                       "added_latency_steps_by_coalescing": (pipe.frames_per_launch // (B * (2 if args.flip else 1)) - 1),
+                       "ranks_in_gather": len(gathered) if gathered is not None else 1,
                        "association_lift_us_per_launch": {k: float(np.median(v)) for k, v in sorted(post_us.items())},
                        "host_ms_per_step": {"submit_wall": host["submit"] / args.steps * 1e3, "process_cpu_per_rank": per_rank_host,
                                             "threads": host_threads,
@@ -536,9 +593,28 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "frames/sec", "cores": cpu_ref.get("cores"), "kind": "port",
                                        "sample": "reference child failed: " + cpu_ref["error"]}
             else:
-                from benchkit import parity
-                m = parity.compare(hip_frames, cpu_ref["ref"])
-                out["config"]["e2e_parity"] = m
+                # e2e_parity: the TIMED path (maps of the last timed launch: pipelined, `--depth` backbones in flight, coalesced
+                # launches) vs the CPU reference on the same frames; e2e_parity_serial: one serial forward through the public API
+                ms = parity.compare(hip_frames, cpu_ref["ref"])
+                m = parity.compare(timed_frames, cpu_ref["ref"]) if timed_frames is not None else None
+                if m is not None:
+                    # ... and the timed RECORDS are these very frames' results (bit for bit): frame i of the batch <-> image_path r0/f{i}
+                    by_path = {}
+                    for r in collected:
+                        by_path.setdefault(r["image_path"], r)
+                    same = True
+                    for i, fr in enumerate(timed_frames):
+                        r = by_path.get(f"r{rank}/f{i}")
+                        if r is None:
+                            same = same and len(fr["p3"]) == 0
+                        else:
+                            same = same and (np.array_equal(np.asarray(r["pred_3d"]), fr["p3"]) and np.array_equal(np.asarray(r["pred_2d"]), fr["p2"])
+                                             and np.array_equal(np.asarray(r["root_d"]), fr["rz"]))
+                    m["timed_records_equal_these_frames"] = bool(same)
+                    m["path"] = (f"timed region: depth {args.depth}, {pipe.frames_per_launch} frames per launch, maps of the last timed launch")
+                out["config"]["e2e_parity"] = m if m is not None else ms
+                out["config"]["e2e_parity_serial"] = ms
+                m = out["config"]["e2e_parity"]
                 out["config"]["e2e_mpjpe_cm"], out["config"]["peak_match"] = m["mpjpe_cm"], m["peak_match"]
                 out["cpu_baseline"] = {
                     "value": 1.0 / cpu_ref["sec_per_frame"], "unit": "frames/sec", "cores": cpu_ref["cores"], "kind": "port",
@@ -549,8 +625,17 @@ def main():
                               f"{cpu_ref['threads']} threads) + oracle/smap_oracle.c association + lifting (1 thread, as the "
                               f"reference) per frame; association also frame-parallel over the cores"}
         print(json.dumps(out), flush=True)
+        if not identical:            # records of one frame differ between timed steps: the overlapped pipeline is not deterministic
+            print("bench.py: timed steps did not reproduce each other's records: " + json.dumps(out["config"]["timed_steps_reproduce"]),
+                  file=sys.stderr, flush=True)
+            rc = 3
     if world > 1:
+        rcs = torch.tensor([rc], dtype=torch.int32, device=cdev)
+        dist.all_reduce(rcs, op=dist.ReduceOp.MAX)
+        rc = int(rcs.item())
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

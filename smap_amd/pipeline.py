@@ -219,6 +219,16 @@ class PosePipeline:
                 out = r if out is None else out + r
         return out
 
+    def last_maps(self):
+        """(hms, det_d, root_d) of the most recent submit(), as its association read them (hms already /255,/127-scaled in
+        place): device tensors that stay valid until the next submit().  Call after flush().  bench.py compares what the TIMED
+        launches produced with the CPU reference through these."""
+        if self.k == 0:
+            return None
+        s = self.slots[(self.k - 1) % self.nslots]
+        assert not s.busy, "flush() first"
+        return s.hms, s.det_d, s.root_d
+
     # -- host side ---------------------------------------------------------------------------
     @staticmethod
     def _wait(ev, poll_s=2e-4):
@@ -286,6 +296,10 @@ class CoalescedPipeline:
     bb_events = property(lambda self: self.inner.bb_events)          # one entry per LAUNCH (group * batch frames)
     post_events = property(lambda self: self.inner.post_events)
     frames_per_launch = property(lambda self: self.inner.chunk)
+
+    def last_maps(self):
+        """Maps of the most recent COALESCED launch (group * batch frames, in submission order), or None if none ran."""
+        return self.inner.last_maps()
 
     @staticmethod
     def _merge(pending):

@@ -649,6 +649,23 @@ def test_full_size_forward_vs_cpu_oracle(precision, tol_max, tol_mean):
         assert ((a - b).abs().mean() / b.abs().mean()).item() < tol_mean, k
 
 
+def test_full_size_forward_vs_imported_reference_digest(golden_dir):
+    """The HIP split-precision path at BASELINE configs[1] against the IMPORTED reference model itself (not the restatement):
+    tests/golden/backbone_full.npz holds per-channel sums and 1024 sampled positions of each output of model.smap.SMAP at
+    1x3x512x832 (tests/golden/gen_golden_full.py); 1e-4 as for the oracle comparison above."""
+    from smap_amd.model.smap import SMAP
+    from test_oracle_cpu import check_against_full_size_digest, full_size_input
+    z = np.load(f"{golden_dir}/backbone_full.npz")
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((128, 208))).eval()
+    net.load_state_dict(recipe_state_dict(net.state_dict()))
+    net.precision = "x3"
+    x = full_size_input(z)
+    outs = [t.cpu() for t in net.to(DEV)(x.to(DEV))]
+    worst = check_against_full_size_digest(z, outs, 1e-4)
+    print("HIP x3 vs imported reference at full size (sampled, channel sums):", worst)
+
+
 @pytest.mark.parametrize("scale,stem_gain", [(1e-4, 1.0), (1.0, 1.0), (3e3, 1.0), (1e5, 1.0), (1.0, 1e-4), (1.0, 1e3), (1.0, 1e5)])
 def test_split_precision_dynamic_range(scale, stem_gain):
     """Split precision keeps fp16's RANGE: values around 1e-4 have subnormal lo parts, values beyond 65504 turn into inf.

@@ -270,6 +270,24 @@ def test_bench_control_flow_two_ranks_gloo():
     assert d["config"]["first_paths"] == ["r0/b2/f0", "r1/b2/f0"] and d["config"]["last_paths"] == ["r0/b6/f7", "r1/b6/f7"]
 
 
+def test_bench_gpus_flag_spawns_its_own_ranks_and_rejects_a_wrong_world():
+    """`python bench.py --gpus 2` WITHOUT a launcher re-executes itself under torch.distributed.run with two ranks (round 3
+    printed an n_gpus: 1 line for it); a launcher whose world size disagrees with --gpus is an error, not a silent line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_in_gather"] == 2 and d["config"]["records_per_rank"] == [24, 24]
+    # world 2 from the launcher, --gpus left at its default of 1: refuse
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29535", os.path.join(ROOT, "bench.py"),
+                        "--steps", "3", "--warmup", "1", "--dry-run"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_control_flow_eight_ranks_gloo():
     """The driver's 8-GPU launch line (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`) with --dry-run: all eight
     ranks reach the one end-of-run gather, rank order == frame order, every rank's host CPU per step is reported."""

@@ -285,6 +285,48 @@ def test_parity_compare_counts_what_it_says():
     assert lost["person_match"] == 0.5 and lost["peak_match"] == 1.0
 
 
+def test_lifter_ties_are_told_from_real_joint_errors():
+    """generate_relZ samples the depth maps at ROUNDED positions (test_util.py:66,74-79): a coordinate 1e-6 px from an index
+    step puts one sample on the neighbouring depth pixel -- a joint error of centimetres from a 1e-6 px input difference.
+    benchkit/parity.py must call that a lifter tie, and must NOT excuse the same error when the coordinates differ by more."""
+    from benchkit import parity
+    from oracle import oracle_lib as O
+    rng = np.random.default_rng(3)
+    H, W = 32, 48
+    det_d = rng.normal(0, 30, (14, H, W)).astype(np.float32)          # rough depth maps: a moved sample is visible
+    root_d = rng.uniform(0.5, 1.0, (H, W)).astype(np.float32)
+    cam = np.asarray([1.0, 4 * W, 4 * H, 4 * W, 4 * H, 1000.0, 1000.0, 2 * W, 2 * H], np.float64)
+    body = np.zeros((1, 15, 4), np.float32)
+    body[0, :, 0] = rng.uniform(8, W - 8, 15)
+    body[0, :, 1] = rng.uniform(8, H - 8, 15)
+    body[0, :, 3] = 1.0
+    body[0, 0, :2] = (20.25, 10.25)                                   # pelvis and neck well inside a depth pixel
+    body[0, 2, :2] = (24.25, 14.25)
+
+    def frame(bd):
+        p2, p3, rz = O.lift(bd, det_d, root_d, cam)
+        peaks = np.zeros((15, 128, 3), np.float32)
+        return dict(peaks=peaks, bodys=bd, p2=p2, p3=p3, rz=rz, det_d=det_d, root_d=root_d, hms=np.ones((43, H, W), np.float32))
+
+    # limb 8 = (2, 12): put joint 12 so that its x4 coordinate sits on the step between two depth pixels: round(x) = 4m - 0.5
+    step = np.float32((4 * 30 - 0.5) / 4)                             # x4 -> 119.5 exactly: np.round goes to 120 (even) = pixel 30
+    a, b = body.copy(), body.copy()
+    a[0, 12, 0] = step
+    b[0, 12, 0] = np.nextafter(step, np.float32(0))                   # one ulp below: rounds to 119 = pixel 29
+    assert parity.lift_sample_pixels(a[0])[2][8][0][-1, 1] != parity.lift_sample_pixels(b[0])[2][8][0][-1, 1]
+    m = parity.compare([frame(a)], [frame(b)])
+    assert m["person_match"] == 1.0 and m["limb_match"] == 1.0
+    assert m["max_joint_err_cm"] > 0.1, "the moved sample must matter in this scene"
+    assert m["joints_over_0.1cm_unexplained"] == 0 and m["lifter_ties"] >= 1, m
+    assert m["lifter_tie_max_coord_diff_px"] < 1e-5
+    # the same sample moved by a coordinate that differs by 0.2 px (still 'the same peak' for the 0.5 px pairing): not a tie
+    c = body.copy()
+    c[0, 12, 0] = step - np.float32(0.05)
+    m2 = parity.compare([frame(a)], [frame(c)])
+    assert m2["limb_match"] == 1.0 and m2["max_joint_err_cm"] > 0.1
+    assert m2["joints_over_0.1cm_unexplained"] >= 1 and m2["lifter_ties"] == 0, m2
+
+
 def test_peak_ties_are_told_from_real_mismatches():
     """A candidate that clears the threshold by 1e-7 of the map scale in one path and misses it in the other is a floating-
     point tie; one that differs by 1e-2 is a mismatch."""
