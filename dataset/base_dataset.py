@@ -83,11 +83,11 @@ class JointDataset(Dataset):
         return bodys, scale, size, (left, top)
 
     def __getitem__(self, index):
-        from smap_amd.preprocess import resize_bilinear_u8
+        from smap_amd.preprocess import resize_linear_u8
         d = self.data[index]
         bodys, scale, (nh, nw), (left, top) = self.annotate(d)
         img = CustomDataset._read_bgr(self.image_path(d))
-        r = resize_bilinear_u8(img, nh, nw)
+        r = resize_linear_u8(img, nh, nw, fx=scale, fy=scale)       # cv2.resize(img, (0, 0), fx=scale, fy=scale): ImageAugmentation.py:70
         canvas = np.full((self.crop_y, self.crop_x, 3), 128, np.uint8)
         # intersection of the resized image (placed at (left, top)) with the canvas
         x0, y0 = max(left, 0), max(top, 0)

@@ -180,9 +180,11 @@ typedef struct smap_op {
     int32_t w_pairs;                /* CONV, 32-half K tiles only: 1 = the weight blob stores them in pairs (see w_off), 0 = one
                                        contiguous block per K tile */
     int32_t status_off;             /* HEADSUM: byte offset (> 0) in the fp32 output buffer of an int32 STATUS word, or 0 = none.
-                                       smap_plan_run clears it, the head sum ORs in 1 when a value it writes is not finite:
-                                       split precision keeps fp16's RANGE, an activation beyond 65504 turns into inf / NaN
-                                       downstream; the host checks the word when it collects the maps. */
+                                       smap_plan_run clears it, the head sum ORs in bit 0 when a value it writes is not finite
+                                       and bit 1 + (b mod 31) for the output frame b the value belongs to (so a host can drop
+                                       the affected frames of a multi-frame launch and keep the others): split precision keeps
+                                       fp16's RANGE, an activation beyond 65504 turns into inf / NaN downstream; the host
+                                       checks the word when it collects the maps. */
     int32_t tail_cout;              /* CONV, tile ids 80..89 only (else 0): the op is a Bottleneck TAIL in one launch
                                        (smap.py:48-77) -- a 3x3 stride-1 conv Cin -> Cout (= the tile's N extent, bias + ReLU,
                                        never stored) followed by a 1x1 conv Cout -> tail_cout whose bias / res_off / relu /

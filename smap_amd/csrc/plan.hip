@@ -471,7 +471,8 @@ __global__ __launch_bounds__(256) void headsum_kernel(HeadSrc s, float* __restri
             if (c >= n_kpt) v = v * 0.5f;
         }
         out[(((size_t)b * C + c) * Ho + y) * Wo + x] = v;
-        if (status && !(fabsf(v) <= 3.4028234e38f)) atomicOr(status, 1);       // inf / NaN: an activation left the fp16 range upstream
+        // inf / NaN: an activation left the fp16 range upstream.  bit 0 = some frame, bit 1 + (b mod 31) = output frame b
+        if (status && !(fabsf(v) <= 3.4028234e38f)) atomicOr(status, 1 | (2 << (b % 31)));
     }
 }
 

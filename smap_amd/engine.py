@@ -828,6 +828,11 @@ class BackboneEngine:
         if tuple(imgs.shape) != (self.B, 3, self.H, self.W) or imgs.dtype != torch.float32 or not imgs.is_cuda:
             raise ValueError(f"imgs must be a float32 GPU tensor [{self.B},3,{self.H},{self.W}], got "
                              f"{tuple(imgs.shape)} {imgs.dtype} {imgs.device}")
+        if out is not None and (out.dtype != torch.float32 or out.device != imgs.device or not out.is_contiguous()
+                                or out.numel() < self.out_floats + 1):
+            # the maps are followed by the status word: a buffer of the pre-round-3 size would be written 4 bytes past its end
+            raise ValueError(f"out must be a contiguous float32 tensor of >= {self.out_floats + 1} elements on {imgs.device} "
+                             f"(BackboneEngine.new_output()), got {out.dtype} x {out.numel()} on {out.device}")
         imgs = imgs.contiguous()
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         count = self.n_ops - first if count is None else count

@@ -49,7 +49,8 @@ class _Slot:
                           rz=mk((B, MAXP), torch.float64), counts=mk((B,), torch.int32))
                      for _ in range(1 + n_extra)]
         self.status = engine.out_floats                                      # index of the engine's status word in `out`
-        self.status_host = torch.zeros((1,), dtype=torch.float32).pin_memory()  # its host copy (bit 0: non-finite maps)
+        # host copy of every launch's status word (bit 0: non-finite maps, bit 1 + f mod 31: frame f of the launch is affected)
+        self.status_host = torch.zeros((len(self.outs),), dtype=torch.float32).pin_memory()
         self.p2_f64 = None               # ground-truth modes: the f64 pred_2d (allocated on first use)
         self.ev_bb = torch.cuda.Event()
         self.ev_post = torch.cuda.Event()       # the host waits on this one: PosePipeline._wait
@@ -59,12 +60,16 @@ class _Slot:
 
 class PosePipeline:
     def __init__(self, model, cfg, batch, H, W, device, refine_weights=None, n_extra=0, do_flip=False, depth=1,
-                 record_mode="run_inference", numpy_records=False, max_frames_per_launch=None):
+                 record_mode="run_inference", numpy_records=False, max_frames_per_launch=None, strict_nonfinite=None):
         """record_mode: test.py's -t: "run_inference" (no ground truth), "generate_result" (one record per frame
         with the annotations attached) or "generate_train" (one record per matched person); the last two need
         `annotations=` in submit()."""
         assert record_mode in ("run_inference", "generate_result", "generate_train")
         self.record_mode = record_mode
+        # frames whose maps came out non-finite (fp16 range exceeded): dropped with a RuntimeWarning and listed in
+        # `dropped_frames` by default; strict_nonfinite=True (env SMAP_STRICT_NONFINITE=1) raises at collection instead
+        self.strict_nonfinite = bool(int(os.environ.get("SMAP_STRICT_NONFINITE", "0"))) if strict_nonfinite is None else bool(strict_nonfinite)
+        self.dropped_frames = []
         self.as_lists = not numpy_records      # numpy_records: records carry ndarray copies (records.to_jsonable at the end)
         self.device = torch.device(device)
         self.cfg = cfg
@@ -193,9 +198,8 @@ class PosePipeline:
                 self._post(*a, **k)
                 p1.record()
                 self.post_events.append((tag if isinstance(tag, str) else "+".join(sorted(set(tag))), p0, p1))
-            st_words = [o[slot.status:slot.status + 1].view(torch.int32) for o in slot.outs]
-            slot.status_host.copy_((st_words[0] if len(st_words) == 1 else torch.stack(st_words).max(0).values).view(torch.float32),
-                                   non_blocking=True)
+            for j, o in enumerate(slot.outs):
+                slot.status_host[j:j + 1].copy_(o[slot.status:slot.status + 1], non_blocking=True)
             timed_post("network", slot, 0, slot.hms, slot.det_d, slot.root_d, cams_d, scale=True, gt=gt)
             for j, (tag, hms, rd, dd) in enumerate(extra):
                 timed_post(tag, slot, 1 + j, hms, slot.det_d if dd is None else dd, rd, cams_d, scale=False)
@@ -241,11 +245,25 @@ class PosePipeline:
 
     def _collect(self, slot):
         self._wait(slot.ev_post)
-        if int(slot.status_host.view(torch.int32)[0]) & 1:
-            slot.busy = False
-            raise RuntimeError("SMAP backbone produced non-finite maps: an activation exceeded the fp16 range (65504) that the "
-                               "engine's arithmetic keeps (INTEGRATION.md section 5); these frames have no valid result")
         tags, extra_tags, annotations = slot.meta
+        words = slot.status_host.view(torch.int32).tolist()
+        if any(w & 1 for w in words):
+            # The reference's fp32 forward has no such failure; its loop would carry on with the other frames (the result file
+            # is only written at the end of the run, test.py:147-151).  So: the frames whose maps are not finite have no
+            # result and are dropped with a warning, the other frames of the launch keep theirs; strict mode raises instead.
+            c = self.engine.B                                                   # output frames per launch
+            bad = [j * c + f for j, w in enumerate(words) for f in range(c) if (w >> (1 + f % 31)) & 1]
+            names = [tags[i] for i in bad if tags[i] is not None]
+            if self.strict_nonfinite:
+                slot.busy = False
+                raise RuntimeError("SMAP backbone produced non-finite maps for %s: an activation exceeded the fp16 range (65504) "
+                                   "that the engine's arithmetic keeps (INTEGRATION.md section 5); these frames have no valid "
+                                   "result" % names)
+            import warnings
+            warnings.warn("SMAP backbone: non-finite maps (an activation exceeded the fp16 range, INTEGRATION.md section 5); "
+                          "no result for %s, the other frames of the launch are kept" % names, RuntimeWarning, stacklevel=2)
+            self.dropped_frames.extend(names)
+            tags = [None if i in set(bad) else t for i, t in enumerate(tags)]   # a None tag = no record (as for padding frames)
         recs = []
         for idx, h in enumerate(slot.host):
             counts = h["counts"].numpy()

@@ -71,11 +71,6 @@ def resize_linear_u8(img, nh, nw, fx=None, fy=None):
     return np.clip(t, 0, 255).astype(np.uint8)
 
 
-def resize_bilinear_u8(img, nh, nw):
-    """Earlier name (dsize-only call)."""
-    return resize_linear_u8(img, nh, nw)
-
-
 def preprocess_batch(images, means, stds, device, net_w=832, net_h=512):
     """images: list of uint8 HxWx3 BGR arrays/tensors.  Returns (imgs [B,3,net_h,net_w] fp32 on `device`,
     scales: dict of lists as the DataLoader would collate them)."""

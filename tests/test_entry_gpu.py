@@ -204,6 +204,45 @@ def test_two_stream_pipeline_equals_serial_path():
         assert by[f"again{i}/{name}"] == (p2, p3, rz), "again/" + name
 
 
+@pytest.mark.parametrize("flip,chunk", [(False, None), (True, None), (False, 2)])
+def test_one_overflowing_frame_does_not_condemn_its_launch(flip, chunk):
+    """A frame whose activations leave the fp16 range ends as NaN maps (status word).  The reference's fp32 loop would carry on
+    with the other frames; so does the pipeline: that frame has no record (RuntimeWarning, `dropped_frames`), the other frames
+    of the SAME launch keep theirs, bit for bit; strict_nonfinite=True raises instead."""
+    from model.smap import SMAP
+    from smap_amd.pipeline import PosePipeline
+    from exps.stage3_root2.config import cfg
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((16, 24))).eval()
+    sd = recipe_state_dict(net.state_dict())
+    for k in list(sd):
+        if k.endswith("up4.res_conv2.bn.bias"):
+            sd[k] = sd[k] + 60.0
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    B = 4
+    x = torch.randn(B, 3, 64, 96, generator=torch.Generator().manual_seed(3)).to(dev)
+    bad = x.clone()
+    bad[2] *= 1e5                                               # frame 2 overflows (test_split_precision_dynamic_range: scale 1e5)
+    cams = np.tile(np.array([0.5, 192, 128, 96, 64, 192, 192, 96, 64], np.float64), (B, 1))
+    tags = [f"f{j}" for j in range(B)]
+    key = lambda recs: [(r["image_path"], r["pred_2d"], r["pred_3d"], r["root_d"]) for r in recs]
+    pipe = PosePipeline(net, cfg, B, 64, 96, dev, depth=2, do_flip=flip, max_frames_per_launch=chunk)
+    pipe.submit(x, cams, tags)
+    clean = pipe.flush()
+    assert {r["image_path"] for r in clean} == set(tags) and not pipe.dropped_frames
+    pipe.submit(bad, cams, tags)
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        got = pipe.flush()
+    assert pipe.dropped_frames == ["f2"]
+    assert key(got) == key([r for r in clean if r["image_path"] != "f2"])
+    strict = PosePipeline(net, cfg, B, 64, 96, dev, depth=1, do_flip=flip, max_frames_per_launch=chunk, strict_nonfinite=True)
+    strict.submit(bad, cams, tags)
+    with pytest.raises(RuntimeError, match="f2"):
+        strict.flush()
+
+
 def test_device_preprocess_equals_host_dataset(tmp_path):
     """smap_preprocess (HIP) == dataset/custom_dataset.py (host: OpenCV's fixed-point INTER_LINEAR restated in numpy, pad 128,
     normalise), bit for bit, for wide / tall / exact / tiny / odd-sized images and an exact 2x shrink (box-mean path)."""
@@ -244,9 +283,9 @@ def _annotated_set(tmp_path, net, dev, sizes, seed):
         h, w = e["img_height"], e["img_width"]
         scale, (nh, nw), (left, top) = croppad_geometry(w, h, 832, 512)
         img = np.load(root / e["img_paths"])
-        from smap_amd.preprocess import resize_bilinear_u8
+        from smap_amd.preprocess import resize_linear_u8
         canvas = np.full((512, 832, 3), 128, np.uint8)
-        r = resize_bilinear_u8(img, nh, nw)
+        r = resize_linear_u8(img, nh, nw, fx=scale, fy=scale)
         x0, y0, x1, y1 = max(left, 0), max(top, 0), min(left + nw, 832), min(top + nh, 512)
         canvas[y0:y1, x0:x1] = r[y0 - top:y1 - top, x0 - left:x1 - left]
         t = torch.from_numpy(canvas).permute(2, 0, 1).float().div(255.0)
