@@ -446,10 +446,12 @@ def main():
     torch.cuda.synchronize()
     cpu0 = time.process_time()
     thr0 = thread_cpu_seconds()
+    wait0 = pipe.wait_s
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     t_loop = time.perf_counter() - t0
+    wait_loop = pipe.wait_s - wait0
     tail = pipe.flush()                       # the K-th batch is complete inside the timed region
     if tail:
         collected.extend(tail)
@@ -567,7 +569,11 @@ def main():
                        "added_latency_steps_by_coalescing": (pipe.frames_per_launch // (B * (2 if args.flip else 1)) - 1),
                        "ranks_in_gather": len(gathered) if gathered is not None else 1,
                        "association_lift_us_per_launch": {k: float(np.median(v)) for k, v in sorted(post_us.items())},
-                       "host_ms_per_step": {"submit_wall": host["submit"] / args.steps * 1e3, "process_cpu_per_rank": per_rank_host,
+                       # submit_wall = enqueue (the host's own work: launches, H2D of the cameras, record building) + backpressure_wait
+                       # (asleep until the GPU has finished the batch submitted `depth` steps earlier: a closed loop must wait somewhere)
+                       "host_ms_per_step": {"submit_wall": host["submit"] / args.steps * 1e3,
+                                            "enqueue_and_records": (host["submit"] - wait_loop) / args.steps * 1e3,
+                                            "backpressure_wait": wait_loop / args.steps * 1e3, "process_cpu_per_rank": per_rank_host,
                                             "threads": host_threads,
                                             "busiest_threads_cpu_ms": [[n, round(v, 2)] for n, v in busiest]},
                        "host_submit_ms_quantiles": [float(np.percentile(host["steps"], q)) for q in (0, 10, 50, 90, 100)],

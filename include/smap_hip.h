@@ -208,9 +208,11 @@ int smap_conv_tile_tail_bn(int tile);
 
 typedef struct smap_plan smap_plan;
 
-/* Copies `ops`; validates geometry.  n_ops <= 4096.  Arena contract: bytes [0,16384) are reserved
- * (smap_plan_run zeroes them: padding taps of the conv kernels read there), every tensor offset is
- * >= 16384, and conv inputs must end below 4 GiB (32-bit offsets from the arena base). */
+/* Copies `ops`; validates geometry.  n_ops <= 4096.  Arena contract: the conv kernels address their input with a 64-bit
+ * base (the input's WINDOW: its arena offset rounded down to a multiple of 4 GiB) plus 32-bit lane offsets, and read zeros
+ * for padding taps at the start of that window.  So bytes [k * 2^32, k * 2^32 + 16384) are RESERVED for every k >= 0
+ * (smap_plan_run zeroes the ones its launches use), no tensor overlaps them (hence no tensor crosses a 4 GiB boundary and
+ * none exceeds 4 GiB - 16 KiB), and the arena may be of any size. */
 int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan);
 void smap_plan_destroy(smap_plan* plan);
 /* Runs the whole schedule on `stream`.
@@ -219,6 +221,43 @@ void smap_plan_destroy(smap_plan* plan);
  *         offsets recorded in the HEADSUM ops, plus the int32 status word at status_off when the ops name one). */
 int smap_plan_run(const smap_plan* plan, const float* input, void* arena, const void* weights,
                   float* out, void* stream);
+/* The same with the images in n_inputs (1..SMAP_MAX_INPUTS, a divisor of B) separate buffers of B / n_inputs frames each,
+ * in order: `inputs` is a HOST array of device pointers.  A launch that serves several of the caller's batches reads them
+ * where they are (the stem indexes the buffers) instead of gathering them first (test.py:43-50 hands one batch at a time). */
+#define SMAP_MAX_INPUTS 8
+int smap_plan_run_inputs(const smap_plan* plan, const float* const* inputs, int n_inputs, void* arena,
+                         const void* weights, float* out, void* stream);
+/* Bytes of arena and of output buffer the schedule touches, computed from the ops (either pointer may be NULL). */
+int smap_workspace_bytes(const smap_plan* plan, int64_t* arena_bytes, int64_t* out_bytes);
+
+/* ---- plan blob: the whole schedule as ONE relocatable byte image, so that a host that cannot run the Python schedule builder
+ * (smap_amd/engine.py describes model/smap.py:313-353 as ops and packs the weights) can still run SMAP.forward from this header
+ * alone: read the file, smap_plan_create_from_blob, hipMalloc info.arena_bytes / info.out_bytes, upload the blob's weight
+ * section [weights_offset, +weights_bytes) to the device, smap_plan_run.  Little-endian, written by
+ * smap_amd/engine.py::BackboneEngine.blob():
+ *   smap_blob_header | smap_op[n_ops] at ops_offset | weight section at weights_offset (256-byte aligned) */
+typedef struct smap_blob_info {
+    int32_t frames, H, W;               /* input: [frames,3,H,W] fp32 NCHW                                      */
+    int32_t out_h, out_w;               /* map size                                                              */
+    int32_t n_hms, n_det, n_root;       /* channels of the three outputs (43, 14, 1)                             */
+    int32_t precision;                  /* 0 = fp16 storage, 1 = split precision                                 */
+    int32_t reserved;
+    int64_t arena_bytes, out_bytes;     /* buffers to allocate (out_bytes includes the status word)              */
+    int64_t weights_offset, weights_bytes;   /* the weight section inside the blob                               */
+    int64_t hms_off, det_off, root_off, status_off;   /* byte offsets of [frames,C,out_h,out_w] fp32 maps / the int32 status word in `out` */
+} smap_blob_info;
+typedef struct smap_blob_header {
+    char magic[8];                      /* "SMAPPLN1"                                                            */
+    uint32_t version, sizeof_op, header_bytes;
+    int32_t n_ops;
+    int64_t ops_offset;
+    int64_t weights_offset, weights_bytes, arena_bytes, out_bytes;     /* = info's, kept flat for readers without the struct */
+    smap_blob_info info;
+} smap_blob_header;
+/* blob: HOST memory.  Validates header, op size, every op (as smap_plan_create) and that the ops stay inside the arena /
+ * output sizes the header states.  info may be NULL. */
+int smap_plan_create_from_blob(const void* blob, size_t blob_bytes, smap_plan** plan, smap_blob_info* info);
+
 /* Runs ops [first, first+count) only (tests, per-layer profiling). */
 int smap_plan_run_range(const smap_plan* plan, int first, int count, const float* input,
                         void* arena, const void* weights, float* out, void* stream);

@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <new>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <type_traits>
 #include "smap_hip.h"
@@ -36,10 +37,25 @@ constexpr int ST_K = 176;                                      // 22 granules x 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
+// The images of a schedule may come as up to SMAP_MAX_INPUTS separate [frames_per,3,H,W] buffers (smap_plan_run_inputs: a
+// launch that coalesces several of the caller's batches reads them where they are -- no gather copy in front of the stem).
+struct StemIn {
+    const float* p[SMAP_MAX_INPUTS];
+    int frames_per;                     // frames per buffer; frame b lives in p[b / frames_per] at index b % frames_per
+};
+__device__ __forceinline__ const float* stem_frame(const StemIn& in, int b, int H, int W)
+{
+    const int k = b / in.frames_per;
+    const float* base = in.p[0];        // compile-time indices only: a run-time index into a by-value kernel argument would
+#pragma unroll                          // be promoted to scratch / LDS (EXPERIMENTS R3.6)
+    for (int j = 1; j < SMAP_MAX_INPUTS; ++j) base = k == j ? in.p[j] : base;
+    return base + (size_t)(b - k * in.frames_per) * 3 * H * W;
+}
+
 // X3 (smap_op.precision = 1): image and weights as fp16 hi/lo pairs, three MFMAs per K step, output pixel = [hi(64) | lo(64)]
 // (see conv.hip).  The weight blob then holds [64][176] hi followed by [64][176] lo of (w * 2^s); acc_scale = 2^-s.
 template <bool X3>
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const _Float16* __restrict__ wk,
+__global__ __launch_bounds__(256) void stem_kernel(const StemIn in, const _Float16* __restrict__ wk,
                                                    const float* __restrict__ bias, _Float16* __restrict__ out,
                                                    int H, int W, int Ho, int Wo, float acc_scale, int flip_from)
 {
@@ -54,13 +70,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
     // flip-TTA: frames >= flip_from are the x-mirrored images of frames 0.. (the mirror lives in this index, not in memory)
     const bool mirror = flip_from > 0 && b >= flip_from;
     const int bsrc = mirror ? b - flip_from : b;
+    const float* __restrict__ img = stem_frame(in, bsrc, H, W);
     for (int i = tid; i < 3 * ST_PH * ST_PW; i += 256) {
         const int c = i / (ST_PH * ST_PW), r = i - c * ST_PH * ST_PW;
         const int py = r / ST_PW, px = r - py * ST_PW;
         const int iy = iy0 + py, ix = ix0 + px;
         float v = 0.f;
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            v = img[(((size_t)bsrc * 3 + c) * H + iy) * W + (mirror ? W - 1 - ix : ix)];
+            v = img[((size_t)c * H + iy) * W + (mirror ? W - 1 - ix : ix)];
         const _Float16 hi = (_Float16)v;
         s_p[i] = hi;
         if (X3) s_p[3 * ST_PH * ST_PW + i] = (_Float16)(v - (float)hi);
@@ -153,7 +170,7 @@ static_assert(SP_SY * SP_SX <= 256 && (SP_SX - 1) * 2 + 8 <= SP_PW, "stem+pool t
 // X3 / flip_from: as in stem_kernel (hi/lo planes, three MFMAs per K step, mirrored read of frames >= flip_from); the conv
 // tile then stays in LDS as fp32 (the maximum is taken over the exact value, then re-split).
 template <bool X3>
-__global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict__ img, const _Float16* __restrict__ wk,
+__global__ __launch_bounds__(256) void stem_pool_kernel(const StemIn in, const _Float16* __restrict__ wk,
                                                         const float* __restrict__ bias, _Float16* __restrict__ out,
                                                         int H, int W, int Hs, int Ws, int Ho, int Wo, float acc_scale, int flip_from)
 {
@@ -170,13 +187,14 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
     const int iy0 = sy0 * 2 - 3, ix0 = sx0 * 2 - 3;
     const bool mirror = flip_from > 0 && b >= flip_from;
     const int bsrc = mirror ? b - flip_from : b;
+    const float* __restrict__ img = stem_frame(in, bsrc, H, W);
     for (int i = tid; i < 3 * SP_PH * SP_PW; i += 256) {
         const int c = i / (SP_PH * SP_PW), r = i - c * SP_PH * SP_PW;
         const int py = r / SP_PW, px = r - py * SP_PW;
         const int iy = iy0 + py, ix = ix0 + px;
         float v = 0.f;
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            v = img[(((size_t)bsrc * 3 + c) * H + iy) * W + (mirror ? W - 1 - ix : ix)];
+            v = img[((size_t)c * H + iy) * W + (mirror ? W - 1 - ix : ix)];
         const _Float16 hi = (_Float16)v;
         s_p[i] = hi;
         if (X3) s_p[3 * SP_PH * SP_PW + i] = (_Float16)(v - (float)hi);
@@ -486,12 +504,27 @@ inline int grid_for(long long total, int block)
 
 struct smap_plan {
     std::vector<smap_op> ops;
+    std::vector<int64_t> windows;          // arena offsets of the zero pages this schedule's conv launches address through
 };
 
-// The first SMAP_ZERO_PAGE bytes of the arena are the conv kernels' "zero page": padding taps and
-// rows past M fetch their 16 bytes there.  smap_plan_run clears it on the stream before the first op.
+// ZERO PAGES and WINDOWS.  The conv kernels address their input with (64-bit uniform base in SGPRs) + (32-bit byte offset per
+// lane); offset 0..SMAP_ZERO_PAGE of that base must read as zeros (padding taps and rows past M fetch their 16 bytes there).
+// The base of a launch is the WINDOW of its input: the arena offset in_off rounded down to a multiple of SMAP_WINDOW (4 GiB); as
+// no tensor crosses a window boundary, an input tensor anywhere in an arena of any size is within 32 bits of its base.  Arena contract: bytes
+// [k * SMAP_WINDOW, k * SMAP_WINDOW + SMAP_ZERO_PAGE) are reserved for every k >= 0 (no tensor overlaps them); smap_plan_run
+// clears the ones its launches use on the stream before the first op.
 constexpr int64_t SMAP_ZERO_PAGE = 16384;  // >= max Cin * 2 bytes + 16 (+ the lo-plane offset, <= 4096, in split precision):
                                            // a padding tap reads zero page + chunk*128 (+ lo offset)
+constexpr int64_t SMAP_WINDOW = (int64_t)1 << 32;
+inline int64_t window_of(int64_t off) { return off & ~(SMAP_WINDOW - 1); }
+// does [off, off + bytes) touch a reserved zero page?
+inline bool hits_zero_page(int64_t off, int64_t bytes)
+{
+    if (off < 0 || bytes <= 0) return false;
+    const int64_t k0 = off / SMAP_WINDOW, k1 = (off + bytes - 1) / SMAP_WINDOW;
+    if (off < k0 * SMAP_WINDOW + SMAP_ZERO_PAGE) return true;
+    return k1 > k0;                        // crosses the start of the next window = its zero page
+}
 
 static int validate(const smap_op& o)
 {
@@ -533,8 +566,18 @@ static int validate(const smap_op& o)
             if ((o.res_off >= 0 || o.add1_off >= 0 || o.add2_off >= 0 || o.aux_off[0] >= 0) && o.Cout % 8) return SMAP_E_ARG;
             if (o.aux_off[0] >= 0 && (o.aux_h[0] <= 0 || o.aux_w[0] <= 0)) return SMAP_E_ARG;
             if (o.in_off < SMAP_ZERO_PAGE || o.out_off < SMAP_ZERO_PAGE || o.w_off < 0 || o.bias_off < 0) return SMAP_E_ARG;
-            // conv A-operand addresses are 32-bit byte offsets from the arena base
-            if (o.in_off + (int64_t)o.B * o.H * o.W * o.in_stride_c * 2 > ((int64_t)1 << 32)) return SMAP_E_ARG;
+            {   // conv A-operand addresses are 32-bit byte offsets from the input's window base; no tensor of the op may lie on a
+                // reserved zero page
+                const int64_t in_bytes = (int64_t)o.B * o.H * o.W * o.in_stride_c * 2;
+                const int64_t M = (int64_t)o.B * o.Ho * o.Wo;
+                const int64_t out_bytes = M * o.out_stride_c * (o.out_fp32 ? 4 : 2);
+                const int64_t dense = M * ((o.tail_cout > 0 ? o.tail_cout : ((o.Cout + 7) & ~7))) * 2 * (1 + o.precision);
+                if (o.in_off - window_of(o.in_off) + in_bytes > ((int64_t)1 << 32)) return SMAP_E_ARG;
+                const int64_t up_bytes = o.aux_off[0] >= 0 ? (int64_t)o.B * o.aux_h[0] * o.aux_w[0] * ((o.Cout + 7) & ~7) * 2 * (1 + o.precision) : 0;
+                if (hits_zero_page(o.in_off, in_bytes) || hits_zero_page(o.out_off, out_bytes) || hits_zero_page(o.res_off, dense) ||
+                    hits_zero_page(o.add1_off, dense) || hits_zero_page(o.add2_off, dense) || hits_zero_page(o.aux_off[0], up_bytes))
+                    return SMAP_E_ARG;
+            }
             if ((int64_t)o.cout_pad * o.ksize * o.ksize * o.Cin * 2 * (1 + o.precision) > ((int64_t)1 << 32)) return SMAP_E_ARG;
             // epilogues address outputs / residuals / addends / the low-res tensor with 32-bit ELEMENT offsets from their bases
             if ((int64_t)o.B * o.Ho * o.Wo * o.out_stride_c >= ((int64_t)1 << 31)) return SMAP_E_ARG;
@@ -595,6 +638,14 @@ int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan)
     smap_plan* p = new (std::nothrow) smap_plan();
     if (!p) return SMAP_E_ARG;
     p->ops.assign(ops, ops + n_ops);
+    p->windows.push_back(0);
+    for (int i = 0; i < n_ops; ++i)
+        if (ops[i].kind == SMAP_OP_CONV) {
+            const int64_t w = window_of(ops[i].in_off);
+            bool have = false;
+            for (int64_t x : p->windows) have = have || x == w;
+            if (!have) p->windows.push_back(w);
+        }
     *plan = p;
     return 0;
 }
@@ -605,16 +656,22 @@ void smap_plan_destroy(smap_plan* plan)
     delete plan;
 }
 
-int smap_plan_run_range(const smap_plan* plan, int first, int count, const float* input, void* arena,
-                        const void* weights, float* out, void* stream)
+static int run_ops(const smap_plan* plan, int first, int count, const float* const* inputs, int n_inputs, void* arena,
+                   const void* weights, float* out, void* stream)
 {
     if (!plan || !arena || !weights || first < 0 || count < 0 || first + count > (int)plan->ops.size())
         return SMAP_E_ARG;
+    if (n_inputs < 0 || n_inputs > SMAP_MAX_INPUTS || (n_inputs > 0 && !inputs)) return SMAP_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     char* ar = static_cast<char*>(arena);
     const char* wb = static_cast<const char*>(weights);
     auto A = [&](int64_t off) -> _Float16* { return off < 0 ? nullptr : reinterpret_cast<_Float16*>(ar + off); };
-    if (hipError_t e = hipMemsetAsync(ar, 0, SMAP_ZERO_PAGE, st); e != hipSuccess) return hip_rc(e);
+    StemIn sin;
+    for (int j = 0; j < SMAP_MAX_INPUTS; ++j) sin.p[j] = j < n_inputs ? inputs[j] : nullptr;
+    sin.frames_per = 1;
+    const bool have_input = n_inputs > 0 && inputs[0];
+    for (int64_t w : plan->windows)
+        if (hipError_t e = hipMemsetAsync(ar + w, 0, SMAP_ZERO_PAGE, st); e != hipSuccess) return hip_rc(e);
     for (int i = first; i < first + count; ++i)          // the status word (one per schedule) starts every run at 0
         if (plan->ops[i].kind == SMAP_OP_HEADSUM && plan->ops[i].status_off > 0 && out) {
             if (hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(out) + plan->ops[i].status_off, 0, 4, st); e != hipSuccess) return hip_rc(e);
@@ -626,8 +683,8 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
         switch (o.kind) {
             case SMAP_OP_CONV: {
                 ConvArgs a;
-                a.arena = ar;
-                a.in_off = o.in_off;
+                a.arena = ar + window_of(o.in_off);          // 64-bit base of the launch; lane offsets are 32-bit from here
+                a.in_off = o.in_off - window_of(o.in_off);
                 a.w = reinterpret_cast<const _Float16*>(wb + o.w_off);
                 a.bias = reinterpret_cast<const float*>(wb + o.bias_off);
                 a.out = ar + o.out_off;
@@ -672,15 +729,18 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                 break;
             }
             case SMAP_OP_STEM: {
-                if (!input) return SMAP_E_ARG;
+                const int frames = o.flip_from > 0 ? o.flip_from : o.B;       // frames the input holds
+                if (!have_input || frames % n_inputs) return SMAP_E_ARG;
+                for (int j = 0; j < n_inputs; ++j) if (!inputs[j]) return SMAP_E_ARG;
+                sin.frames_per = frames / n_inputs;
                 dim3 grid((o.Wo + ST_T - 1) / ST_T, (o.Ho + ST_T - 1) / ST_T, o.B);
                 if (o.precision)
-                    hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, st, input,
+                    hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, st, sin,
                                        reinterpret_cast<const _Float16*>(wb + o.w_off),
                                        reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, o.Ho,
                                        o.Wo, o.acc_scale, o.flip_from);
                 else
-                    hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, st, input,
+                    hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, st, sin,
                                        reinterpret_cast<const _Float16*>(wb + o.w_off),
                                        reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, o.Ho,
                                        o.Wo, 1.f, o.flip_from);
@@ -688,16 +748,19 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
                 break;
             }
             case SMAP_OP_STEMPOOL: {
-                if (!input) return SMAP_E_ARG;
+                const int frames = o.flip_from > 0 ? o.flip_from : o.B;
+                if (!have_input || frames % n_inputs) return SMAP_E_ARG;
+                for (int j = 0; j < n_inputs; ++j) if (!inputs[j]) return SMAP_E_ARG;
+                sin.frames_per = frames / n_inputs;
                 const int hs = (o.H + 6 - 7) / 2 + 1, ws = (o.W + 6 - 7) / 2 + 1;
                 dim3 grid((o.Wo + SP_PX - 1) / SP_PX, (o.Ho + SP_PY - 1) / SP_PY, o.B);
                 if (o.precision)
-                    hipLaunchKernelGGL(stem_pool_kernel<true>, grid, dim3(256), 0, st, input,
+                    hipLaunchKernelGGL(stem_pool_kernel<true>, grid, dim3(256), 0, st, sin,
                                        reinterpret_cast<const _Float16*>(wb + o.w_off),
                                        reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, hs, ws,
                                        o.Ho, o.Wo, o.acc_scale, o.flip_from);
                 else
-                    hipLaunchKernelGGL(stem_pool_kernel<false>, grid, dim3(256), 0, st, input,
+                    hipLaunchKernelGGL(stem_pool_kernel<false>, grid, dim3(256), 0, st, sin,
                                        reinterpret_cast<const _Float16*>(wb + o.w_off),
                                        reinterpret_cast<const float*>(wb + o.bias_off), A(o.out_off), o.H, o.W, hs, ws,
                                        o.Ho, o.Wo, 1.f, o.flip_from);
@@ -752,11 +815,90 @@ int smap_plan_run_range(const smap_plan* plan, int first, int count, const float
     return 0;
 }
 
+// arena / output bytes the schedule touches, from the ops alone (a host that did not build the schedule sizes its buffers with it)
+int smap_workspace_bytes(const smap_plan* plan, int64_t* arena_bytes, int64_t* out_bytes)
+{
+    if (!plan) return SMAP_E_ARG;
+    int64_t ar = SMAP_ZERO_PAGE, ob = 0;
+    auto up = [](int64_t& m, int64_t off, int64_t bytes) { if (off >= 0 && off + bytes > m) m = off + bytes; };
+    for (const smap_op& o : plan->ops) {
+        const int64_t M = (int64_t)o.B * o.Ho * o.Wo, pl = 1 + o.precision;
+        switch (o.kind) {
+            case SMAP_OP_CONV: {
+                const int64_t c8 = o.tail_cout > 0 ? o.tail_cout : ((o.Cout + 7) & ~7);
+                up(ar, o.in_off, (int64_t)o.B * o.H * o.W * o.in_stride_c * 2);
+                up(ar, o.out_off, M * o.out_stride_c * (o.out_fp32 ? 4 : 2));
+                up(ar, o.res_off, M * c8 * 2 * pl); up(ar, o.add1_off, M * c8 * 2 * pl); up(ar, o.add2_off, M * c8 * 2 * pl);
+                up(ar, o.aux_off[0], (int64_t)o.B * o.aux_h[0] * o.aux_w[0] * c8 * 2 * pl);
+                break;
+            }
+            case SMAP_OP_STEM: case SMAP_OP_STEMPOOL: up(ar, o.out_off, M * 64 * 2 * pl); break;
+            case SMAP_OP_MAXPOOL:
+                up(ar, o.in_off, (int64_t)o.B * o.H * o.W * o.Cin * 2 * pl); up(ar, o.out_off, M * o.Cout * 2 * pl); break;
+            case SMAP_OP_UPADD:
+                up(ar, o.in_off, M * o.Cout * 2); up(ar, o.out_off, M * o.Cout * 2);
+                up(ar, o.aux_off[0], (int64_t)o.B * o.aux_h[0] * o.aux_w[0] * o.Cout * 2); break;
+            case SMAP_OP_HEADSUM: {
+                const int64_t frames = o.flip_from > 0 ? 2 * (int64_t)o.B : o.B;        // the sources hold the mirrored half too
+                for (int k = 0; k < o.n_aux; ++k) up(ar, o.aux_off[k], frames * o.aux_h[k] * o.aux_w[k] * o.Cin * 4);
+                up(ob, o.ext_off, M * o.Cout * 4);
+                if (o.status_off > 0) up(ob, o.status_off, 4);
+                break;
+            }
+            default: break;
+        }
+    }
+    if (arena_bytes) *arena_bytes = ar;
+    if (out_bytes) *out_bytes = ob;
+    return 0;
+}
+
+// ---- serialised plans: include/smap_hip.h "plan blob"
+int smap_plan_create_from_blob(const void* blob, size_t blob_bytes, smap_plan** plan, smap_blob_info* info)
+{
+    if (!blob || !plan || blob_bytes < sizeof(smap_blob_header)) return SMAP_E_ARG;
+    smap_blob_header h;
+    memcpy(&h, blob, sizeof(h));
+    if (memcmp(h.magic, "SMAPPLN1", 8) || h.version != 1 || h.sizeof_op != sizeof(smap_op) || h.header_bytes != sizeof(smap_blob_header))
+        return SMAP_E_ARG;
+    if (h.n_ops <= 0 || h.n_ops > 4096 || h.ops_offset < (int64_t)sizeof(h) || h.weights_offset < 0 || h.weights_bytes < 0) return SMAP_E_ARG;
+    if (h.ops_offset + (int64_t)h.n_ops * (int64_t)sizeof(smap_op) > (int64_t)blob_bytes || h.weights_offset + h.weights_bytes > (int64_t)blob_bytes)
+        return SMAP_E_ARG;
+    std::vector<smap_op> ops(h.n_ops);
+    memcpy(ops.data(), static_cast<const char*>(blob) + h.ops_offset, (size_t)h.n_ops * sizeof(smap_op));
+    for (const smap_op& o : ops) {      // the blob's weight section must hold what the ops point at
+        if ((o.kind == SMAP_OP_CONV || o.kind == SMAP_OP_STEM || o.kind == SMAP_OP_STEMPOOL) &&
+            (o.w_off < 0 || o.w_off >= h.weights_bytes || o.bias_off < 0 || o.bias_off >= h.weights_bytes))
+            return SMAP_E_ARG;
+    }
+    smap_plan* p = nullptr;
+    if (int rc = smap_plan_create(ops.data(), h.n_ops, &p)) return rc;
+    int64_t ar = 0, ob = 0;
+    smap_workspace_bytes(p, &ar, &ob);
+    if (ar > h.arena_bytes || ob > h.out_bytes) { smap_plan_destroy(p); return SMAP_E_ARG; }     // header and ops disagree
+    if (info) *info = h.info;
+    *plan = p;
+    return 0;
+}
+
+int smap_plan_run_range(const smap_plan* plan, int first, int count, const float* input, void* arena,
+                        const void* weights, float* out, void* stream)
+{
+    return run_ops(plan, first, count, &input, input ? 1 : 0, arena, weights, out, stream);
+}
+
 int smap_plan_run(const smap_plan* plan, const float* input, void* arena, const void* weights, float* out,
                   void* stream)
 {
     if (!plan) return SMAP_E_ARG;
-    return smap_plan_run_range(plan, 0, (int)plan->ops.size(), input, arena, weights, out, stream);
+    return run_ops(plan, 0, (int)plan->ops.size(), &input, input ? 1 : 0, arena, weights, out, stream);
+}
+
+int smap_plan_run_inputs(const smap_plan* plan, const float* const* inputs, int n_inputs, void* arena, const void* weights,
+                         float* out, void* stream)
+{
+    if (!plan || n_inputs < 1) return SMAP_E_ARG;
+    return run_ops(plan, 0, (int)plan->ops.size(), inputs, n_inputs, arena, weights, out, stream);
 }
 
 }  // extern "C"

@@ -69,6 +69,7 @@ LAYERS = (3, 4, 6, 3)            # smap.py:299  resnet-50
 PLANES = (64, 128, 256, 512)
 ALIGN = 256
 ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
+WINDOW = 1 << 32              # csrc/plan.hip SMAP_WINDOW: bytes [k * WINDOW, k * WINDOW + ZERO_PAGE) of the arena are reserved
 PRECISIONS = ("f16", "x3")
 X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 56, 57, 60, 61, 62, 63, 64, 65, 66, 68, 69, 70)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
 
@@ -348,8 +349,9 @@ DEFAULT_REMAP = {}
 
 
 class ArenaTooLarge(ValueError):
-    """The schedule's conv inputs would end above 4 GiB (the conv kernels address activations with 32-bit byte offsets
-    from the arena base, csrc/plan.hip::validate): run the frames in smaller batches."""
+    """One activation tensor of the schedule exceeds a 4 GiB window (the conv kernels address their input with 32-bit byte
+    offsets from a 4 GiB-aligned base, csrc/plan.hip): run the frames in smaller batches.  (Until round 3 the whole ARENA had
+    to stay below 4 GiB; now only a single tensor has a limit -- 4 GiB is 52 frames of the widest split-precision tensor.)"""
 
 
 class Graph:
@@ -629,7 +631,13 @@ class Graph:
             if op.out is not None:
                 op.out.first = i
                 op.out.last = max(op.out.last, i)
-        free, top = [], ZERO_PAGE    # free: list of (off, size); arena[0:8192] is the conv kernels' zero page
+        # arena[k * WINDOW : k * WINDOW + ZERO_PAGE] are the conv kernels' zero pages (csrc/plan.hip): never allocated, so no
+        # tensor crosses a window boundary and every conv input is within 32 bits of its window's base
+        free, top = [], ZERO_PAGE    # free: list of (off, size)
+        for t in self.tensors:
+            if _rup(t.nbytes, ALIGN) > WINDOW - ZERO_PAGE:
+                raise ArenaTooLarge(f"{t.name}: {t.nbytes / 2 ** 30:.2f} GiB ({self.B} frames, precision {self.precision}) does not fit a "
+                                    "4 GiB addressing window of the conv kernels -- use a smaller batch (PosePipeline splits by itself)")
         by_first = {}
         for t in self.tensors:
             by_first.setdefault(t.first, []).append(t)
@@ -650,6 +658,11 @@ class Graph:
                     if sz > need:
                         free.append((o + need, sz - need))
                 else:
+                    nxt = (top // WINDOW + 1) * WINDOW                 # start of the next window = its zero page
+                    if top + need > nxt:                               # would run into it: leave the rest of this window free
+                        if reuse and nxt > top:
+                            free.append((top, nxt - top))
+                        top = nxt + ZERO_PAGE
                     t.off = top
                     top += need
             for t in expiring.get(i, []):
@@ -657,18 +670,16 @@ class Graph:
                     free.append((t.off, _rup(t.nbytes, ALIGN)))
                     free.sort()
                     merged = []
-                    for o, sz in free:
+                    for o, sz in free:                                 # (blocks on either side of a zero page are never adjacent)
                         if merged and merged[-1][0] + merged[-1][1] == o:
                             merged[-1] = (merged[-1][0], merged[-1][1] + sz)
                         else:
                             merged.append((o, sz))
                     free = merged
         self.arena_bytes = max(top, ALIGN)
-        for op in self.ops:
-            if op.kind == OP_CONV and op.inp.off + op.inp.nbytes > (1 << 32):
-                raise ArenaTooLarge(f"{op.out.name}: conv input ends at {(op.inp.off + op.inp.nbytes) / 2 ** 30:.2f} GiB of a "
-                                    f"{self.arena_bytes / 2 ** 30:.2f} GiB arena ({self.B} frames, precision {self.precision}); the "
-                                    "conv kernels take inputs below 4 GiB -- use a smaller batch (PosePipeline splits by itself)")
+        for t in self.tensors:
+            if t.off >= 0:
+                assert t.off % WINDOW >= ZERO_PAGE and t.off // WINDOW == (t.off + t.nbytes - 1) // WINDOW, t.name
         return self.arena_bytes
 
     def emit(self):
@@ -739,6 +750,33 @@ class Graph:
                 if p.get("flip_from"):
                     o.flip_from, o.in_c_off, o.w_off = p["flip_from"], p["n_kpt"], p["w_off"]
         return arr
+
+    def blob(self):
+        """The allocated schedule as one relocatable byte image (include/smap_hip.h "plan blob": smap_blob_header | smap_op[n]
+        | weight section), little-endian: smap_plan_create_from_blob validates it and hands back the buffer sizes and the
+        output layout, so that a host with nothing but the header can run SMAP.forward (tests/c/blob_runner.c)."""
+        ops = self.emit()
+        n_ops = len(self.ops)
+        hdr = _L.BlobHeader()
+        ops_off = _rup(C.sizeof(hdr), ALIGN)
+        ops_bytes = C.sizeof(_L.SmapOp) * n_ops
+        w_off = _rup(ops_off + ops_bytes, ALIGN)
+        wblob = self.weight_blob().numpy().tobytes()
+        hdr.magic, hdr.version, hdr.sizeof_op, hdr.header_bytes = b"SMAPPLN1", 1, C.sizeof(_L.SmapOp), C.sizeof(hdr)
+        hdr.n_ops, hdr.ops_offset = n_ops, ops_off
+        hdr.weights_offset, hdr.weights_bytes = w_off, len(wblob)
+        hdr.arena_bytes, hdr.out_bytes = self.arena_bytes, self.out_bytes + 4
+        i = hdr.info
+        i.frames, i.H, i.W, i.out_h, i.out_w = self.frames, self.H, self.W, self.out_h, self.out_w
+        i.n_hms, i.n_det, i.n_root, i.precision = self.kpt_paf, self.paf, 1, int(self.x3)
+        i.arena_bytes, i.out_bytes, i.weights_offset, i.weights_bytes = hdr.arena_bytes, hdr.out_bytes, w_off, len(wblob)
+        i.hms_off, i.det_off, i.root_off = self.out_layout["hms"][0], self.out_layout["det_d"][0], self.out_layout["root_d"][0]
+        i.status_off = self.status_off
+        out = bytearray(w_off + len(wblob))
+        out[:C.sizeof(hdr)] = bytes(hdr)
+        out[ops_off:ops_off + ops_bytes] = bytes(ops)
+        out[w_off:] = wblob
+        return bytes(out)
 
     def weight_blob(self):
         blob = torch.zeros((max(self.woff, ALIGN),), dtype=torch.uint8)
@@ -823,25 +861,44 @@ class BackboneEngine:
             pass
 
     def run(self, imgs, first=0, count=None, out=None):
-        """imgs: [B,3,H,W] fp32 contiguous on the device.  Returns (hms, det_d, root_d) views of the
-        output buffer `out` (default: the engine's own, overwritten by the next run)."""
-        if tuple(imgs.shape) != (self.B, 3, self.H, self.W) or imgs.dtype != torch.float32 or not imgs.is_cuda:
-            raise ValueError(f"imgs must be a float32 GPU tensor [{self.B},3,{self.H},{self.W}], got "
-                             f"{tuple(imgs.shape)} {imgs.dtype} {imgs.device}")
-        if out is not None and (out.dtype != torch.float32 or out.device != imgs.device or not out.is_contiguous()
+        """imgs: [B,3,H,W] fp32 contiguous on the device -- or a list / tuple of n (1..8, a divisor of B) such tensors of B / n
+        frames each, read where they are (smap_plan_run_inputs: no gather copy in front of the stem).  Returns (hms, det_d,
+        root_d) views of the output buffer `out` (default: the engine's own, overwritten by the next run)."""
+        parts = list(imgs) if isinstance(imgs, (list, tuple)) else [imgs]
+        n = len(parts)
+        if not 1 <= n <= _L.MAX_INPUTS or self.B % n:
+            raise ValueError(f"{n} input buffers for a schedule of {self.B} frames (1..{_L.MAX_INPUTS} buffers, a divisor of the batch)")
+        for t in parts:
+            if tuple(t.shape) != (self.B // n, 3, self.H, self.W) or t.dtype != torch.float32 or not t.is_cuda:
+                raise ValueError(f"imgs must be float32 GPU tensor(s) [{self.B // n},3,{self.H},{self.W}], got "
+                                 f"{tuple(t.shape)} {t.dtype} {t.device}")
+        parts = [t.contiguous() for t in parts]
+        dev0 = parts[0].device
+        if out is not None and (out.dtype != torch.float32 or out.device != dev0 or not out.is_contiguous()
                                 or out.numel() < self.out_floats + 1):
             # the maps are followed by the status word: a buffer of the pre-round-3 size would be written 4 bytes past its end
-            raise ValueError(f"out must be a contiguous float32 tensor of >= {self.out_floats + 1} elements on {imgs.device} "
+            raise ValueError(f"out must be a contiguous float32 tensor of >= {self.out_floats + 1} elements on {dev0} "
                              f"(BackboneEngine.new_output()), got {out.dtype} x {out.numel()} on {out.device}")
-        imgs = imgs.contiguous()
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        count = self.n_ops - first if count is None else count
+        outp = C.c_void_p((self.out if out is None else out).data_ptr())
         with torch.cuda.device(self.device):
-            _L.check(self.lib.smap_plan_run_range(self.handle, first, count, C.c_void_p(imgs.data_ptr()),
-                                                  C.c_void_p(self.arena.data_ptr()), C.c_void_p(self.weights.data_ptr()),
-                                                  C.c_void_p((self.out if out is None else out).data_ptr()), st),
-                     "smap_plan_run")
+            if n == 1 or first != 0 or count is not None:
+                if n != 1:
+                    raise ValueError("partial runs (first / count) take one input buffer")
+                count = self.n_ops - first if count is None else count
+                _L.check(self.lib.smap_plan_run_range(self.handle, first, count, C.c_void_p(parts[0].data_ptr()),
+                                                      C.c_void_p(self.arena.data_ptr()), C.c_void_p(self.weights.data_ptr()), outp, st),
+                         "smap_plan_run")
+            else:
+                ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in parts])
+                _L.check(self.lib.smap_plan_run_inputs(self.handle, ptrs, n, C.c_void_p(self.arena.data_ptr()),
+                                                       C.c_void_p(self.weights.data_ptr()), outp, st), "smap_plan_run_inputs")
         return (self.hms, self.det_d, self.root_d) if out is None else self.views(out)
+
+    def blob(self):
+        """The whole schedule as one relocatable byte image (Graph.blob): what a host without this Python builder loads with
+        smap_plan_create_from_blob.  Returns bytes."""
+        return self.graph.blob()
 
     def capture(self, out=None):
         """Record the whole schedule (the ~208 launches of smap_plan_run) into a HIP graph.  Returns

@@ -18,7 +18,9 @@ SO_PATH = os.environ.get("SMAP_HIP_LIB") or os.path.join(HERE, "libsmap_hip.so")
 SYMBOLS = [
     "smap_version", "smap_scale_hms", "smap_flip_merge", "smap_nms", "smap_paf_score", "smap_group", "smap_lift",
     "smap_refine", "smap_register_gt", "smap_lift_gt", "smap_refine_gt", "smap_refine_mlp", "smap_preprocess", "smap_sizeof_op", "smap_conv_tile_dims", "smap_conv_tile_bk", "smap_conv_tile_tail_bn", "smap_plan_create", "smap_plan_destroy", "smap_plan_run", "smap_plan_run_range",
+    "smap_plan_run_inputs", "smap_workspace_bytes", "smap_plan_create_from_blob",
 ]
+MAX_INPUTS = 8                         # SMAP_MAX_INPUTS
 
 
 class SmapOp(C.Structure):
@@ -41,6 +43,21 @@ class SmapOp(C.Structure):
         ("tail_cout", C.c_int32), ("tail_cout_pad", C.c_int32), ("tail_acc_scale", C.c_float),
         ("tail_w_off", C.c_int64), ("tail_bias_off", C.c_int64),
     ]
+
+
+class BlobInfo(C.Structure):
+    """Mirror of `struct smap_blob_info`."""
+    _fields_ = [("frames", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32),
+                ("n_hms", C.c_int32), ("n_det", C.c_int32), ("n_root", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32),
+                ("arena_bytes", C.c_int64), ("out_bytes", C.c_int64), ("weights_offset", C.c_int64), ("weights_bytes", C.c_int64),
+                ("hms_off", C.c_int64), ("det_off", C.c_int64), ("root_off", C.c_int64), ("status_off", C.c_int64)]
+
+
+class BlobHeader(C.Structure):
+    """Mirror of `struct smap_blob_header`."""
+    _fields_ = [("magic", C.c_char * 8), ("version", C.c_uint32), ("sizeof_op", C.c_uint32), ("header_bytes", C.c_uint32),
+                ("n_ops", C.c_int32), ("ops_offset", C.c_int64), ("weights_offset", C.c_int64), ("weights_bytes", C.c_int64),
+                ("arena_bytes", C.c_int64), ("out_bytes", C.c_int64), ("info", BlobInfo)]
 
 
 _lib = None
@@ -84,6 +101,9 @@ def load():
     lib.smap_plan_destroy.restype = None
     lib.smap_plan_run.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.smap_plan_run_range.argtypes = [vp, ip, ip, vp, vp, vp, vp, vp]
+    lib.smap_plan_run_inputs.argtypes = [vp, C.POINTER(vp), ip, vp, vp, vp, vp]
+    lib.smap_workspace_bytes.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.smap_plan_create_from_blob.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(BlobInfo)]
     for s in SYMBOLS:
         if s not in ("smap_version", "smap_plan_destroy"):  # everything else returns int
             getattr(lib, s).restype = ip

@@ -108,12 +108,14 @@ class PosePipeline:
         self.slots = [_Slot(self.engine, self.device, n_extra, batch) for _ in range(self.nslots)]
         self.frames_per_launch = self.chunk
         self.k = 0
+        self.wait_s = 0.0                # host time spent WAITING for the GPU inside submit() / flush() (sleeping, not enqueueing)
         self.bb_events = []              # (start, end) HIP events of timed backbone runs
         self.post_events = []            # (tag, start, end) HIP events of timed association+lifting passes (time_backbone=True)
 
     # -- device side -------------------------------------------------------------------------
-    def _post(self, slot, idx, hms, det_d, root_d, cams, scale, gt=None):
-        """Association + lifting of one set of maps on the post stream; results -> pinned memory.
+    def _post(self, slot, idx, hms, det_d, root_d, cams, scale, gt=None, row0=0):
+        """Association + lifting of one set of maps on the post stream; results -> pinned memory (rows row0.. of result set idx:
+        a coalesced launch hands its callers' extra maps over batch by batch, where they lie).
         gt = (gt_roots [B,G,2], gt_counts [B]) on the device: register the persons to the annotations first
         (test_util.py:18-42) and lift in the f64 flavour of the ground-truth modes."""
         if scale:
@@ -125,19 +127,21 @@ class PosePipeline:
         if self.refine is not None:
             p3 = dapalib.refine_batch(p2, p3, counts, *self.refine)
         h = slot.host[idx]
+        n = hms.shape[0]
         if gt is not None:
             if slot.p2_f64 is None:
                 slot.p2_f64 = torch.empty(tuple(p2.shape), dtype=torch.float64).pin_memory()
             slot.p2_f64.copy_(p2, non_blocking=True)
         else:
-            h["p2"].copy_(p2, non_blocking=True)
+            h["p2"][row0:row0 + n].copy_(p2, non_blocking=True)
         for k, t in (("p3", p3), ("rz", rz), ("counts", counts)):
-            h[k].copy_(t, non_blocking=True)
+            h[k][row0:row0 + n].copy_(t, non_blocking=True)
 
     def submit(self, imgs, cams, tags, extra=(), time_backbone=False, annotations=None):
-        """imgs [B,3,H,W] fp32 on the device; cams [B,9] float64 (host array); tags: B image names.
-        extra: tuples (tag_prefix, hms, root_d, det_d) of already-scaled maps to associate as well
-        (bench only).  annotations (ground-truth modes): B arrays [G_i,15,C] of the KEPT annotations of each
+        """imgs [B,3,H,W] fp32 on the device -- or a list of equally sized tensors that together hold the B frames (read where
+        they are: smap_plan_run_inputs); cams [B,9] float64 (host array); tags: B image names.
+        extra: tuples (tag_prefix, hms, root_d, det_d) of already-scaled maps to associate as well (bench only); each of the three
+        may be a list of tensors covering the B frames in order (associated part by part, no concatenation).  annotations (ground-truth modes): B arrays [G_i,15,C] of the KEPT annotations of each
         frame (records.kept_annotations; G_i may be 0 -- the frame is skipped, test.py:81-82).
         Returns the record list of the previous batch or None."""
         if self._model.weights_generation != self._generation:
@@ -162,25 +166,34 @@ class PosePipeline:
         cur = torch.cuda.current_stream(self.device)
         s_bb.wait_stream(cur)                          # imgs were produced on the caller's stream
         self.s_post.wait_stream(cur)
-        imgs.record_stream(s_bb)
+        img_parts = list(imgs) if isinstance(imgs, (list, tuple)) else [imgs]
+        if len(img_parts) > 1 and (len(img_parts) > 8 or len({tuple(t.shape) for t in img_parts}) > 1 or
+                                   (len(slot.outs) > 1 and len(img_parts) % len(slot.outs))):
+            img_parts = [torch.cat(img_parts)]         # shapes the stem's buffer table cannot express: gather (never on the bench path)
+        for t in img_parts:
+            t.record_stream(s_bb)
         cams_d.record_stream(self.s_post)
         if gt is not None:
             gt[0].record_stream(self.s_post)
             gt[1].record_stream(self.s_post)
-        for _, e_hms, e_rd, e_dd in extra:               # the caller may drop its references (CoalescedPipeline passes temporaries)
+        as_parts = lambda t: list(t) if isinstance(t, (list, tuple)) else [t]
+        for _, e_hms, e_rd, e_dd in extra:               # the caller may drop its references
             for t in (e_hms, e_rd, e_dd):
                 if t is not None:
-                    t.record_stream(self.s_post)
+                    for q in as_parts(t):
+                        q.record_stream(self.s_post)
         with torch.cuda.stream(s_bb):
             if time_backbone:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if len(slot.outs) == 1:
-                eng.run(imgs, out=slot.out)
+                eng.run(img_parts if len(img_parts) > 1 else img_parts[0], out=slot.out)
             else:                                      # the batch in engine-sized launches, one after the other on this stream
                 c = eng.B
+                per = len(img_parts) // len(slot.outs)
                 for j, o in enumerate(slot.outs):
-                    hm, dd, rd = eng.run(imgs[j * c:(j + 1) * c], out=o)
+                    src = img_parts[0][j * c:(j + 1) * c] if len(img_parts) == 1 else img_parts[j * per:(j + 1) * per]
+                    hm, dd, rd = eng.run(src[0] if isinstance(src, list) and len(src) == 1 else src, out=o)
                     slot.hms[j * c:(j + 1) * c].copy_(hm, non_blocking=True)
                     slot.det_d[j * c:(j + 1) * c].copy_(dd, non_blocking=True)
                     slot.root_d[j * c:(j + 1) * c].copy_(rd, non_blocking=True)
@@ -202,7 +215,14 @@ class PosePipeline:
                 slot.status_host[j:j + 1].copy_(o[slot.status:slot.status + 1], non_blocking=True)
             timed_post("network", slot, 0, slot.hms, slot.det_d, slot.root_d, cams_d, scale=True, gt=gt)
             for j, (tag, hms, rd, dd) in enumerate(extra):
-                timed_post(tag, slot, 1 + j, hms, slot.det_d if dd is None else dd, rd, cams_d, scale=False)
+                row = 0
+                hp, rp = as_parts(hms), as_parts(rd)
+                dp = [None] * len(hp) if dd is None else as_parts(dd)
+                for h_, r_, d_ in zip(hp, rp, dp):       # part by part where the maps lie (leading-dimension slices are views)
+                    n_ = h_.shape[0]
+                    timed_post(tag if isinstance(tag, str) else tag[row], slot, 1 + j, h_, slot.det_d[row:row + n_] if d_ is None else d_, r_, cams_d[row:row + n_],
+                               scale=False, row0=row)
+                    row += n_
             slot.ev_post.record()
         slot.meta = (list(tags), [t for t, *_ in extra], annotations)
         slot.busy = True
@@ -244,7 +264,10 @@ class PosePipeline:
             time.sleep(poll_s)
 
     def _collect(self, slot):
+        import time
+        t0 = time.perf_counter()
         self._wait(slot.ev_post)
+        self.wait_s += time.perf_counter() - t0          # back-pressure: the host sleeping until the GPU has finished a batch
         tags, extra_tags, annotations = slot.meta
         words = slot.status_host.view(torch.int32).tolist()
         if any(w & 1 for w in words):
@@ -314,6 +337,7 @@ class CoalescedPipeline:
     bb_events = property(lambda self: self.inner.bb_events)          # one entry per LAUNCH (group * batch frames)
     post_events = property(lambda self: self.inner.post_events)
     frames_per_launch = property(lambda self: self.inner.chunk)
+    wait_s = property(lambda self: self.inner.wait_s + self._small.wait_s)
 
     def last_maps(self):
         """Maps of the most recent COALESCED launch (group * batch frames, in submission order), or None if none ran."""
@@ -321,7 +345,9 @@ class CoalescedPipeline:
 
     @staticmethod
     def _merge(pending):
-        imgs = torch.cat([p[0] for p in pending])
+        """The group's batches as ONE submit of the inner pipeline WITHOUT copying a map or an image: images and extra maps go
+        down as lists of the callers' tensors (the stem reads up to 8 input buffers; the association runs part by part)."""
+        imgs = [p[0] for p in pending]
         cams = np.concatenate([np.asarray(p[1]) for p in pending])
         tags = [t for p in pending for t in p[2]]
         extra = []
@@ -329,8 +355,8 @@ class CoalescedPipeline:
             parts = [p[3][j] for p in pending]
             assert all((q[3] is None) == (parts[0][3] is None) for q in parts)
             prefixes = [q[0] for q, p in zip(parts, pending) for _ in p[2]]
-            extra.append((prefixes if len(set(prefixes)) > 1 else prefixes[0], torch.cat([q[1] for q in parts]),
-                          torch.cat([q[2] for q in parts]), None if parts[0][3] is None else torch.cat([q[3] for q in parts])))
+            extra.append((prefixes if len(set(prefixes)) > 1 else prefixes[0], [q[1] for q in parts],
+                          [q[2] for q in parts], None if parts[0][3] is None else [q[3] for q in parts]))
         ann = None if pending[0][4] is None else [a for p in pending for a in p[4]]
         return imgs, cams, tags, extra, ann
 

@@ -31,6 +31,43 @@ def test_library_exports_every_declared_symbol():
     assert so.smap_sizeof_op() == ctypes.sizeof(L.SmapOp)
 
 
+def test_plan_blob_round_trip_and_workspace_bytes():
+    """The serialised schedule (Graph.blob -> smap_plan_create_from_blob, no GPU involved in either): header, ops and weight
+    section come back as written, the library sizes the buffers from the ops alone (smap_workspace_bytes) within what the
+    header states, and damaged blobs are refused."""
+    import ctypes as C
+    from recipe import recipe_state_dict
+    from smap_amd import lib as L
+    from smap_amd.engine import Graph
+    from smap_amd.model.smap import SMAP
+    lib = L.load()
+    torch.manual_seed(0)
+    sd = recipe_state_dict(SMAP(make_cfg((16, 24))).state_dict())
+    for precision, flip in (("x3", None), ("f16", list(range(43)))):
+        g = Graph(sd, 2, 64, 96, precision=precision, flip_pair=flip)
+        g.allocate()
+        blob = g.blob()
+        plan, info = C.c_void_p(), L.BlobInfo()
+        assert lib.smap_plan_create_from_blob(blob, len(blob), C.byref(plan), C.byref(info)) == 0
+        assert (info.frames, info.H, info.W, info.out_h, info.out_w) == (2, 64, 96, 16, 24)
+        assert (info.n_hms, info.n_det, info.n_root, info.precision) == (43, 14, 1, int(precision == "x3"))
+        assert info.arena_bytes == g.arena_bytes and info.out_bytes == g.out_bytes + 4 and info.status_off == g.out_bytes
+        assert (info.hms_off, info.det_off, info.root_off) == (0, 2 * 43 * 16 * 24 * 4, 2 * 57 * 16 * 24 * 4)
+        assert blob[info.weights_offset:info.weights_offset + info.weights_bytes] == g.weight_blob().numpy().tobytes()
+        ar, ob = C.c_int64(), C.c_int64()
+        assert lib.smap_workspace_bytes(plan, C.byref(ar), C.byref(ob)) == 0
+        assert ob.value == info.out_bytes and 0.5 * g.arena_bytes < ar.value <= g.arena_bytes     # ops touch (almost) all of the arena
+        lib.smap_plan_destroy(plan)
+        bad = bytearray(blob)
+        bad[0:1] = b"X"
+        assert lib.smap_plan_create_from_blob(bytes(bad), len(bad), C.byref(plan), None) == -1      # magic
+        assert lib.smap_plan_create_from_blob(blob, len(blob) // 2, C.byref(plan), None) == -1      # truncated
+        hdr = L.BlobHeader.from_buffer_copy(blob[:C.sizeof(L.BlobHeader)])
+        hdr.arena_bytes = 4096                                                                       # header smaller than what the ops touch
+        lied = bytes(hdr) + blob[C.sizeof(hdr):]
+        assert lib.smap_plan_create_from_blob(lied, len(lied), C.byref(plan), None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from smap_amd import lib as L
     monkeypatch.setattr(L, "_lib", None)
