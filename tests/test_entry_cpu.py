@@ -335,8 +335,8 @@ def test_test_py_dry_run_eight_ranks(tmp_path):
 
 def test_coalesced_pipeline_protocol_without_a_gpu(monkeypatch):
     """smap_amd/pipeline.py::CoalescedPipeline on CPU, the device pipeline replaced by a recorder: `group` submitted batches reach
-    the inner pipeline as ONE concatenated batch (frames, cameras, tags, per-frame prefixes of the extra maps, annotations, in
-    submission order), records come back in order, an incomplete trailing group goes through a batch-sized pipeline at
+    the inner pipeline as ONE batch (cameras, tags, per-frame prefixes of the extra maps and annotations concatenated in
+    submission order; images and extra maps as LISTS of the callers' tensors -- nothing is copied), records come back in order, an incomplete trailing group goes through a batch-sized pipeline at
     flush(), and make_pipeline picks the group size from the frames per launch (x2 with flip-TTA)."""
     import smap_amd.pipeline as P
 
@@ -351,9 +351,12 @@ def test_coalesced_pipeline_protocol_without_a_gpu(monkeypatch):
             Recorder.built.append(self)
 
         def submit(self, imgs, cams, tags, extra=(), time_backbone=False, annotations=None):
+            ident = [id(t) for t in imgs] if isinstance(imgs, list) else None           # the callers' own tensors, not copies
+            cat = lambda t: torch.cat(list(t)) if isinstance(t, (list, tuple)) else t
+            imgs = cat(imgs)
             assert len(imgs) == len(cams) == len(tags) == self.B
-            self.calls.append((imgs.clone(), np.asarray(cams).copy(), list(tags), [(t, h.clone(), r.clone(), d) for t, h, r, d in extra],
-                               time_backbone, annotations))
+            self.calls.append((imgs.clone(), np.asarray(cams).copy(), list(tags), [(t, cat(h).clone(), cat(r).clone(), d) for t, h, r, d in extra],
+                               time_backbone, annotations, ident))
             self.q.append([{"image_path": t, "v": float(imgs[i].sum())} for i, t in enumerate(tags)])
             return self.q.pop(0) if len(self.q) > 1 else None
 
@@ -366,9 +369,10 @@ def test_coalesced_pipeline_protocol_without_a_gpu(monkeypatch):
     B = 2
     pipe = P.make_pipeline(None, None, B, 8, 8, "cpu", launch_frames=6, depth=2)
     assert isinstance(pipe, P.CoalescedPipeline) and pipe.group == 3 and pipe.B == B and pipe.frames_per_launch == 6
-    got = []
+    got, sent = [], []
     for i in range(8):                                   # 8 batches = 2 full groups + 2 left over
         imgs = torch.full((B, 3, 8, 8), float(i))
+        sent.append(imgs)
         cams = np.full((B, 9), float(i))
         ex = [(f"K{i % 2}", torch.full((B, 43, 2, 2), 10.0 + i), torch.full((B, 1, 2, 2), 20.0 + i), None)]
         got += pipe.submit(imgs, cams, [f"b{i}/{j}" for j in range(B)], extra=ex, time_backbone=(i == 4)) or []
@@ -377,7 +381,8 @@ def test_coalesced_pipeline_protocol_without_a_gpu(monkeypatch):
     assert [r["v"] for r in got] == [float(i) * 3 * 64 for i in range(8) for _ in range(B)]
     big, small = Recorder.built[0], Recorder.built[1]
     assert big.B == 6 and small.B == 2 and len(big.calls) == 2 and len(small.calls) == 2
-    imgs, cams, tags, extra, timed, ann = big.calls[1]                                               # batches 3, 4, 5
+    imgs, cams, tags, extra, timed, ann, ident = big.calls[1]                                        # batches 3, 4, 5
+    assert ident == [id(sent[3]), id(sent[4]), id(sent[5])]                                          # handed down as they are: no gather copy
     assert imgs[:, 0, 0, 0].tolist() == [3, 3, 4, 4, 5, 5] and cams[:, 0].tolist() == [3, 3, 4, 4, 5, 5] and timed and ann is None
     assert tags == [f"b{i}/{j}" for i in (3, 4, 5) for j in range(B)]
     assert extra[0][0] == ["K1", "K1", "K0", "K0", "K1", "K1"] and extra[0][1][:, 0, 0, 0].tolist() == [13, 13, 14, 14, 15, 15]
