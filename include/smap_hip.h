@@ -118,7 +118,8 @@ int smap_preprocess(const unsigned char* src, int h, int w, int nh, int nw, int 
 /* One op of the static inference schedule.  Offsets are BYTE offsets into the
  * caller's activation arena / weight blob; -1 = absent. */
 enum smap_op_kind {
-    SMAP_OP_CONV = 0,       /* conv_bn_relu (smap.py:13-45) with folded BN, implicit GEMM on MFMA */
+    SMAP_OP_CONV = 0,       /* conv_bn_relu (smap.py:13-45) with folded BN, implicit GEMM on MFMA; with tail_cout / head_cin a
+                               Bottleneck's 3x3 + 1x1, or the whole Bottleneck (smap.py:48-77), in one launch */
     SMAP_OP_STEM = 1,       /* ResNet_top conv 7x7 s2 (smap.py:83-84) from fp32 NCHW input      */
     SMAP_OP_MAXPOOL = 2,    /* ResNet_top maxpool 3x3 s2 p1 (smap.py:86)                         */
     SMAP_OP_UPADD = 3,      /* out = relu(a + bilinear_align_corners(t)) (smap.py:213-217)       */
@@ -194,6 +195,14 @@ typedef struct smap_op {
     float tail_acc_scale;           /* precision 1: 2^-s of the 1x1 weights */
     int64_t tail_w_off;             /* weight-blob byte offsets of the 1x1: blocks [n chunk][k chunk][BN2 rows][128 B], rows */
     int64_t tail_bias_off;          /* in the halo tiles' format (64 channels, or hi32 | lo32); fp32 bias [tail_cout_pad] */
+    int32_t head_cin;               /* CONV, tile ids 90..99 only (else 0): the op is a WHOLE stride-1 identity Bottleneck in one launch
+                                       (smap.py:48-77; csrc/convb.hip, split precision): a LEADING 1x1 conv head_cin -> Cin (bias +
+                                       ReLU, never stored, recomputed on the 3x3's halo) in front of the 3x3 and its tail.  The input
+                                       tensor then has head_cin channels (in_stride_c = 2 * head_cin), is read once, and is also
+                                       the residual: res_off must equal in_off and tail_cout = head_cin. */
+    float head_acc_scale;           /* 2^-s of the leading 1x1's weights */
+    int64_t head_w_off;             /* weight-blob byte offsets of the leading 1x1: blocks [k chunk][Cin rows][128 B] in the halo */
+    int64_t head_bias_off;          /* tiles' row format (hi32 | lo32 of 32 input channels); fp32 bias [Cin] */
 } smap_op;
 
 /* sizeof(smap_op) as compiled: lets a foreign-language binding verify its struct mirror. */

@@ -39,7 +39,12 @@ def run_graph(g, imgs, quantize, keep=False):
             T[op.out.name] = F.max_pool2d(T[op.inp.name], 3, 2, 1)
         elif op.kind == OP_CONV:
             cin, cout, k = p["Cin"], p["Cout"], p["ksize"]
-            x = T[op.inp.name][:, p["in_c_off"]:p["in_c_off"] + cin]
+            if "head" in p:                              # whole Bottleneck (csrc/convb.hip): the leading 1x1 + ReLU in front of the 3x3; its
+                hd = p["head"]                           # output is rounded like a stored activation (split precision: exact here)
+                assert not quantize, "the whole-block kernel exists in split precision only (interpreted un-quantized)"
+                x = _q(F.relu(F.conv2d(T[op.inp.name], hd["w_ref"].to(dt).to(dev), hd["b_ref"].to(dt).to(dev))), quantize)
+            else:
+                x = T[op.inp.name][:, p["in_c_off"]:p["in_c_off"] + cin]
             if quantize:
                 K = k * k * cin
                 from smap_amd.engine import unpack_conv_weights      # the blob holds pre-tiled weight blocks

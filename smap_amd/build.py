@@ -22,6 +22,7 @@ SOURCES = [
     ("conv3.hip", []),
     ("convp.hip", []),
     ("convf.hip", []),
+    ("convb.hip", []),
     ("plan.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),

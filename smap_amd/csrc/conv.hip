@@ -461,7 +461,7 @@ extern "C" int smap_conv_tile_bk(int tile, int precision)
 {
     int bm, bn;
     if (smap_conv_tile_dims(tile, &bm, &bn)) return 0;
-    if ((tile >= 30 && tile < 40) || (tile >= 80 && tile < 90)) return precision ? 32 : 64;
+    if ((tile >= 30 && tile < 40) || (tile >= 80 && tile < 100)) return precision ? 32 : 64;
     if (tile >= 60 && tile < 80) return tile == 69 ? 64 : 32;
     if (precision) return (tile <= 4 || tile == 52) ? 64 : 32;
     return ((tile >= 20 && tile <= 27) || tile == 50 || tile == 51 || tile == 53 || tile == 54 || tile == 55) ? 32 : 64;
@@ -471,6 +471,7 @@ extern "C" int smap_conv_tile_bk(int tile, int precision)
 extern "C" int smap_conv_tile_tail_bn(int tile)
 {
     int bm, bn, bn2;
+    if (tile >= 90 && tile < 100) return smap_convb_tile_dims(tile, &bm, &bn, &bn2) ? 0 : bn2;
     return (tile >= 80 && tile < 90 && !smap_convf_tile_dims(tile, &bm, &bn, &bn2)) ? bn2 : 0;
 }
 
@@ -481,6 +482,7 @@ extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
     if (tile >= 30 && tile < 40) return smap_conv3_tile_dims(tile, bm, bn);
     if (tile >= 60 && tile < 80) return smap_convp_tile_dims(tile, bm, bn);
     if (tile >= 80 && tile < 90) { int bn2; return smap_convf_tile_dims(tile, bm, bn, &bn2); }
+    if (tile >= 90 && tile < 100) { int bn2; return smap_convb_tile_dims(tile, bm, bn, &bn2); }
     switch (tile) {
         case 20: case 24: *bm = 128; *bn = 128; return 0;      // 20..27: BK = 32 staging (smaller LDS, more workgroups per CU)
         case 21: case 25: *bm = 128; *bn = 64; return 0;
@@ -503,13 +505,14 @@ extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
 int smap_conv_tile_has_x3(int tile)
 {
     return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 57) || (tile >= 60 && tile <= 70) ||
-           (tile >= 80 && tile <= 82);
+           (tile >= 80 && tile <= 82) || tile == 90 || tile == 91;
 }
 
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
 {
     if (tile >= 60 && tile < 80) return smap_launch_convp(a, tile, st);      // persistent wave-specialised kernel, both precisions
     if (tile >= 80 && tile < 90) return smap_launch_convf(a, tile, st);      // 3x3 + fused 1x1 tail, both precisions
+    if (tile >= 90 && tile < 100) return smap_launch_convb(a, tile, st);     // whole identity Bottleneck, split precision
     if (a.x3) {
         if (tile >= 30 && tile < 40) return smap_launch_conv3(a, tile, st);     // halo-tiled 3x3, split-precision instance
         switch (tile) {                                     // LDS = max(STAGES * 2 * (BM + BN) * row bytes, fp32 epilogue tile)

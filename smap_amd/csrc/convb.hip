@@ -1,0 +1,510 @@
+// convb.hip -- a whole stride-1 identity Bottleneck (model/smap.py:48-77) in ONE launch, split precision:
+//     y1 = relu(W1 x + b1)            1x1, C = 4P -> P      (conv_bn_relu1)
+//     y2 = relu(W2 * y1 + b2)         3x3 pad 1, P -> P     (conv_bn_relu2)
+//     out = relu(W3 y2 + b3 + x)      1x1, P -> C, + the block's input as the residual (+ the two skip adds of smap.py:142-153)
+//
+// Why: as three launches the block moves 4096 bytes per pixel through the fabric (x read by c1, y1 written and read, y2 written
+// and read, x read again as the residual, out written) and every launch of these layers sits on the HBM read+write roof
+// (DESIGN.md section 6).  Here x is read ONCE and out written once: 2048 bytes per pixel.  y1 and y2 never leave the CU, and the
+// residual never leaves it either: while the K chunks of x pass through the LDS staging buffers of the leading 1x1, every wave
+// copies the centre pixels' values it will need in the last epilogue into registers (the register file holds the 64 KB / 128 KB
+// an LDS that is full of y1 cannot).
+//
+// Work per workgroup (4 waves, 80 KiB of LDS, two workgroups per CU so that one streams x while the other multiplies):
+// a TH x 16 tile of output pixels (TH = 4 | 8).
+//   phase 1  c1 on the (TH+2) x 18 halo patch (rows of the patch = GEMM rows, rounded up to PROWS = 128 | 192): K = C in 32-channel
+//            chunks, each chunk staged as [PROWS][hi32 | lo32] (x) + [P][hi32 | lo32] (W1) by LDS-DMA in a ring over the WHOLE
+//            80 KiB (y1 does not exist yet); accumulators -> relu -> hi/lo -> y1 in conv3.hip's patch layout, rows outside the
+//            image forced to 0 (the 3x3 pads y1, not x).  The halo is recomputed: +41 % (+69 %) of c1 = +10 % (+16 %) MFMA work.
+//   phase 2  the 3x3 as nine shifted views of y1 (conv3.hip), one 16 KiB weight slot per tap (both 32-channel chunks) in a ring
+//            behind y1; accumulators -> relu -> hi/lo -> y2, written over y1 once every wave is done with it.
+//   phase 3  the tail 1x1 in four chunks of 64 output channels (weight slots in the same ring) with convp.hip's register
+//            epilogue: permlane32_swap -> 8 consecutive channels per lane, + the residual held since phase 1, ReLU, skip adds,
+//            16-byte NHWC stores of both planes.
+// MFMA operand order is weights FIRST everywhere (D rows = channels, columns = pixels): a lane then owns 4 consecutive
+// channels of one pixel, which is what the hi/lo writes into LDS and the register epilogue want.
+//
+// Weights (smap_amd/engine.py::Graph.conv_block, all three in pack_halo_rows' format: 128-byte rows = [hi32 | lo32] of one
+// 32-channel chunk, slot s of row r = logical granule s ^ ((r >> 1) & 7)):
+//   W1  [8 chunks][64 rows]            W2  [2 chunks][9 taps][64 rows]            W3  [4 n chunks][2 chunks][64 rows]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "smap_hip.h"
+#include "plan.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void wait_vm(int n)
+{
+    switch (n) {
+#define W_(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        W_(0) W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15) W_(16)
+#undef W_
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// every LDS read of this wave has returned, then the workgroup barrier (raw: an LDS-DMA in flight must survive it)
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int TH>
+__global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, int tiles_x, int tiles_y)
+{
+    constexpr int P = 64, C = 4 * P, TW = 16, CH = 32, ROWB = 128;
+    constexpr int PW = TW + 2, PH = TH + 2;
+    constexpr int PROWS = ((PH * PW + 31) / 32) * 32;           // patch rows rounded to MFMA blocks: 128 | 192
+    constexpr int MB1 = PROWS / 32;                             // M blocks of phase 1: 4 | 6
+    constexpr int BM = TH * TW;                                 // output pixels of the tile: 64 | 128
+    constexpr int MI = BM / 64;                                 // 32-pixel blocks per wave in phases 2, 3 (2 x 2 waves): 1 | 2
+    static_assert(MB1 == 4 || MB1 == 6, "TH = 4 or 8");
+    constexpr int KC1 = C / CH, KC2 = P / CH;                   // K chunks: 8 (leading 1x1), 2 (3x3 per tap, tail)
+    constexpr int Y1_BYTES = KC2 * PROWS * ROWB;                // 32 | 48 KiB
+    constexpr int Y2_BYTES = KC2 * BM * ROWB;                   // 16 | 32 KiB: y2 takes over the start of y1's region
+    static_assert(Y2_BYTES + C * 4 <= Y1_BYTES && C == 256, "room for the tail-bias table; one bias value per thread");
+    constexpr int LDS_BYTES = 80 * 1024;
+    constexpr int XS = PROWS * ROWB, WS1 = P * ROWB;            // phase-1 stage = x chunk (16 | 24 KiB) + W1 chunk (8 KiB)
+    constexpr int ST1 = XS + WS1;
+    constexpr int NS1 = LDS_BYTES / ST1;                        // stages: 3 | 2
+    constexpr int LA = XS / 4096, LB1 = WS1 / 4096, LPT1 = LA + LB1;   // LDS-DMA instructions per thread and stage
+    constexpr int SLOT = KC2 * P * ROWB;                        // 16 KiB weight slot of phases 2 and 3
+    constexpr int NS = (LDS_BYTES - Y1_BYTES) / SLOT;           // ring slots behind y1: 3 | 2
+    constexpr int LS = SLOT / 4096;                             // 4 per thread
+    constexpr int NTAP = 9, NCH3 = C / 64, NSLOT = NTAP + NCH3; // 13 weight slots per tile: 9 taps, 4 tail chunks
+    static_assert(NS1 >= 2 && NS >= 2 && NS1 * ST1 <= LDS_BYTES && Y1_BYTES + NS * SLOT <= LDS_BYTES, "LDS plan");
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];   // ONE array: a second __shared__ object makes hipcc drain vmcnt
+
+    SMAP_TL_BEGIN
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int logical;                                                // XCD-aware order (conv.hip): neighbouring tiles share an L2
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    int t = logical;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;                    // phases 2, 3: pixel half / channel half of the wave
+
+    // ================================================================= phase 1: y1 = relu(W1 x + b1) on the halo patch
+    const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
+    const char* __restrict__ w1g = reinterpret_cast<const char*>(a.w0);
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int srow = wave * 8 + lrow;
+    const int gl = lslot ^ ((srow >> 1) & 7);                   // logical granule this lane fetches: 0..3 hi, 4..7 lo
+    unsigned a_off[LA];                                         // patch row -> byte offset of its granule (0 = zero page)
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int prow = i * 32 + srow;
+        const int py = prow / PW, px = prow - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        a_off[i] = 0;
+        if (prow < PH * PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+            const long long e = ((long long)(b * a.H + iy) * a.W + ix) * a.in_stride_c + (gl & 3) * 8 + (gl >> 2) * a.in_lo;
+            a_off[i] = (unsigned)(a.in_off + e * 2);
+        }
+    }
+    auto issue1 = [&](int st, int kc) {                         // stage st <- K chunk kc of x and of W1
+        char* sX = smem + st * ST1;
+        const char* gA = arena + (unsigned)(kc * CH * 2);       // invalid rows: zero page + chunk offset
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_off[i]), (lds_void*)(sX + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+        const char* gW = w1g + (long long)kc * WS1 + (unsigned)(wave * 1024 + lane * 16);
+#pragma unroll
+        for (int i = 0; i < LB1; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gW + i * 4096), (lds_void*)(sX + XS + i * 4096 + wave * 1024), 16, 0, 0);
+    };
+    // centre pixels of this lane in phases 2 and 3: p = wm*(MI*32) + mi*32 + l31 -> patch row of the pixel itself
+    int crow[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int p = wm * (MI * 32) + mi * 32 + l31;
+        crow[mi] = (p / TW + 1) * PW + (p % TW) + 1;
+    }
+    // the residual of the last epilogue, collected while x passes through LDS: rs[nc][mi][j][plane] = channels
+    // nc*64 + wn*32 + 16*j + 8*lhi .. +7 of pixel (mi, l31) -- the layout the register epilogue of phase 3 ends in
+    half8 rs[NCH3][MI][2][2];
+
+    constexpr int NB1 = MB1 == 6 ? 3 : 2;                       // 32 x 32 blocks of y1 per wave: (mb = wave, n = 0 | 1) [+ one of M blocks 4, 5]
+    // Biases enter through the ACCUMULATORS (acc = b / 2^-s before the first MFMA; the power-of-two scale makes that exact): an
+    // ordinary global load in the middle of the LDS-DMA pipeline would make hipcc drain the whole queue (vmcnt(0)) at its use.
+    // b1 here (its loads are the oldest of the kernel), b2 during the last K chunk, b3 via a 1 KiB table in LDS.
+    const int xmb = 4 + (wave >> 1), xnb = wave & 1;            // the extra block (TH = 8): patch rows 128..191, channel half wave & 1
+    float4 b1raw[NB1][4];
+#pragma unroll
+    for (int j = 0; j < NB1; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b1raw[j][q] = *reinterpret_cast<const float4*>(a.bias0 + (j < 2 ? j : xnb) * 32 + 8 * q + 4 * lhi);
+    const float b3_mine = a.bias2[tid];                         // tail bias: one value per thread, parked until the table can be written
+#pragma unroll
+    for (int st = 0; st < NS1 - 1; ++st) issue1(st, st);        // the first stages go out behind the bias loads
+    f32x16 acc1[NB1];
+    {
+        const float inv0 = 1.f / a.acc_scale0;
+#pragma unroll
+        for (int j = 0; j < NB1; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc1[j][4 * q + 0] = b1raw[j][q].x * inv0; acc1[j][4 * q + 1] = b1raw[j][q].y * inv0;
+                acc1[j][4 * q + 2] = b1raw[j][q].z * inv0; acc1[j][4 * q + 3] = b1raw[j][q].w * inv0;
+            }
+    }
+    const int fswz = (l31 >> 1) & 7;                            // (row >> 1) & 7 of every fragment row = multiple of 32 + l31
+
+#pragma unroll
+    for (int kc = 0; kc < KC1; ++kc) {
+        if (kc + NS1 - 1 <= KC1) wait_vm((NS1 - 2) * LPT1);     // chunk kc has landed; younger stages stay in flight
+        else wait_vm(0);
+        lds_barrier();
+        if (kc + NS1 - 1 < KC1) issue1((kc + NS1 - 1) % NS1, kc + NS1 - 1);     // into the stage chunk kc-1 was read from
+        const char* sX = smem + (kc % NS1) * ST1;
+        const char* sW = sX + XS;
+        if ((kc & 1) == wn) {                                   // this wave's residual channels are in this chunk
+            constexpr int nc_of[KC1] = {0, 0, 1, 1, 2, 2, 3, 3};
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        rs[nc_of[kc]][mi][j][pl] = *reinterpret_cast<const half8*>(
+                            sX + crow[mi] * ROWB + ((((2 * j + lhi) + 4 * pl) ^ ((crow[mi] >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int kk = 0; kk < CH / 16; ++kk) {
+            const int g = kk * 2 + lhi;
+            half8 wf[2][2], xf[2], xe[2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const int slot = ((g + 4 * pl) ^ fswz) << 4;
+                wf[pl][0] = *reinterpret_cast<const half8*>(sW + l31 * ROWB + slot);
+                wf[pl][1] = *reinterpret_cast<const half8*>(sW + (32 + l31) * ROWB + slot);
+                xf[pl] = *reinterpret_cast<const half8*>(sX + (wave * 32 + l31) * ROWB + slot);
+                if (MB1 == 6) xe[pl] = *reinterpret_cast<const half8*>(sX + (xmb * 32 + l31) * ROWB + slot);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {                    // small cross terms first, then hi*hi (conv3.hip's order)
+                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nb], xf[1], acc1[nb], 0, 0, 0);
+                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][nb], xf[0], acc1[nb], 0, 0, 0);
+                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nb], xf[0], acc1[nb], 0, 0, 0);
+            }
+            if (MB1 == 6) {                                     // the extra block's channel half is wave-uniform: a scalar branch, no copy
+                if (xnb) {
+                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][1], xe[1], acc1[NB1 - 1], 0, 0, 0);
+                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][1], xe[0], acc1[NB1 - 1], 0, 0, 0);
+                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][1], xe[0], acc1[NB1 - 1], 0, 0, 0);
+                } else {
+                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][0], xe[1], acc1[NB1 - 1], 0, 0, 0);
+                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][0], xe[0], acc1[NB1 - 1], 0, 0, 0);
+                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][0], xe[0], acc1[NB1 - 1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    lds_barrier();                                              // every wave is done with the staging buffers (all DMA has landed)
+    // phase 2's accumulators start at b2 / scale: the loads go out now, ahead of the first weight slots, and are consumed after
+    // y1 has been written (the wait hipcc puts there covers slot 0, which is needed then anyway)
+    float4 b2v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b2v[q] = *reinterpret_cast<const float4*>(a.bias + wn * 32 + 8 * q + 4 * lhi);
+
+    // ---- weight slots of phases 2 and 3: slot s < 9 = tap s of the 3x3 (its two 32-channel chunks), slot 9 + nc = tail chunk nc
+    char* ring = smem + Y1_BYTES;
+    const char* __restrict__ w2g = reinterpret_cast<const char*>(a.w);
+    const char* __restrict__ w3g = reinterpret_cast<const char*>(a.w2);
+    const unsigned wlane = (unsigned)(wave * 1024 + lane * 16);
+    auto issue_slot = [&](int s) {
+        char* dst = ring + (s % NS) * SLOT + wave * 1024;
+        if (s < NTAP) {
+#pragma unroll
+            for (int cc = 0; cc < KC2; ++cc) {                  // conv3.hip's blocks are ordered [chunk][tap]: two 8 KiB pieces
+                const char* g = w2g + (long long)(cc * NTAP + s) * (P * ROWB) + wlane;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(g + i * 4096), (lds_void*)(dst + cc * (P * ROWB) + i * 4096), 16, 0, 0);
+            }
+        } else {
+            const char* g = w3g + (long long)(s - NTAP) * SLOT + wlane;
+#pragma unroll
+            for (int i = 0; i < LS; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(g + i * 4096), (lds_void*)(dst + i * 4096), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_slot(s);
+    // Ring protocol.  Iteration s: [barrier: slot s is published, slot s-1's buffer is free] -> issue slot s + NS - 1 -> multiply
+    // -> WAIT for slot s + 1 (younger slots stay in flight) -> [stores of the iteration].  The wait stands BEFORE the iteration's
+    // own stores, so it only ever covers stores that are a whole iteration old.
+    auto wait_slot = [&](int nxt) {                             // slots issued by now: up to min(nxt + NS - 2, NSLOT - 1)
+        if (nxt >= NSLOT) return;
+        const int younger = (nxt + NS - 2 < NSLOT ? nxt + NS - 2 : NSLOT - 1) - nxt;
+        wait_vm(younger * LS);
+    };
+
+    // ---- accumulators -> y1 [KC2][PROWS][128 B] (rows = patch pixels, conv3.hip's format).  acc[4*q + e] = channel
+    //      nb*32 + 8*q + 4*lhi + e of patch row mb*32 + l31; rows outside the image are the 3x3's zero padding.
+    char* sY1 = smem;
+    auto put_y1 = [&](const f32x16& acc, int nb, int mb) {
+        const int prow = mb * 32 + l31;
+        const int py = prow / PW, px = prow - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool live = prow < PH * PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const int sw = (prow >> 1) & 7;
+        char* row = sY1 + (nb * PROWS + prow) * ROWB + lhi * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            half4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[4 * q + e] * a.acc_scale0;        // (bias inside: accumulator start value)
+                x = x < 0.f ? 0.f : x;                          // NaN stays NaN (torch's ReLU)
+                x = live ? x : 0.f;
+                h[e] = (_Float16)x;
+                l[e] = (_Float16)(x - (float)h[e]);
+            }
+            *reinterpret_cast<half4*>(row + ((q ^ sw) << 4)) = h;
+            *reinterpret_cast<half4*>(row + (((q + 4) ^ sw) << 4)) = l;
+        }
+    };
+    put_y1(acc1[0], 0, wave);
+    put_y1(acc1[1], 1, wave);
+    if (MB1 == 6) put_y1(acc1[NB1 - 1], xnb, xmb);
+    f32x16 acc2[MI];
+    {
+        const float inv = 1.f / a.acc_scale;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc2[mi][4 * q + 0] = b2v[q].x * inv; acc2[mi][4 * q + 1] = b2v[q].y * inv;
+                acc2[mi][4 * q + 2] = b2v[q].z * inv; acc2[mi][4 * q + 3] = b2v[q].w * inv;
+            }
+    }
+    wait_vm((NS - 2) * LS);                                     // slot 0 (only slots 0 .. NS-2 are issued)
+
+    // ================================================================= phase 2: the 3x3 on y1
+    int prow0[MI];                                              // patch row of tap (0,0) of this lane's pixels
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) prow0[mi] = crow[mi] - PW - 1;
+    const int b_row0 = wn * (P / 2) + l31;                      // this wave's 32 output channels of the 3x3
+
+#pragma unroll
+    for (int s = 0; s < NTAP; ++s) {
+        lds_barrier();                                          // slot s landed for every wave; y1 complete (s = 0); slot s-1's buffer is free
+        if (s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
+        const char* sB = ring + (s % NS) * SLOT;
+        const int shift = (s / 3) * PW + (s % 3);
+#pragma unroll
+        for (int cc = 0; cc < KC2; ++cc)
+#pragma unroll
+            for (int kk = 0; kk < CH / 16; ++kk) {
+                const int g = kk * 2 + lhi;
+                half8 af[2][MI], bf[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int prow = prow0[mi] + shift;
+                        af[pl][mi] = *reinterpret_cast<const half8*>(sY1 + (cc * PROWS + prow) * ROWB + (((g + 4 * pl) ^ ((prow >> 1) & 7)) << 4));
+                    }
+                    bf[pl] = *reinterpret_cast<const half8*>(sB + (cc * P + b_row0) * ROWB + (((g + 4 * pl) ^ fswz) << 4));
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[1][mi], acc2[mi], 0, 0, 0);
+                    acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1], af[0][mi], acc2[mi], 0, 0, 0);
+                    acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[0][mi], acc2[mi], 0, 0, 0);
+                }
+            }
+        wait_slot(s + 1);
+    }
+    lds_barrier();                                              // every wave is done with y1: y2 may overwrite it
+
+    // ---- accumulators -> y2 [KC2][BM][128 B] (rows = tile pixels).  acc2[mi][4*q + e] = channel wn*32 + 8*q + 4*lhi + e
+    char* sY2 = smem;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int p = wm * (MI * 32) + mi * 32 + l31;
+        const int sw = (p >> 1) & 7;
+        char* row = sY2 + (wn * BM + p) * ROWB + lhi * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            half4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc2[mi][4 * q + e] * a.acc_scale;     // (bias inside)
+                x = x < 0.f ? 0.f : x;
+                h[e] = (_Float16)x;
+                l[e] = (_Float16)(x - (float)h[e]);
+            }
+            *reinterpret_cast<half4*>(row + ((q ^ sw) << 4)) = h;
+            *reinterpret_cast<half4*>(row + (((q + 4) ^ sw) << 4)) = l;
+        }
+    }
+
+    float* sB3 = reinterpret_cast<float*>(smem + Y2_BYTES);    // [C] tail bias / scale: the part of y1's region y2 leaves free
+    sB3[tid] = b3_mine * (1.f / a.tail_acc_scale);
+
+    // ================================================================= phase 3: the tail 1x1 + residual + ReLU (+ skip adds)
+    unsigned m_dense[MI], m_out[MI];
+    bool m_ok[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int p = wm * (MI * 32) + mi * 32 + l31;
+        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+        m_ok[mi] = oy < a.Ho && ox < a.Wo;
+        const unsigned m = m_ok[mi] ? (unsigned)((b * a.Ho + oy) * a.Wo + ox) : 0u;
+        m_dense[mi] = m * (unsigned)(2 * a.tail_cout8);
+        m_out[mi] = m * (unsigned)a.out_stride_c + (unsigned)a.out_c_off;
+    }
+    const int p_row0 = wm * (MI * 32) + l31;                    // + mi*32: pixel rows of y2
+    const int c_row0 = wn * 32 + l31;                           // channel rows of a tail chunk
+    _Float16* __restrict__ outp = reinterpret_cast<_Float16*>(a.out);
+
+#pragma unroll
+    for (int nc = 0; nc < NCH3; ++nc) {
+        const int s = NTAP + nc;
+        lds_barrier();                                          // slot s landed for every wave; y2 complete (nc = 0); slot s-1's buffer is free
+        if (s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
+        const char* sW = ring + (s % NS) * SLOT;
+        f32x16 acc3[MI];                                        // start value b3 / scale: rows = channels nc*64 + wn*32 + 8*q + 4*lhi + e
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b4 = *reinterpret_cast<const float4*>(sB3 + nc * 64 + wn * 32 + 8 * q + 4 * lhi);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                acc3[mi][4 * q + 0] = b4.x; acc3[mi][4 * q + 1] = b4.y; acc3[mi][4 * q + 2] = b4.z; acc3[mi][4 * q + 3] = b4.w;
+            }
+        }
+#pragma unroll
+        for (int kc = 0; kc < KC2; ++kc)
+#pragma unroll
+            for (int kk = 0; kk < CH / 16; ++kk) {
+                const int g = kk * 2 + lhi;
+                half8 pf[2][MI], wf[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        pf[pl][mi] = *reinterpret_cast<const half8*>(sY2 + (kc * BM + p_row0 + mi * 32) * ROWB + (((g + 4 * pl) ^ fswz) << 4));
+                    wf[pl] = *reinterpret_cast<const half8*>(sW + (kc * 64 + c_row0) * ROWB + (((g + 4 * pl) ^ fswz) << 4));
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    acc3[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], pf[1][mi], acc3[mi], 0, 0, 0);
+                    acc3[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1], pf[0][mi], acc3[mi], 0, 0, 0);
+                    acc3[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], pf[0][mi], acc3[mi], 0, 0, 0);
+                }
+            }
+        wait_slot(s + 1);                                       // before this chunk's stores: covers the previous chunk's (old) stores only
+        // ---- register epilogue (convp.hip): half-wave swap -> acc3[mi][8*j .. 8*j+7] = channels n_lane + 16*j .. +7 of the pixel
+        const int n_lane = nc * 64 + wn * 32 + 8 * lhi;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xf = acc3[mi][8 * j + e], yf = acc3[mi][8 * j + 4 + e];   // (bit_cast of a vector ELEMENT lvalue reads element 0)
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf), __float_as_uint(yf), false, false);
+                    const unsigned s0 = sw[0], s1 = sw[1];
+                    acc3[mi][8 * j + e] = a.tail_acc_scale * __uint_as_float(s0);       // (bias inside)
+                    acc3[mi][8 * j + 4 + e] = a.tail_acc_scale * __uint_as_float(s1);
+                }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)                          // + x, from the registers filled in phase 1
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc3[mi][8 * j + e] += (float)rs[nc][mi][j][0][e] + (float)rs[nc][mi][j][1][e];
+        if (a.relu) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[mi][r] = acc3[mi][r] < 0.f ? 0.f : acc3[mi][r];
+        }
+        auto add_tensor = [&](const _Float16* __restrict__ tsr) {       // post-ReLU skip adds of the last block of a layer
+            half8 h[MI][2][2];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        h[mi][j][pl] = *reinterpret_cast<const half8*>(tsr + m_dense[mi] + (unsigned)(n_lane + 16 * j) + pl * a.tail_cout8);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc3[mi][8 * j + e] += (float)h[mi][j][0][e] + (float)h[mi][j][1][e];
+        };
+        if (a.add1) add_tensor(a.add1);
+        if (a.add2) add_tensor(a.add2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!m_ok[mi]) continue;
+                _Float16* op = outp + (m_out[mi] + (unsigned)(n_lane + 16 * j));
+                half8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h[e] = (_Float16)acc3[mi][8 * j + e];
+                    l[e] = (_Float16)(acc3[mi][8 * j + e] - (float)h[e]);
+                }
+                *reinterpret_cast<half8*>(op) = h;
+                *reinterpret_cast<half8*>(op + a.out_lo) = l;
+            }
+    }
+    SMAP_TL_END(a)
+}
+
+template <int TH>
+hipError_t launchb(const ConvArgs& a, hipStream_t st)
+{
+    const int B = a.M / (a.Ho * a.Wo);
+    const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + TH - 1) / TH;
+    hipLaunchKernelGGL((bottleneck_kernel<TH>), dim3(tiles_x * tiles_y * B), dim3(256), 0, st, a, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// tile ids 90..99: the fused identity Bottleneck (P = 64 planes; *bm = output pixels per workgroup, *bn = P, *bn2 = tail chunk)
+int smap_convb_tile_dims(int tile, int* bm, int* bn, int* bn2)
+{
+    switch (tile) {
+        case 90: *bm = 64; *bn = 64; *bn2 = 64; return 0;       // 4 x 16 pixel tiles
+        case 91: *bm = 128; *bn = 64; *bn2 = 64; return 0;      // 8 x 16
+        default: return -1;
+    }
+}
+
+hipError_t smap_launch_convb(const ConvArgs& a, int tile, hipStream_t st)
+{
+    if (!a.x3 || a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.up || a.out_fp32 || !a.w0 || !a.w2 || a.Cin != 64 ||
+        a.tail_cout8 != 256 || a.head_cin != 256 || a.H != a.Ho || a.W != a.Wo)
+        return hipErrorInvalidValue;
+    switch (tile) {
+        case 90: return launchb<4>(a, st);
+        case 91: return launchb<8>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}

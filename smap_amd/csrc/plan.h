@@ -32,6 +32,11 @@ struct ConvArgs {
     int tail_cout8;          // channels the tail writes (multiple of 8)
     int tail_chunks;         // tail cout_pad / BN2
     float tail_acc_scale;
+    // fused leading 1x1 (convb.hip, tile ids 90..99): the op's INPUT tensor then has head_cin channels, w / bias are the 3x3's
+    const _Float16* w0;      // packed [k chunk][P rows][128 B] weights of the leading 1x1, or null
+    const float* bias0;      // [P] fp32
+    int head_cin;            // channels of the block's input (= of its output)
+    float acc_scale0;
 #ifdef SMAP_TRACE
     long long* dbg;          // diagnostics build only (tools/build_ablate.py --trace): per-workgroup phase stamps
 #endif
@@ -68,6 +73,8 @@ int smap_convp_tile_dims(int tile, int* bm, int* bn);                       // c
 hipError_t smap_launch_convp(const ConvArgs& a, int tile, hipStream_t st);
 int smap_convf_tile_dims(int tile, int* bm, int* bn, int* bn2);             // convf.hip (tile ids 80..89, 3x3 + fused 1x1 tail)
 hipError_t smap_launch_convf(const ConvArgs& a, int tile, hipStream_t st);
+int smap_convb_tile_dims(int tile, int* bm, int* bn, int* bn2);             // convb.hip (tile ids 90..99, whole identity Bottleneck)
+hipError_t smap_launch_convb(const ConvArgs& a, int tile, hipStream_t st);
 
 #ifdef SMAP_TIMELINE
 // every workgroup of a conv kernel calls these two (first / last statement): 100 MHz device-wide clock

@@ -49,9 +49,14 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          60: (128, 256), 61: (256, 128), 62: (128, 128), 63: (128, 64), 64: (128, 64), 65: (128, 64),
          66: (128, 256), 68: (128, 128), 69: (128, 128), 70: (128, 128),
          # 80..82: csrc/convf.hip, a Bottleneck's 3x3 (BN = all of its planes) with the following 1x1 fused in (TAIL_BN)
-         80: (128, 64), 81: (128, 64), 82: (128, 128)}
+         80: (128, 64), 81: (128, 64), 82: (128, 128),
+         # 90..91: csrc/convb.hip, a whole identity Bottleneck of 64 planes (1x1 -> 3x3 -> 1x1 + residual) per 4x16 / 8x16 pixel tile
+         90: (64, 64), 91: (128, 64)}
 TAIL_DEFAULT = {}                          # Bottleneck planes -> fused tile id (empty: every block runs c2 and c3 as two launches)
-TAIL_BN = {80: 64, 81: 128, 82: 64}      # output channels per chunk of the fused 1x1 (csrc/convf.hip::smap_convf_tile_dims)
+TAIL_BN = {80: 64, 81: 128, 82: 64, 90: 64, 91: 64}      # output channels per chunk of the fused 1x1 (csrc/convf.hip::smap_convf_tile_dims)
+# Bottleneck planes -> tile id of the WHOLE-block launch (csrc/convb.hip) for stride-1 identity blocks in split precision; {} = off.
+# SMAP_BLOCK="64:91" overrides (A/B hook; "" = off).
+BLOCK_DEFAULT = {}
 # (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
 #  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)
 
@@ -101,8 +106,8 @@ def tile_legal(tile, *, cout, cout_pad=None, plain3=True, up=False, out_fp32=Fal
     """Can tile id `tile` run an op with these properties?  Mirrors csrc/plan.hip::validate."""
     if 30 <= tile < 40:
         return plain3
-    if 80 <= tile < 90:
-        return False                     # only Graph.conv_tail builds these
+    if 80 <= tile < 100:
+        return False                     # only Graph.conv_tail / Graph.conv_block build these
     if 60 <= tile < 80:
         cp = cout_pad if cout_pad is not None else _rup(cout, TILES[tile][1])
         return not up and not out_fp32 and cout % 8 == 0 and cp <= 2048
@@ -145,7 +150,7 @@ def pick_tile_x3(M, cout, key=None):
 def tile_family(tile):
     """Which kernel a tile id selects: "halo" (csrc/conv3.hip; csrc/convf.hip = the same 3x3 with a fused 1x1 tail),
     "persist" (csrc/convp.hip) or "igemm" (csrc/conv.hip)."""
-    return "halo" if (30 <= tile < 40 or 80 <= tile < 90) else "persist" if 60 <= tile < 80 else "igemm"
+    return "halo" if (30 <= tile < 40 or 80 <= tile < 100) else "persist" if 60 <= tile < 80 else "igemm"
 
 
 def tile_bk(tile, x3):
@@ -499,6 +504,48 @@ class Graph:
             w_ref=w3 if self.keep_ref else None, b_ref=b3 if self.keep_ref else None)))
         return out
 
+    def conv_block(self, name, pre, x, tile, add1=None, add2=None):
+        """A whole stride-1 identity Bottleneck (smap.py:48-77: conv_bn_relu1 1x1 -> conv_bn_relu2 3x3 -> conv_bn_relu3 1x1, + x,
+        ReLU, + add1, + add2) as ONE launch (csrc/convb.hip, tile ids 90..99, split precision): x is read once, the two
+        intermediates and the residual never leave the CU."""
+        assert self.x3, "the whole-block kernel has a split-precision instance only"
+        w1, b1 = fold_conv_bn(self.sd, pre + ".conv_bn_relu1")
+        w3, b3 = fold_conv_bn(self.sd, pre + ".conv_bn_relu2")
+        wt, bt = fold_conv_bn(self.sd, pre + ".conv_bn_relu3")
+        P, C = w1.shape[0], w1.shape[1]
+        bn2 = TAIL_BN[tile]
+        assert P == 64 and C == 4 * P == x.C == wt.shape[0] and w3.shape[:2] == (P, P) and w3.shape[2] == 3 and wt.shape[1] == P
+        M = self.B * x.H * x.W
+        hi, lo, sc1 = split_f16(w1.reshape(P, C))
+        wk1 = pack_halo_rows(torch.stack([hi, lo]), P, 1, C, True)                    # [1][C/32][1][P rows][128 B]
+        hi, lo, sc3 = split_f16(w3.permute(0, 2, 3, 1).reshape(P, 9 * P))
+        wk3 = pack_halo_rows(torch.stack([hi, lo]), P, 9, P, True)                    # [1][P/32][9 taps][P rows][128 B]
+        hi, lo, sct = split_f16(wt.reshape(C, P))
+        wkt = pack_halo_rows(torch.stack([hi, lo]), bn2, 1, P, True)                  # [C/64][P/32][1][64 rows][128 B]
+        out = self.tensor(name, x.H, x.W, C)
+        self.flops += 2 * M * (P * C + P * 9 * P + C * P)
+        self.alg_bytes += (x.nbytes + out.nbytes + (wk1.numel() + wk3.numel() + wkt.numel()) * 2
+                           + sum(t.nbytes for t in (add1, add2) if t is not None))
+        keep = self.keep_ref
+        self.ops.append(Op(OP_CONV, out=out, inp=x, res=x, add1=add1, add2=add2, p=dict(
+            Cin=P, in_c_off=0, Cout=P, ksize=3, stride=1, pad=1, relu=1, cout_pad=P, tile=tile, out_fp32=0,
+            w_off=self._add_w(wk3), bias_off=self._add_w(b3.to(torch.float32)), acc_scale=sc3, frames=self.B, w_pairs=0,
+            head=dict(cin=C, w_off=self._add_w(wk1), bias_off=self._add_w(b1.to(torch.float32)), acc_scale=sc1,
+                      w_ref=w1 if keep else None, b_ref=b1 if keep else None),
+            tail=dict(cout=C, cout_pad=C, w_off=self._add_w(wkt), bias_off=self._add_w(bt.to(torch.float32)), acc_scale=sct,
+                      w_ref=wt if keep else None, b_ref=bt if keep else None),
+            w_ref=w3 if keep else None, b_ref=b3 if keep else None)))
+        return out
+
+    def block_tile(self, planes, stride, has_ds):
+        """Tile id of the whole-block launch for this Bottleneck, or None.  Identity blocks (no shortcut conv) of stride 1 in
+        split precision only; SMAP_BLOCK="64:91" chooses per width (A/B hook), default BLOCK_DEFAULT."""
+        if stride != 1 or has_ds or not self.x3:
+            return None
+        spec = os.environ.get("SMAP_BLOCK")
+        table = BLOCK_DEFAULT if spec is None else {int(k): int(v) for k, v in (kv.split(":") for kv in spec.split(",") if ":" in kv)}
+        return table.get(planes)
+
     # -- the network (smap.py:313-353 structure, :403-419 data flow)
     def _build(self):
         B, H, W, sd = self.B, self.H, self.W, self.sd
@@ -534,6 +581,9 @@ class Graph:
 
     def _bottleneck(self, pre, x, planes, stride, has_ds, add1=None, add2=None):
         # Bottleneck (smap.py:48-77): stride on the 3x3, shortcut 1x1 stride-s when shape changes
+        blk = self.block_tile(planes, stride, has_ds)
+        if blk is not None:         # c1 + c2 + c3 + residual in one launch (csrc/convb.hip)
+            return self.conv_block(pre + ".c3", pre, x, blk, add1=add1, add2=add2)
         idn = self.conv(pre + ".downsample", [pre + ".downsample"], x, 1, stride, relu=False) if has_ds else x
         y = self.conv(pre + ".c1", [pre + ".conv_bn_relu1"], x, 1, 1, relu=True)
         tail = self.tail_tile(planes, stride)
@@ -709,6 +759,9 @@ class Graph:
                     tl = p["tail"]
                     o.tail_cout, o.tail_cout_pad, o.tail_acc_scale = tl["cout"], tl["cout_pad"], tl["acc_scale"]
                     o.tail_w_off, o.tail_bias_off = tl["w_off"], tl["bias_off"]
+                if "head" in p:
+                    hd = p["head"]
+                    o.head_cin, o.head_acc_scale, o.head_w_off, o.head_bias_off = hd["cin"], hd["acc_scale"], hd["w_off"], hd["bias_off"]
                 o.in_off, o.out_off, o.w_off, o.bias_off = x.off, y.off, p["w_off"], p["bias_off"]
                 for nm in ("res", "add1", "add2"):
                     t = getattr(op, nm)

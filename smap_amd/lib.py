@@ -42,6 +42,7 @@ class SmapOp(C.Structure):
         ("flip_from", C.c_int32), ("w_pairs", C.c_int32), ("status_off", C.c_int32),
         ("tail_cout", C.c_int32), ("tail_cout_pad", C.c_int32), ("tail_acc_scale", C.c_float),
         ("tail_w_off", C.c_int64), ("tail_bias_off", C.c_int64),
+        ("head_cin", C.c_int32), ("head_acc_scale", C.c_float), ("head_w_off", C.c_int64), ("head_bias_off", C.c_int64),
     ]
 
 

@@ -361,6 +361,145 @@ TAIL_CASES = [
 ]
 
 
+def _run_block(B, H, W, tile, use_adds, seed=0, mode="full", relu=True):
+    """One whole-Bottleneck op (csrc/convb.hip, split precision): relu(W3 relu(W2 * relu(W1 x + b1) + b2) + b3 + x) [+ adds],
+    P = 64 planes, C = 256 channels.  `mode` switches parts of the block off so that a failure names the phase
+    (tools/debug/convb_probe.py): "residual" (W3 = b3 = 0: out = relu(x)), "no_c1" (W1 = 0: y1 = relu(b1) inside the image),
+    "centre_tap" (only the centre tap of the 3x3 is non-zero: no shifted views), "full"."""
+    from smap_amd import lib as L
+    from smap_amd.engine import TAIL_BN, ZERO_PAGE, pack_halo_rows, split_f16
+    lib = L.load()
+    P, Cc = 64, 256
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, H, W, Cc, generator=g)
+    w1 = torch.randn(P, Cc, 1, 1, generator=g) * (1.0 / Cc) ** 0.5
+    b1 = torch.randn(P, generator=g) * 0.5
+    w3 = torch.randn(P, P, 3, 3, generator=g) * (1.0 / (9 * P)) ** 0.5
+    b3 = torch.randn(P, generator=g) * 0.5
+    wt = torch.randn(Cc, P, 1, 1, generator=g) * (1.0 / P) ** 0.5
+    bt = torch.randn(Cc, generator=g)
+    a1 = torch.randn(B, H, W, Cc, generator=g) if use_adds else None
+    a2 = torch.randn(B, H, W, Cc, generator=g) if use_adds else None
+    if mode == "residual":
+        wt, bt = wt * 0, bt * 0
+    elif mode == "no_c1":
+        w1 = w1 * 0
+    elif mode == "centre_tap":
+        m = torch.zeros(3, 3)
+        m[1, 1] = 1
+        w3 = w3 * m
+    bn2 = TAIL_BN[tile]
+    hi, lo, sc1 = split_f16(w1.reshape(P, Cc).double())
+    wk1 = pack_halo_rows(torch.stack([hi, lo]), P, 1, Cc, True)
+    hi, lo, sc3 = split_f16(w3.permute(0, 2, 3, 1).reshape(P, 9 * P).double())
+    wk3 = pack_halo_rows(torch.stack([hi, lo]), P, 9, P, True)
+    hi, lo, sct = split_f16(wt.reshape(Cc, P).double())
+    wkt = pack_halo_rows(torch.stack([hi, lo]), bn2, 1, P, True)
+    al = lambda n: (n + 255) // 256 * 256
+    raw8 = lambda t: t.contiguous().view(torch.uint8).reshape(-1)
+    chunks, woffs, cur = [raw8(wk3), raw8(b3), raw8(wkt), raw8(bt), raw8(wk1), raw8(b1)], [], 0
+    for c in chunks:
+        woffs.append(cur)
+        cur += al(c.numel())
+    blob = torch.zeros(cur, dtype=torch.uint8)
+    for c, o in zip(chunks, woffs):
+        blob[o:o + c.numel()] = c
+    parts, offs, cur = [x, a1, a2], [], ZERO_PAGE
+    stored = [_split(t) if t is not None else None for t in parts]
+    for t in stored:
+        offs.append(cur if t is not None else -1)
+        cur += al(t.numel() * 2) if t is not None else 0
+    out_off = cur
+    arena = torch.zeros(out_off + al(B * H * W * Cc * 4) + 256, dtype=torch.uint8)
+    for t, o in zip(stored, offs):
+        if t is not None:
+            arena[o:o + t.numel() * 2] = raw8(t)
+    op = L.SmapOp()
+    op.kind, op.B, op.H, op.W, op.Cin, op.in_stride_c, op.in_c_off = 0, B, H, W, P, Cc * 2, 0
+    op.Ho, op.Wo, op.Cout, op.ksize, op.stride, op.pad, op.relu = H, W, P, 3, 1, 1, int(relu)
+    op.cout_pad, op.out_stride_c, op.out_c_off, op.out_fp32, op.tile = P, Cc * 2, 0, 0, tile
+    op.in_off, op.out_off, op.w_off, op.bias_off = offs[0], out_off, woffs[0], woffs[1]
+    op.res_off, op.add1_off, op.add2_off = offs[0], offs[1], offs[2]
+    op.precision, op.acc_scale = 1, sc3
+    op.tail_cout, op.tail_cout_pad, op.tail_acc_scale, op.tail_w_off, op.tail_bias_off = Cc, Cc, sct, woffs[2], woffs[3]
+    op.head_cin, op.head_acc_scale, op.head_w_off, op.head_bias_off = Cc, sc1, woffs[4], woffs[5]
+    for i in range(3):
+        op.aux_off[i] = -1
+    op.ext_off = -1
+    h = C.c_void_p()
+    L.check(lib.smap_plan_create(C.byref(op), 1, C.byref(h)), "create")
+    arena_d, blob_d = arena.to(DEV), blob.to(DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.smap_plan_run(h, None, C.c_void_p(arena_d.data_ptr()), C.c_void_p(blob_d.data_ptr()), None, st), "run")
+    torch.cuda.synchronize()
+    lib.smap_plan_destroy(h)
+    got = arena_d[out_off:out_off + B * H * W * Cc * 4].cpu().view(torch.float16).view(B, H, W, 2, Cc).float()
+    got = got[..., 0, :] + got[..., 1, :]
+    xin = x.double().permute(0, 3, 1, 2)
+    y = F.relu(F.conv2d(xin, w1.double(), b1.double()))
+    y = F.relu(F.conv2d(y, w3.double(), b3.double(), padding=1))
+    y = (F.conv2d(y, wt.double(), bt.double()) + xin).permute(0, 2, 3, 1)
+    if relu:
+        y = F.relu(y)
+    if use_adds:
+        y = y + a1.double() + a2.double()
+    return got, y.float()
+
+
+BLOCK_CASES = [
+    # B, H,  W,  tile, adds
+    (2, 16, 32, 90, False),
+    (1, 13, 52, 90, True),           # ragged pixel tiles in both directions (4 x 16 tiles)
+    (3, 10, 14, 90, False),          # narrower than one tile
+    (2, 16, 32, 91, False),
+    (1, 13, 52, 91, True),           # ragged 8 x 16 tiles
+    (3, 10, 14, 91, True),
+    (1, 32, 208, 91, False),         # a full row of 13 tiles
+]
+
+
+@pytest.mark.parametrize("mode", ["full", "residual", "no_c1", "centre_tap"])
+@pytest.mark.parametrize("case", BLOCK_CASES, ids=lambda c: "x".join(map(str, c[:4])) + ("+adds" if c[4] else ""))
+def test_whole_bottleneck_launch(case, mode):
+    """csrc/convb.hip: the three convs of an identity Bottleneck + residual in one launch against the f64 evaluation of the
+    same block on the same split-precision operands; the partial modes name the phase when something is off."""
+    got, ref = _run_block(*case, seed=(hash(case) + len(mode)) % 1000, mode=mode)
+    err = (got - ref).abs()
+    assert torch.isfinite(got).all()
+    tol = 3e-6 * ref.abs().max().item() + 1e-6
+    assert err.max().item() < tol, (err.max().item(), tol, np.unravel_index(err.argmax().item(), err.shape))
+
+
+@pytest.mark.parametrize("spec", ["64:90", "64:91"])
+def test_small_schedule_with_whole_bottleneck_launches(golden_dir, small, monkeypatch, spec):
+    """Identity Bottlenecks of layer1 as ONE launch each (csrc/convb.hip): every stored tensor against the f64 interpretation
+    of the SAME schedule, and the outputs against the golden outputs of the reference model."""
+    from smap_amd.engine import BackboneEngine, Graph
+    from oracle.graph_interp import run_graph
+    _, sd = small
+    z = np.load(f"{golden_dir}/backbone_small.npz")
+    x = torch.from_numpy(z["x"])
+    monkeypatch.setenv("SMAP_BLOCK", spec)
+    eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision="x3")
+    assert sum(1 for op in eng.graph.ops if op.kind == 0 and "head" in op.p) == 6
+    assert not any(t.name.endswith((".c1", ".c2")) for t in eng.graph.tensors if ".layer1.1" in t.name or ".layer1.2" in t.name)
+    outs = [o.cpu() for o in eng.run(x.to(DEV))]
+    torch.cuda.synchronize()
+    g = Graph(sd, 2, 64, 96, keep_ref=True, precision="x3")
+    with torch.no_grad():
+        *ref, T = run_graph(g, x.double(), quantize=False, keep=True)
+    worst = []
+    for t in eng.graph.tensors:
+        got = eng.read_tensor(t.name).cpu().double().permute(0, 3, 1, 2)
+        want = T[t.name].double()
+        c = want.shape[1]
+        worst.append(((got[:, :c] - want).abs().max().item() / (want.abs().max().item() + 1e-6), t.name))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 2e-5, worst[:5]
+    for a, k in zip(outs, ("hms", "det_d", "root_d")):
+        assert np.abs(a.numpy() - z[k]).max() < 2e-5 * np.abs(z[k]).max(), k
+
+
 @pytest.mark.parametrize("x3", [False, True], ids=["f16", "x3"])
 @pytest.mark.parametrize("case", TAIL_CASES, ids=lambda c: "x".join(map(str, c[:7])))
 def test_fused_bottleneck_tail(case, x3):

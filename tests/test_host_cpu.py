@@ -121,6 +121,13 @@ def test_shipped_launcher_settings_are_plannable():
             if b[0] > a[1]:
                 break
             assert a[3] <= b[2] or b[3] <= a[2] or a[1] < b[0]
+    # the LIBRARY agrees with the allocator's idea of windows and zero pages (smap_plan_create runs without a GPU): a library
+    # built with another window size than engine.WINDOW refuses these ops -- round 4 lost a GPU visit to exactly that
+    import ctypes as C
+    from smap_amd import lib as L
+    h = C.c_void_p()
+    assert L.load().smap_plan_create(g.emit(), len(g.ops), C.byref(h)) == 0
+    L.load().smap_plan_destroy(h)
     with pytest.raises(ArenaTooLarge, match="smaller batch"):
         Graph(sd, 32, 512, 832, precision="x3", flip_pair=list(range(43))).allocate()
     with pytest.raises(ValueError):
