@@ -12,9 +12,9 @@
 //
 // Work per workgroup (4 waves, 80 KiB of LDS, two workgroups per CU so that one streams x while the other multiplies):
 // a TH x 16 tile of output pixels (TH = 4 | 8).
-//   phase 1  c1 on the (TH+2) x 18 halo patch (rows of the patch = GEMM rows, rounded up to PROWS = 128 | 192): K = C in 32-channel
-//            chunks, each chunk staged as [PROWS][hi32 | lo32] (x) + [P][hi32 | lo32] (W1) by LDS-DMA in a ring over the WHOLE
-//            80 KiB (y1 does not exist yet); accumulators -> relu -> hi/lo -> y1 in conv3.hip's patch layout, rows outside the
+//   phase 1  c1 on the (TH+2) x 18 halo patch (rows of the patch = GEMM rows, rounded up to PROWS = 128 | 192): K = C in 16-channel
+//            stages, each staged as [PROWS][hi16 | lo16] (x) + [P][hi16 | lo16] (W1) by LDS-DMA in a ring of 6 | 5 stages over the
+//            WHOLE 80 KiB (y1 does not exist yet; x comes from HBM: depth is what this phase lives on); accumulators -> relu -> hi/lo -> y1 in conv3.hip's patch layout, rows outside the
 //            image forced to 0 (the 3x3 pads y1, not x).  The halo is recomputed: +41 % (+69 %) of c1 = +10 % (+16 %) MFMA work.
 //   phase 2  the 3x3 as nine shifted views of y1 (conv3.hip), one 16 KiB weight slot per tap (both 32-channel chunks) in a ring
 //            behind y1; accumulators -> relu -> hi/lo -> y2, written over y1 once every wave is done with it.
@@ -26,7 +26,8 @@
 //
 // Weights (smap_amd/engine.py::Graph.conv_block, all three in pack_halo_rows' format: 128-byte rows = [hi32 | lo32] of one
 // 32-channel chunk, slot s of row r = logical granule s ^ ((r >> 1) & 7)):
-//   W1  [8 chunks][64 rows]            W2  [2 chunks][9 taps][64 rows]            W3  [4 n chunks][2 chunks][64 rows]
+//   W2  [2 chunks][9 taps][64 rows]            W3  [4 n chunks][2 chunks][64 rows]
+// and W1 in 16-channel stages (engine.pack_rows16): [16 stages][64 rows][64 B = hi16 | lo16], slot s of row r = granule s ^ ((r >> 2) & 3).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "smap_hip.h"
@@ -68,25 +69,37 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
     constexpr int BM = TH * TW;                                 // output pixels of the tile: 64 | 128
     constexpr int MI = BM / 64;                                 // 32-pixel blocks per wave in phases 2, 3 (2 x 2 waves): 1 | 2
     static_assert(MB1 == 4 || MB1 == 6, "TH = 4 or 8");
-    constexpr int KC1 = C / CH, KC2 = P / CH;                   // K chunks: 8 (leading 1x1), 2 (3x3 per tap, tail)
+    constexpr int KC2 = P / CH;                                 // 32-channel chunks of the 3x3's and the tail's K: 2
     constexpr int Y1_BYTES = KC2 * PROWS * ROWB;                // 32 | 48 KiB
     constexpr int Y2_BYTES = KC2 * BM * ROWB;                   // 16 | 32 KiB: y2 takes over the start of y1's region
     static_assert(Y2_BYTES + C * 4 <= Y1_BYTES && C == 256, "room for the tail-bias table; one bias value per thread");
     constexpr int LDS_BYTES = 80 * 1024;
-    constexpr int XS = PROWS * ROWB, WS1 = P * ROWB;            // phase-1 stage = x chunk (16 | 24 KiB) + W1 chunk (8 KiB)
+    // phase 1 stages 16 channels at a time (64-byte rows [hi16 | lo16], one MFMA K step per stage): a 12 | 16 KiB stage, so that
+    // 5 | 4 of them are in flight behind the one being multiplied -- x comes from HBM, and with 32-channel stages (3 | 2 of them in
+    // 80 KiB) a workgroup waited a full memory latency per stage (profiles/r4_v2_*: 172 us per block)
+    constexpr int CH1 = 16, ROW1 = 64, KS1 = C / CH1;           // 16 stages
+    constexpr int XS = PROWS * ROW1, WS1 = P * ROW1;            // phase-1 stage = x rows (8 | 12 KiB) + W1 rows (4 KiB)
     constexpr int ST1 = XS + WS1;
-    constexpr int NS1 = LDS_BYTES / ST1;                        // stages: 3 | 2
-    constexpr int LA = XS / 4096, LB1 = WS1 / 4096, LPT1 = LA + LB1;   // LDS-DMA instructions per thread and stage
-    constexpr int SLOT = KC2 * P * ROWB;                        // 16 KiB weight slot of phases 2 and 3
-    constexpr int NS = (LDS_BYTES - Y1_BYTES) / SLOT;           // ring slots behind y1: 3 | 2
-    constexpr int LS = SLOT / 4096;                             // 4 per thread
-    constexpr int NTAP = 9, NCH3 = C / 64, NSLOT = NTAP + NCH3; // 13 weight slots per tile: 9 taps, 4 tail chunks
+    constexpr int NS1 = LDS_BYTES / ST1;                        // stages: 6 | 5
+    constexpr int LA = XS / 4096, LB1 = WS1 / 4096, LPT1 = LA + LB1;   // LDS-DMA instructions per thread and stage: 2 | 3, + 1
+    constexpr int SLOT = P * ROWB;                              // 8 KiB weight slot of phases 2 and 3: 64 rows x one 32-channel chunk
+    constexpr int NS = (LDS_BYTES - Y1_BYTES) / SLOT;           // ring slots behind y1: 6 | 4
+    constexpr int LS = SLOT / 4096;                             // 2 per thread
+    constexpr int NTAP = 9, NCH3 = C / 64;
+    constexpr int NS2 = NTAP * KC2, NS3 = NCH3 * KC2, NSLOT = NS2 + NS3;   // 18 (tap, chunk) slots + 8 (tail chunk, k chunk) slots per tile
     static_assert(NS1 >= 2 && NS >= 2 && NS1 * ST1 <= LDS_BYTES && Y1_BYTES + NS * SLOT <= LDS_BYTES, "LDS plan");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];   // ONE array: a second __shared__ object makes hipcc drain vmcnt
 
     SMAP_TL_BEGIN
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SMAP_TRACE
+    long long tr_t[8];
+#define TRB(i) tr_t[i] = __builtin_amdgcn_s_memtime()
+#else
+#define TRB(i)
+#endif
+    TRB(0);
     int logical;                                                // XCD-aware order (conv.hip): neighbouring tiles share an L2
     {
         const int nblk = gridDim.x, bid = blockIdx.x;
@@ -104,28 +117,29 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
     // ================================================================= phase 1: y1 = relu(W1 x + b1) on the halo patch
     const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
     const char* __restrict__ w1g = reinterpret_cast<const char*>(a.w0);
-    const int lrow = lane >> 3, lslot = lane & 7;
-    const int srow = wave * 8 + lrow;
-    const int gl = lslot ^ ((srow >> 1) & 7);                   // logical granule this lane fetches: 0..3 hi, 4..7 lo
+    // a wave-wide LDS-DMA covers 16 rows x 64 B: lane -> row lane / 4, 16-byte slot lane % 4; slot s of row r holds logical granule
+    // s ^ ((r >> 2) & 3) (0, 1 = hi channels 0..7, 8..15 of the stage; 2, 3 = lo): conflict-free ds_read_b128 (conv.hip, BK = 32)
+    const int srow = wave * 16 + (lane >> 2);
+    const int gl = (lane & 3) ^ ((srow >> 2) & 3);
     unsigned a_off[LA];                                         // patch row -> byte offset of its granule (0 = zero page)
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int prow = i * 32 + srow;
+        const int prow = i * 64 + srow;
         const int py = prow / PW, px = prow - py * PW;
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
         a_off[i] = 0;
         if (prow < PH * PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
-            const long long e = ((long long)(b * a.H + iy) * a.W + ix) * a.in_stride_c + (gl & 3) * 8 + (gl >> 2) * a.in_lo;
+            const long long e = ((long long)(b * a.H + iy) * a.W + ix) * a.in_stride_c + (gl & 1) * 8 + (gl >> 1) * a.in_lo;
             a_off[i] = (unsigned)(a.in_off + e * 2);
         }
     }
-    auto issue1 = [&](int st, int kc) {                         // stage st <- K chunk kc of x and of W1
+    auto issue1 = [&](int st, int ks) {                         // stage st <- channels 16 ks .. +15 of x and of W1
         char* sX = smem + st * ST1;
-        const char* gA = arena + (unsigned)(kc * CH * 2);       // invalid rows: zero page + chunk offset
+        const char* gA = arena + (unsigned)(ks * CH1 * 2);      // invalid rows: zero page + stage offset
 #pragma unroll
         for (int i = 0; i < LA; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_off[i]), (lds_void*)(sX + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
-        const char* gW = w1g + (long long)kc * WS1 + (unsigned)(wave * 1024 + lane * 16);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_off[i]), (lds_void*)(sX + (i * 64 + wave * 16) * ROW1), 16, 0, 0);
+        const char* gW = w1g + (long long)ks * WS1 + (unsigned)(wave * 1024 + lane * 16);
 #pragma unroll
         for (int i = 0; i < LB1; ++i)
             __builtin_amdgcn_global_load_lds((gbl_void*)(gW + i * 4096), (lds_void*)(sX + XS + i * 4096 + wave * 1024), 16, 0, 0);
@@ -165,98 +179,85 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
                 acc1[j][4 * q + 2] = b1raw[j][q].z * inv0; acc1[j][4 * q + 3] = b1raw[j][q].w * inv0;
             }
     }
-    const int fswz = (l31 >> 1) & 7;                            // (row >> 1) & 7 of every fragment row = multiple of 32 + l31
+    const int fswz = (l31 >> 1) & 7;                            // (row >> 1) & 7 of every 128-byte fragment row = multiple of 32 + l31
+    TRB(1);
 
+    const int fs4 = (l31 >> 2) & 3;                             // (row >> 2) & 3 of every phase-1 fragment row = multiple of 32 + l31
 #pragma unroll
-    for (int kc = 0; kc < KC1; ++kc) {
-        if (kc + NS1 - 1 <= KC1) wait_vm((NS1 - 2) * LPT1);     // chunk kc has landed; younger stages stay in flight
-        else wait_vm(0);
+    for (int ks = 0; ks < KS1; ++ks) {
+        if (ks + NS1 - 1 <= KS1) wait_vm((NS1 - 2) * LPT1);     // stage ks has landed; younger stages stay in flight
+        else wait_vm((KS1 - 1 - ks) * LPT1);
         lds_barrier();
-        if (kc + NS1 - 1 < KC1) issue1((kc + NS1 - 1) % NS1, kc + NS1 - 1);     // into the stage chunk kc-1 was read from
-        const char* sX = smem + (kc % NS1) * ST1;
+        if (ks + NS1 - 1 < KS1) issue1((ks + NS1 - 1) % NS1, ks + NS1 - 1);     // into the buffer stage ks-1 was read from
+        const char* sX = smem + (ks % NS1) * ST1;
         const char* sW = sX + XS;
-        if ((kc & 1) == wn) {                                   // this wave's residual channels are in this chunk
-            constexpr int nc_of[KC1] = {0, 0, 1, 1, 2, 2, 3, 3};
+        if (((ks >> 1) & 1) == wn) {                            // this wave's residual channels: nc*64 + wn*32 + 16*j + 8*lhi .. = stage 4 nc + 2 wn + j
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int pl = 0; pl < 2; ++pl)
+                    rs[ks >> 2][mi][ks & 1][pl] = *reinterpret_cast<const half8*>(
+                        sX + crow[mi] * ROW1 + (((lhi + 2 * pl) ^ ((crow[mi] >> 2) & 3)) << 4));
+        }
+        half8 wf[2][2], xf[2], xe[2];
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl)
-                        rs[nc_of[kc]][mi][j][pl] = *reinterpret_cast<const half8*>(
-                            sX + crow[mi] * ROWB + ((((2 * j + lhi) + 4 * pl) ^ ((crow[mi] >> 1) & 7)) << 4));
+        for (int pl = 0; pl < 2; ++pl) {
+            const int slot = ((lhi + 2 * pl) ^ fs4) << 4;
+            wf[pl][0] = *reinterpret_cast<const half8*>(sW + l31 * ROW1 + slot);
+            wf[pl][1] = *reinterpret_cast<const half8*>(sW + (32 + l31) * ROW1 + slot);
+            xf[pl] = *reinterpret_cast<const half8*>(sX + (wave * 32 + l31) * ROW1 + slot);
+            if (MB1 == 6) xe[pl] = *reinterpret_cast<const half8*>(sX + (xmb * 32 + l31) * ROW1 + slot);
         }
 #pragma unroll
-        for (int kk = 0; kk < CH / 16; ++kk) {
-            const int g = kk * 2 + lhi;
-            half8 wf[2][2], xf[2], xe[2];
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                const int slot = ((g + 4 * pl) ^ fswz) << 4;
-                wf[pl][0] = *reinterpret_cast<const half8*>(sW + l31 * ROWB + slot);
-                wf[pl][1] = *reinterpret_cast<const half8*>(sW + (32 + l31) * ROWB + slot);
-                xf[pl] = *reinterpret_cast<const half8*>(sX + (wave * 32 + l31) * ROWB + slot);
-                if (MB1 == 6) xe[pl] = *reinterpret_cast<const half8*>(sX + (xmb * 32 + l31) * ROWB + slot);
-            }
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {                    // small cross terms first, then hi*hi (conv3.hip's order)
-                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nb], xf[1], acc1[nb], 0, 0, 0);
-                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][nb], xf[0], acc1[nb], 0, 0, 0);
-                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nb], xf[0], acc1[nb], 0, 0, 0);
-            }
-            if (MB1 == 6) {                                     // the extra block's channel half is wave-uniform: a scalar branch, no copy
-                if (xnb) {
-                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][1], xe[1], acc1[NB1 - 1], 0, 0, 0);
-                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][1], xe[0], acc1[NB1 - 1], 0, 0, 0);
-                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][1], xe[0], acc1[NB1 - 1], 0, 0, 0);
-                } else {
-                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][0], xe[1], acc1[NB1 - 1], 0, 0, 0);
-                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][0], xe[0], acc1[NB1 - 1], 0, 0, 0);
-                    acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][0], xe[0], acc1[NB1 - 1], 0, 0, 0);
-                }
+        for (int nb = 0; nb < 2; ++nb) {                        // small cross terms first, then hi*hi (conv3.hip's order)
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nb], xf[1], acc1[nb], 0, 0, 0);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][nb], xf[0], acc1[nb], 0, 0, 0);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nb], xf[0], acc1[nb], 0, 0, 0);
+        }
+        if (MB1 == 6) {                                         // the extra block's channel half is wave-uniform: a scalar branch, no copy
+            if (xnb) {
+                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][1], xe[1], acc1[NB1 - 1], 0, 0, 0);
+                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][1], xe[0], acc1[NB1 - 1], 0, 0, 0);
+                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][1], xe[0], acc1[NB1 - 1], 0, 0, 0);
+            } else {
+                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][0], xe[1], acc1[NB1 - 1], 0, 0, 0);
+                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][0], xe[0], acc1[NB1 - 1], 0, 0, 0);
+                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][0], xe[0], acc1[NB1 - 1], 0, 0, 0);
             }
         }
     }
     lds_barrier();                                              // every wave is done with the staging buffers (all DMA has landed)
+    TRB(2);
     // phase 2's accumulators start at b2 / scale: the loads go out now, ahead of the first weight slots, and are consumed after
     // y1 has been written (the wait hipcc puts there covers slot 0, which is needed then anyway)
     float4 b2v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) b2v[q] = *reinterpret_cast<const float4*>(a.bias + wn * 32 + 8 * q + 4 * lhi);
 
-    // ---- weight slots of phases 2 and 3: slot s < 9 = tap s of the 3x3 (its two 32-channel chunks), slot 9 + nc = tail chunk nc
+    // ---- weight slots of phases 2 and 3, 8 KiB each (64 rows of one 32-channel chunk): 18 (tap, chunk) slots, then 8 (tail chunk, k chunk)
     char* ring = smem + Y1_BYTES;
     const char* __restrict__ w2g = reinterpret_cast<const char*>(a.w);
     const char* __restrict__ w3g = reinterpret_cast<const char*>(a.w2);
     const unsigned wlane = (unsigned)(wave * 1024 + lane * 16);
     auto issue_slot = [&](int s) {
         char* dst = ring + (s % NS) * SLOT + wave * 1024;
-        if (s < NTAP) {
+        // slot s < 18: tap s / 2, chunk s % 2 of the 3x3 (conv3.hip's blocks are ordered [chunk][tap]); then [tail chunk][k chunk]
+        const char* g = (s < NS2 ? w2g + (long long)((s % KC2) * NTAP + s / KC2) * SLOT : w3g + (long long)(s - NS2) * SLOT) + wlane;
 #pragma unroll
-            for (int cc = 0; cc < KC2; ++cc) {                  // conv3.hip's blocks are ordered [chunk][tap]: two 8 KiB pieces
-                const char* g = w2g + (long long)(cc * NTAP + s) * (P * ROWB) + wlane;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    __builtin_amdgcn_global_load_lds((gbl_void*)(g + i * 4096), (lds_void*)(dst + cc * (P * ROWB) + i * 4096), 16, 0, 0);
-            }
-        } else {
-            const char* g = w3g + (long long)(s - NTAP) * SLOT + wlane;
-#pragma unroll
-            for (int i = 0; i < LS; ++i)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(g + i * 4096), (lds_void*)(dst + i * 4096), 16, 0, 0);
-        }
+        for (int i = 0; i < LS; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(g + i * 4096), (lds_void*)(dst + i * 4096), 16, 0, 0);
     };
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue_slot(s);
-    // Ring protocol.  Iteration s: [barrier: slot s is published, slot s-1's buffer is free] -> issue slot s + NS - 1 -> multiply
-    // -> WAIT for slot s + 1 (younger slots stay in flight) -> [stores of the iteration].  The wait stands BEFORE the iteration's
-    // own stores, so it only ever covers stores that are a whole iteration old.
-    auto wait_slot = [&](int nxt) {                             // slots issued by now: up to min(nxt + NS - 2, NSLOT - 1)
-        if (nxt >= NSLOT) return;
-        const int younger = (nxt + NS - 2 < NSLOT ? nxt + NS - 2 : NSLOT - 1) - nxt;
-        wait_vm(younger * LS);
+    // Ring protocol.  Slot s: [barrier: slot s is published, slot s-1's buffer is free] -> issue slot s + NS - 1 -> multiply ->
+    // WAIT for the next slot(s); younger ones stay in flight.  In phase 3 a chunk's two slots are waited for together at the end
+    // of the PREVIOUS chunk's multiplications, i.e. BEFORE that chunk's stores: a counted vmcnt also counts stores, and a wait
+    // that covers stores issued a moment ago costs a store round trip (csrc/convf.hip pays that once per chunk).
+    auto wait_slots = [&](int cur, int upto) {                  // in slot `cur` (its issue done): slots <= upto have landed
+        if (upto >= NSLOT) upto = NSLOT - 1;
+        const int issued = cur + NS - 1 < NSLOT ? cur + NS - 1 : NSLOT - 1;
+        wait_vm((issued > upto ? issued - upto : 0) * LS);
     };
-
     // ---- accumulators -> y1 [KC2][PROWS][128 B] (rows = patch pixels, conv3.hip's format).  acc[4*q + e] = channel
     //      nb*32 + 8*q + 4*lhi + e of patch row mb*32 + l31; rows outside the image are the 3x3's zero padding.
     char* sY1 = smem;
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
             }
     }
     wait_vm((NS - 2) * LS);                                     // slot 0 (only slots 0 .. NS-2 are issued)
+    TRB(3);
 
     // ================================================================= phase 2: the 3x3 on y1
     int prow0[MI];                                              // patch row of tap (0,0) of this lane's pixels
@@ -305,36 +307,36 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
     const int b_row0 = wn * (P / 2) + l31;                      // this wave's 32 output channels of the 3x3
 
 #pragma unroll
-    for (int s = 0; s < NTAP; ++s) {
+    for (int s = 0; s < NS2; ++s) {
         lds_barrier();                                          // slot s landed for every wave; y1 complete (s = 0); slot s-1's buffer is free
         if (s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
         const char* sB = ring + (s % NS) * SLOT;
-        const int shift = (s / 3) * PW + (s % 3);
+        const int tap = s / KC2, cc = s % KC2;
+        const int shift = (tap / 3) * PW + (tap % 3);
 #pragma unroll
-        for (int cc = 0; cc < KC2; ++cc)
+        for (int kk = 0; kk < CH / 16; ++kk) {
+            const int g = kk * 2 + lhi;
+            half8 af[2][MI], bf[2];
 #pragma unroll
-            for (int kk = 0; kk < CH / 16; ++kk) {
-                const int g = kk * 2 + lhi;
-                half8 af[2][MI], bf[2];
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const int prow = prow0[mi] + shift;
-                        af[pl][mi] = *reinterpret_cast<const half8*>(sY1 + (cc * PROWS + prow) * ROWB + (((g + 4 * pl) ^ ((prow >> 1) & 7)) << 4));
-                    }
-                    bf[pl] = *reinterpret_cast<const half8*>(sB + (cc * P + b_row0) * ROWB + (((g + 4 * pl) ^ fswz) << 4));
-                }
+            for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[1][mi], acc2[mi], 0, 0, 0);
-                    acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1], af[0][mi], acc2[mi], 0, 0, 0);
-                    acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[0][mi], acc2[mi], 0, 0, 0);
+                    const int prow = prow0[mi] + shift;
+                    af[pl][mi] = *reinterpret_cast<const half8*>(sY1 + (cc * PROWS + prow) * ROWB + (((g + 4 * pl) ^ ((prow >> 1) & 7)) << 4));
                 }
+                bf[pl] = *reinterpret_cast<const half8*>(sB + b_row0 * ROWB + (((g + 4 * pl) ^ fswz) << 4));
             }
-        wait_slot(s + 1);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[1][mi], acc2[mi], 0, 0, 0);
+                acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1], af[0][mi], acc2[mi], 0, 0, 0);
+                acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[0][mi], acc2[mi], 0, 0, 0);
+            }
+        }
+        wait_slots(s, s + 1 < NS2 ? s + 1 : s + 2);            // the last tap also waits for both slots of the first tail chunk
     }
     lds_barrier();                                              // every wave is done with y1: y2 may overwrite it
+    TRB(4);
 
     // ---- accumulators -> y2 [KC2][BM][128 B] (rows = tile pixels).  acc2[mi][4*q + e] = channel wn*32 + 8*q + 4*lhi + e
     char* sY2 = smem;
@@ -379,21 +381,23 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
 
 #pragma unroll
     for (int nc = 0; nc < NCH3; ++nc) {
-        const int s = NTAP + nc;
-        lds_barrier();                                          // slot s landed for every wave; y2 complete (nc = 0); slot s-1's buffer is free
-        if (s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
-        const char* sW = ring + (s % NS) * SLOT;
         f32x16 acc3[MI];                                        // start value b3 / scale: rows = channels nc*64 + wn*32 + 8*q + 4*lhi + e
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b4 = *reinterpret_cast<const float4*>(sB3 + nc * 64 + wn * 32 + 8 * q + 4 * lhi);
+        for (int kc = 0; kc < KC2; ++kc) {
+            const int s = NS2 + nc * KC2 + kc;
+            lds_barrier();                                      // slot s landed for every wave; y2 + bias table complete (first slot); slot s-1's buffer is free
+            if (s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
+            const char* sW = ring + (s % NS) * SLOT;
+            if (kc == 0) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                acc3[mi][4 * q + 0] = b4.x; acc3[mi][4 * q + 1] = b4.y; acc3[mi][4 * q + 2] = b4.z; acc3[mi][4 * q + 3] = b4.w;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(sB3 + nc * 64 + wn * 32 + 8 * q + 4 * lhi);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        acc3[mi][4 * q + 0] = b4.x; acc3[mi][4 * q + 1] = b4.y; acc3[mi][4 * q + 2] = b4.z; acc3[mi][4 * q + 3] = b4.w;
+                    }
+                }
             }
-        }
-#pragma unroll
-        for (int kc = 0; kc < KC2; ++kc)
 #pragma unroll
             for (int kk = 0; kk < CH / 16; ++kk) {
                 const int g = kk * 2 + lhi;
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
                         pf[pl][mi] = *reinterpret_cast<const half8*>(sY2 + (kc * BM + p_row0 + mi * 32) * ROWB + (((g + 4 * pl) ^ fswz) << 4));
-                    wf[pl] = *reinterpret_cast<const half8*>(sW + (kc * 64 + c_row0) * ROWB + (((g + 4 * pl) ^ fswz) << 4));
+                    wf[pl] = *reinterpret_cast<const half8*>(sW + c_row0 * ROWB + (((g + 4 * pl) ^ fswz) << 4));
                 }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
@@ -412,7 +416,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
                     acc3[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], pf[0][mi], acc3[mi], 0, 0, 0);
                 }
             }
-        wait_slot(s + 1);                                       // before this chunk's stores: covers the previous chunk's (old) stores only
+            if (kc == KC2 - 1) wait_slots(s, s + 2);            // both slots of the next chunk, BEFORE this chunk's stores
+        }
         // ---- register epilogue (convp.hip): half-wave swap -> acc3[mi][8*j .. 8*j+7] = channels n_lane + 16*j .. +7 of the pixel
         const int n_lane = nc * 64 + wn * 32 + 8 * lhi;
 #pragma unroll
@@ -473,6 +478,17 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
                 *reinterpret_cast<half8*>(op + a.out_lo) = l;
             }
     }
+#ifdef SMAP_TRACE
+    TRB(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TRB(6);
+    if (a.dbg && tid == 0) {                                    // stamps of wave 0: start, set-up, phase 1, y1 written, phase 2, last store issued, stores retired
+        long long* d = a.dbg + (long long)blockIdx.x * 8;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        d[0] = tr_t[0]; d[1] = tr_t[1]; d[2] = tr_t[2]; d[3] = tr_t[3]; d[4] = tr_t[4]; d[5] = tr_t[5]; d[6] = tr_t[6]; d[7] = hwid;
+    }
+#endif
     SMAP_TL_END(a)
 }
 

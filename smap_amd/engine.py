@@ -233,6 +233,18 @@ def pack_halo_rows(w2, bn, taps, cin, x3):
     return rows[:, :, :, r[:, None], idx, :].contiguous()
 
 
+def pack_rows16(w2):
+    """[2 planes][rows][K] (hi | lo) -> [K / 16][rows][4 slots][8 halves]: the 16-channel stages of csrc/convb.hip's leading 1x1 --
+    64-byte rows [hi16 | lo16], logical granule = plane * 2 + g (g = which 8 of the 16 channels), slot s of row r holds
+    granule s ^ ((r >> 2) & 3)."""
+    planes, rows, K = w2.shape
+    assert planes == 2 and K % 16 == 0
+    w = w2.reshape(2, rows, K // 16, 2, 8).permute(2, 1, 0, 3, 4).reshape(K // 16, rows, 4, 8)
+    r = torch.arange(rows)
+    idx = torch.arange(4)[None, :] ^ ((r[:, None] >> 2) & 3)
+    return w[:, r[:, None], idx, :].contiguous()
+
+
 def unpack_halo_rows(packed, bn, taps, cin, cout_pad, x3):
     planes, K = (2 if x3 else 1), taps * cin
     perm = pack_halo_rows(torch.arange(planes * cout_pad * K, dtype=torch.int64).reshape(planes, cout_pad, K), bn, taps, cin, x3).reshape(-1)
@@ -517,7 +529,7 @@ class Graph:
         assert P == 64 and C == 4 * P == x.C == wt.shape[0] and w3.shape[:2] == (P, P) and w3.shape[2] == 3 and wt.shape[1] == P
         M = self.B * x.H * x.W
         hi, lo, sc1 = split_f16(w1.reshape(P, C))
-        wk1 = pack_halo_rows(torch.stack([hi, lo]), P, 1, C, True)                    # [1][C/32][1][P rows][128 B]
+        wk1 = pack_rows16(torch.stack([hi, lo]))                                      # [C/16 stages][P rows][64 B]
         hi, lo, sc3 = split_f16(w3.permute(0, 2, 3, 1).reshape(P, 9 * P))
         wk3 = pack_halo_rows(torch.stack([hi, lo]), P, 9, P, True)                    # [1][P/32][9 taps][P rows][128 B]
         hi, lo, sct = split_f16(wt.reshape(C, P))

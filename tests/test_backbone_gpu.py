@@ -361,13 +361,13 @@ TAIL_CASES = [
 ]
 
 
-def _run_block(B, H, W, tile, use_adds, seed=0, mode="full", relu=True):
+def _run_block(B, H, W, tile, use_adds, seed=0, mode="full", relu=True, check=True):
     """One whole-Bottleneck op (csrc/convb.hip, split precision): relu(W3 relu(W2 * relu(W1 x + b1) + b2) + b3 + x) [+ adds],
     P = 64 planes, C = 256 channels.  `mode` switches parts of the block off so that a failure names the phase
     (tools/debug/convb_probe.py): "residual" (W3 = b3 = 0: out = relu(x)), "no_c1" (W1 = 0: y1 = relu(b1) inside the image),
     "centre_tap" (only the centre tap of the 3x3 is non-zero: no shifted views), "full"."""
     from smap_amd import lib as L
-    from smap_amd.engine import TAIL_BN, ZERO_PAGE, pack_halo_rows, split_f16
+    from smap_amd.engine import TAIL_BN, ZERO_PAGE, pack_halo_rows, pack_rows16, split_f16
     lib = L.load()
     P, Cc = 64, 256
     g = torch.Generator().manual_seed(seed)
@@ -390,7 +390,7 @@ def _run_block(B, H, W, tile, use_adds, seed=0, mode="full", relu=True):
         w3 = w3 * m
     bn2 = TAIL_BN[tile]
     hi, lo, sc1 = split_f16(w1.reshape(P, Cc).double())
-    wk1 = pack_halo_rows(torch.stack([hi, lo]), P, 1, Cc, True)
+    wk1 = pack_rows16(torch.stack([hi, lo]))
     hi, lo, sc3 = split_f16(w3.permute(0, 2, 3, 1).reshape(P, 9 * P).double())
     wk3 = pack_halo_rows(torch.stack([hi, lo]), P, 9, P, True)
     hi, lo, sct = split_f16(wt.reshape(Cc, P).double())
@@ -433,6 +433,8 @@ def _run_block(B, H, W, tile, use_adds, seed=0, mode="full", relu=True):
     L.check(lib.smap_plan_run(h, None, C.c_void_p(arena_d.data_ptr()), C.c_void_p(blob_d.data_ptr()), None, st), "run")
     torch.cuda.synchronize()
     lib.smap_plan_destroy(h)
+    if not check:                                            # tools/trace_convb.py: the launch is what matters
+        return None, None
     got = arena_d[out_off:out_off + B * H * W * Cc * 4].cpu().view(torch.float16).view(B, H, W, 2, Cc).float()
     got = got[..., 0, :] + got[..., 1, :]
     xin = x.double().permute(0, 3, 1, 2)

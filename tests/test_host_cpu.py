@@ -335,10 +335,10 @@ def test_lifter_ties_are_told_from_real_joint_errors():
     assert m["person_match"] == 1.0 and m["limb_match"] == 1.0
     assert m["max_joint_err_cm"] > 0.1, "the moved sample must matter in this scene"
     assert m["joints_over_0.1cm_unexplained"] == 0 and m["lifter_ties"] >= 1, m
-    assert m["lifter_tie_max_coord_diff_px"] < 1e-5
+    assert m["lifter_tie_max_coord_diff_px"] < 1e-4
     # the same sample moved by a coordinate that differs by 0.2 px (still 'the same peak' for the 0.5 px pairing): not a tie
     c = body.copy()
-    c[0, 12, 0] = step - np.float32(0.05)
+    c[0, 12, 0] = step - np.float32(0.05)                              # 0.2 network px away: far beyond LIFT_TIE_PX
     m2 = parity.compare([frame(a)], [frame(c)])
     assert m2["limb_match"] == 1.0 and m2["max_joint_err_cm"] > 0.1
     assert m2["joints_over_0.1cm_unexplained"] >= 1 and m2["lifter_ties"] == 0, m2
