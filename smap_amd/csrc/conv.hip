@@ -462,7 +462,7 @@ extern "C" int smap_conv_tile_bk(int tile, int precision)
     int bm, bn;
     if (smap_conv_tile_dims(tile, &bm, &bn)) return 0;
     if ((tile >= 30 && tile < 40) || (tile >= 80 && tile < 100)) return precision ? 32 : 64;
-    if (tile >= 60 && tile < 80) return tile == 69 ? 64 : 32;
+    if (tile >= 60 && tile < 80) return 32;
     if (precision) return (tile <= 4 || tile == 52) ? 64 : 32;
     return ((tile >= 20 && tile <= 27) || tile == 50 || tile == 51 || tile == 53 || tile == 54 || tile == 55) ? 32 : 64;
 }
@@ -488,7 +488,7 @@ extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
         case 21: case 25: *bm = 128; *bn = 64; return 0;
         case 22: case 26: *bm = 64; *bn = 64; return 0;
         case 23: case 27: *bm = 64; *bn = 128; return 0;
-        case 55: case 56: case 57: *bm = 128; *bn = 128; return 0;   // 55..57: deep pipelines (3 K tiles in flight)
+        case 55: *bm = 128; *bn = 128; return 0;                    // 55: deep pipeline (3 K tiles in flight; 56, 57 retired: no table entry)
         case 50: case 51: case 52: *bm = 128; *bn = 128; return 0;   // 50..54: eight-wave workgroups
         case 53: *bm = 256; *bn = 128; return 0;
         case 54: *bm = 128; *bn = 256; return 0;
@@ -504,7 +504,7 @@ extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
 // tiles that have a split-precision instance (plan.hip::validate asks)
 int smap_conv_tile_has_x3(int tile)
 {
-    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 57) || (tile >= 60 && tile <= 70) ||
+    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 55) || (tile >= 60 && tile <= 65) ||
            (tile >= 80 && tile <= 82) || tile == 90 || tile == 91;
 }
 
@@ -535,8 +535,6 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
             case 53: return launch_x3<256, 128, 4, 2, 2, 32>(a, st);  // 96 KiB, 8 waves of 64x64
             case 54: return launch_x3<128, 256, 2, 4, 2, 32>(a, st);  // 96 KiB, 8 waves of 64x64
             case 55: return launch_x3<128, 128, 2, 4, 4, 32>(a, st);  // 128 KiB: 8 waves, 3 K tiles (96 KiB) in flight
-            case 56: return launch_x3<128, 128, 4, 2, 4, 32>(a, st);
-            case 57: return launch_x3<128, 128, 2, 2, 4, 32>(a, st);  // 128 KiB: 4 waves, 3 K tiles in flight
             default: return hipErrorInvalidValue;
         }
     }
@@ -566,8 +564,6 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
         case 53: return launch<256, 128, 4, 2, 2, 32>(a, st);   // 128 KiB (fp32 epilogue tile)
         case 54: return launch<128, 256, 2, 4, 2, 32>(a, st);
         case 55: return launch<128, 128, 2, 4, 4, 32>(a, st);   // 64 KiB: 8 waves, 3 K tiles in flight
-        case 56: return launch<128, 128, 2, 4, 4, 64>(a, st);   // 128 KiB: BK = 64, 3 K tiles (96 KiB) in flight
-        case 57: return launch<128, 128, 2, 2, 4, 64>(a, st);   // = tile 5
         default: return hipErrorInvalidValue;
     }
 }

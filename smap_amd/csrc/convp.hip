@@ -533,15 +533,13 @@ hipError_t launchp(const ConvArgs& a, hipStream_t st)
 
 int smap_convp_tile_dims(int tile, int* bm, int* bn)
 {
+    // (ids 66, 68, 69, 70 -- split loaders, 64-half K tiles, eight loader waves -- were round-3 experiments that no measured table
+    //  entry selects: retired from the shipped library in round 4; the template parameters NLA / P_BK / P_NLW they instantiated remain)
     switch (tile) {
         case 60: *bm = 128; *bn = 256; return 0;      // 8 compute waves of 64 px x 64 ch
         case 61: *bm = 256; *bn = 128; return 0;
         case 62: *bm = 128; *bn = 128; return 0;      // 8 compute waves of 32 px x 64 ch
         case 63: case 64: case 65: *bm = 128; *bn = 64; return 0;
-        case 66: *bm = 128; *bn = 256; return 0;                // tile 60 with split loaders (2 + 2 waves)
-        case 68: *bm = 128; *bn = 128; return 0;                // tile 62 with split loaders (2 + 2)
-        case 69: *bm = 128; *bn = 128; return 0;                // tile 62 with 64-half K tiles (128-byte rows = full lines), 2 stages
-        case 70: *bm = 128; *bn = 128; return 0;                // tile 62 with EIGHT loader waves   // N = 64 layers: 8 waves of 32 px x 32 ch, 6 / 3 / 2 stages
         default: return -1;
     }
 }
@@ -557,10 +555,6 @@ hipError_t smap_launch_convp(const ConvArgs& a, int tile, hipStream_t st)
             case 63: return launchp<128, 64, 4, 2, 6, true>(a, st);      // 6 x 24 KiB
             case 64: return launchp<128, 64, 4, 2, 3, true>(a, st);
             case 65: return launchp<128, 64, 4, 2, 2, true>(a, st);
-            case 66: return launchp<128, 256, 2, 4, 3, true, 2>(a, st);
-            case 68: return launchp<128, 128, 4, 2, 4, true, 2>(a, st);
-            case 69: return launchp<128, 128, 4, 2, 2, true, 0, 64>(a, st);   // 2 x 64 KiB
-            case 70: return launchp<128, 128, 4, 2, 4, true, 0, 32, 8>(a, st);
             default: return hipErrorInvalidValue;
         }
     }
@@ -571,10 +565,6 @@ hipError_t smap_launch_convp(const ConvArgs& a, int tile, hipStream_t st)
         case 63: return launchp<128, 64, 4, 2, 6, false>(a, st);
         case 64: return launchp<128, 64, 4, 2, 3, false>(a, st);
         case 65: return launchp<128, 64, 4, 2, 2, false>(a, st);
-        case 66: return launchp<128, 256, 2, 4, 4, false, 2>(a, st);
-        case 68: return launchp<128, 128, 4, 2, 4, false, 2>(a, st);
-        case 69: return launchp<128, 128, 4, 2, 4, false, 0, 64>(a, st);  // 4 x 32 KiB
-        case 70: return launchp<128, 128, 4, 2, 4, false, 0, 32, 8>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -43,11 +43,10 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          38: (128, 32), 39: (128, 32),                                     # Cout <= 32 heads
          # 50..54: csrc/conv.hip with EIGHT waves per workgroup (two per SIMD from one workgroup: the low-resolution layers)
          50: (128, 128), 51: (128, 128), 52: (128, 128), 53: (256, 128), 54: (128, 256),
-         # 55..57: 4-stage pipelines (three K tiles in flight per workgroup: bytes in flight, not occupancy, for the streaming layers)
-         55: (128, 128), 56: (128, 128), 57: (128, 128),
+         # 55: 4-stage pipeline (three K tiles in flight per workgroup: bytes in flight, not occupancy, for the streaming layers)
+         55: (128, 128),
          # 60..62: csrc/convp.hip, persistent workgroups with loader waves and a register epilogue (no fused bilinear add, no fp32 out)
          60: (128, 256), 61: (256, 128), 62: (128, 128), 63: (128, 64), 64: (128, 64), 65: (128, 64),
-         66: (128, 256), 68: (128, 128), 69: (128, 128), 70: (128, 128),
          # 80..82: csrc/convf.hip, a Bottleneck's 3x3 (BN = all of its planes) with the following 1x1 fused in (TAIL_BN)
          80: (128, 64), 81: (128, 64), 82: (128, 128),
          # 90..91: csrc/convb.hip, a whole identity Bottleneck of 64 planes (1x1 -> 3x3 -> 1x1 + residual) per 4x16 / 8x16 pixel tile
@@ -76,7 +75,7 @@ ALIGN = 256
 ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
 WINDOW = 1 << 32              # csrc/plan.hip SMAP_WINDOW: bytes [k * WINDOW, k * WINDOW + ZERO_PAGE) of the arena are reserved
 PRECISIONS = ("f16", "x3")
-X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 56, 57, 60, 61, 62, 63, 64, 65, 66, 68, 69, 70)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
+X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 60, 61, 62, 63, 64, 65)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
 
 
 def split_f16(w, scaled=True):
@@ -161,7 +160,7 @@ def tile_bk(tile, x3):
     if fam == "halo":
         return 32 if x3 else 64
     if fam == "persist":
-        return 64 if tile == 69 else 32
+        return 32
     if x3:
         return 64 if tile in (0, 1, 2, 3, 4, 52) else 32
     return 32 if tile in (20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 53, 54, 55) else 64

@@ -161,9 +161,7 @@ CASES = [
     (1, 32, 52, 256, 512, 1, 2, 61, False, True, True),
     (8, 64, 104, 64, 256, 1, 1, 62, True, True, False),      # 832 tiles on <= 256 workgroups: the persistent walk
     (2, 8, 12, 512, 256, 1, 1, 62, True, False, True),
-    (3, 10, 14, 192, 320, 3, 1, 55, True, True, True),       # 4-stage pipelines (55..57)
-    (2, 16, 24, 64, 256, 1, 1, 56, False, True, False),
-    (2, 8, 12, 512, 256, 1, 1, 57, True, False, True),
+    (3, 10, 14, 192, 320, 3, 1, 55, True, True, True),       # 4-stage pipeline
     # halo-tiled 3x3 stride-1 kernel (conv3.hip), tile ids 30..33: ragged pixel tiles in both directions
     (2, 16, 24, 64, 64, 3, 1, 30, True, False, False),
     (3, 10, 14, 192, 320, 3, 1, 31, True, False, False),
@@ -218,8 +216,6 @@ X3_CASES = [
     (1, 16, 26, 64, 320, 3, 1, 54, True, True, True),
     # 4-stage pipelines (tile ids 55..57), incl. K shorter than the pipeline
     (3, 10, 14, 192, 320, 3, 1, 55, True, True, True),
-    (2, 16, 24, 64, 256, 1, 1, 56, False, True, False),
-    (2, 8, 12, 512, 256, 1, 1, 57, True, False, True),
     # persistent wave-specialised kernel (convp.hip)
     (2, 16, 24, 64, 256, 1, 1, 60, False, False, False),
     (3, 10, 14, 192, 320, 3, 1, 60, True, True, True),
@@ -229,12 +225,7 @@ X3_CASES = [
     (8, 32, 52, 256, 256, 3, 1, 61, True, False, False),     # 3x3 taps through the persistent loader, tiles < workgroups
     (8, 64, 104, 64, 256, 1, 1, 62, True, True, False),
     (2, 8, 12, 2048, 256, 1, 1, 62, True, False, True),
-    (8, 64, 104, 128, 256, 1, 1, 66, True, True, False),     # split loaders: activation waves / weight waves
-    (3, 10, 14, 192, 320, 3, 1, 66, True, True, True),
-    (8, 32, 52, 256, 256, 3, 1, 68, True, False, False),
     (2, 16, 24, 256, 64, 1, 1, 63, True, False, False),      # N = 64 tile, 6-stage ring
-    (8, 32, 52, 256, 256, 3, 1, 69, True, False, False),     # 64-half K tiles
-    (3, 10, 14, 192, 320, 3, 1, 69, True, True, True),
     # halo-tiled 3x3 (conv3.hip) in split precision: 32-channel chunks, rows = [hi32 | lo32]
     (2, 16, 24, 64, 64, 3, 1, 30, True, False, False),
     (3, 10, 14, 192, 320, 3, 1, 31, True, False, False),

@@ -188,7 +188,7 @@ def test_weight_packing_matches_the_kernels_address_arithmetic():
     random.seed(0)
     for tile, x3, ks, cin, cout_pad in ((0, False, 3, 128, 256), (0, True, 1, 256, 256), (20, True, 3, 64, 128), (22, True, 1, 256, 256),
                                         (52, True, 1, 128, 256), (31, True, 3, 128, 256), (31, False, 3, 128, 256), (36, True, 3, 64, 64),
-                                        (38, False, 3, 256, 32), (60, True, 1, 64, 512), (62, False, 3, 64, 256), (69, True, 1, 128, 128)):
+                                        (38, False, 3, 256, 32), (60, True, 1, 64, 512), (62, False, 3, 64, 256), (64, True, 1, 128, 64)):
         planes, K, bn = (2 if x3 else 1), ks * ks * cin, TILES[tile][1]
         w2 = torch.arange(planes * cout_pad * K, dtype=torch.float32).reshape(planes, cout_pad, K)
         for pairs in (True, False):
@@ -335,7 +335,7 @@ def test_lifter_ties_are_told_from_real_joint_errors():
     assert m["person_match"] == 1.0 and m["limb_match"] == 1.0
     assert m["max_joint_err_cm"] > 0.1, "the moved sample must matter in this scene"
     assert m["joints_over_0.1cm_unexplained"] == 0 and m["lifter_ties"] >= 1, m
-    assert m["lifter_tie_max_coord_diff_px"] < 1e-4
+    assert m["lifter_tie_max_coord_diff_px"] < 5e-4
     # the same sample moved by a coordinate that differs by 0.2 px (still 'the same peak' for the 0.5 px pairing): not a tie
     c = body.copy()
     c[0, 12, 0] = step - np.float32(0.05)                              # 0.2 network px away: far beyond LIFT_TIE_PX
