@@ -287,7 +287,8 @@ def compare(hip, ref, root_idx=2):
         # ... of which NOT explained by a straddled index step of the lifter (must be 0), and the explained events
         "joints_over_0.1cm_unexplained": len(big_unexplained), "unexplained_examples": big_unexplained[:4],
         "joints_moved_after_peak_tie": int(after_peak_tie),
-        "lifter_ties": int(lifter_ties), "lifter_tie_events": len(tie_events),      # joints moved / skeletons with a straddled step "lifter_tie_max_coord_diff_px": float(max(tie_diffs)) if tie_diffs else 0.0,
+        "lifter_ties": int(lifter_ties), "lifter_tie_events": len(tie_events),      # joints moved / skeletons with a straddled step
+        "lifter_tie_max_coord_diff_px": float(max(tie_diffs)) if tie_diffs else 0.0,
         "root_z_max_err_cm": float(max(rz_errs)) if rz_errs else 0.0,
         "root_z_mean_cm": float(np.mean([r for b in ref for r in b["rz"]])) if any(len(b["rz"]) for b in ref) else 0.0,
         "map_rel_err_max": maps,
