@@ -202,7 +202,14 @@ typedef struct smap_op {
                                        the residual: res_off must equal in_off and tail_cout = head_cin. */
     float head_acc_scale;           /* 2^-s of the leading 1x1's weights */
     int64_t head_w_off;             /* weight-blob byte offsets of the leading 1x1: blocks [k chunk][Cin rows][128 B] in the halo */
-    int64_t head_bias_off;          /* tiles' row format (hi32 | lo32 of 32 input channels); fp32 bias [Cin] */
+    int64_t head_bias_off;          /* tiles' row format (hi32 | lo32 of 32 input channels; tile ids 90, 91: 16-channel stages, 64-byte rows,
+                                       smap_amd/engine.py::pack_rows16); fp32 bias [Cin] */
+    int64_t short_w_off;            /* tile ids 92, 93 only (present iff short_acc_scale > 0): the FIRST block of a layer (smap.py:124-129) -- head_cin = 64 input
+                                       channels and, instead of "+ input", a 1x1 SHORTCUT conv head_cin -> tail_cout (folded BN, no ReLU) on
+                                       the same input, added before the final ReLU.  Weight blocks [n chunk][k chunk][64 rows][128 B] like
+                                       the tail's; its bias is folded into the tail's bias by the packer; res_off = -1 */
+    float short_acc_scale;          /* 2^-s of the shortcut conv's weights; 0 = the op has no shortcut conv */
+    int32_t reserved0;
 } smap_op;
 
 /* sizeof(smap_op) as compiled: lets a foreign-language binding verify its struct mirror. */

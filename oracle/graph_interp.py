@@ -67,6 +67,9 @@ def run_graph(g, imgs, quantize, keep=False):
                 else:
                     w1, b1 = tl["w_ref"].to(dt), tl["b_ref"].to(dt)
                 y = F.conv2d(y, w1.to(dev), b1.to(dev))
+            if "short" in p:                             # first block of a layer: + the 1x1 shortcut conv of the block's input
+                sh = p["short"]
+                y = y + F.conv2d(T[op.inp.name], sh["w_ref"].to(dt).to(dev), sh["b_ref"].to(dt).to(dev))
             if op.res is not None:
                 y = y + T[op.res.name]
             if op.aux:                                   # fused relu(u_skip(x) + bilinear(up_conv@low))

@@ -37,6 +37,8 @@ struct ConvArgs {
     const float* bias0;      // [P] fp32
     int head_cin;            // channels of the block's input (= of its output)
     float acc_scale0;
+    const _Float16* wd;      // tile ids 92, 93: packed [n chunk][k chunk][64 rows][128 B] weights of the 1x1 SHORTCUT conv of a layer's first
+    float acc_scale_d;       // block (head_cin -> tail_cout, no ReLU; its bias is folded into bias2), or null
 #ifdef SMAP_TRACE
     long long* dbg;          // diagnostics build only (tools/build_ablate.py --trace): per-workgroup phase stamps
 #endif

@@ -550,15 +550,19 @@ static int validate(const smap_op& o)
                 return SMAP_E_ARG;                       // halo-tiled kernel: plain 3x3 stride-1 convs only
             if ((o.tile >= 80 && o.tile < 100) != (o.tail_cout > 0)) return SMAP_E_ARG;
             if ((o.tile >= 90 && o.tile < 100) != (o.head_cin > 0)) return SMAP_E_ARG;
-            if (o.tile >= 90 && o.tile < 100) {          // whole identity Bottleneck (convb.hip): split precision, P = 64 planes, C = 256
+            if (o.tile >= 90 && o.tile < 100) {          // whole Bottleneck (convb.hip): split precision, P = 64 planes, 256 output channels
+                const bool first = o.tile == 92 || o.tile == 93;       // a layer's FIRST block: 64 input channels, 1x1 shortcut conv instead of + x
                 if (o.precision != 1 || o.ksize != 3 || o.stride != 1 || o.pad != 1 || o.out_fp32 || o.aux_off[0] >= 0) return SMAP_E_ARG;
-                if (o.Cin != 64 || o.Cout != 64 || o.cout_pad != 64 || o.head_cin != 256 || o.tail_cout != 256 || o.tail_cout_pad != 256)
+                if (o.Cin != 64 || o.Cout != 64 || o.cout_pad != 64 || o.head_cin != (first ? 64 : 256) || o.tail_cout != 256 || o.tail_cout_pad != 256)
                     return SMAP_E_ARG;
-                if (o.in_stride_c != 2 * o.head_cin || o.in_c_off != 0 || o.res_off != o.in_off) return SMAP_E_ARG;   // the residual IS the input
+                if (o.in_stride_c != 2 * o.head_cin || o.in_c_off != 0) return SMAP_E_ARG;
+                if (first ? (o.res_off >= 0 || o.add1_off >= 0 || o.add2_off >= 0 || o.short_w_off < 0 || !(o.short_acc_scale > 0.f))
+                          : (o.res_off != o.in_off || o.short_acc_scale != 0.f))     // identity block: the residual IS the input
+                    return SMAP_E_ARG;
                 if (o.head_w_off < 0 || o.head_bias_off < 0 || o.tail_w_off < 0 || o.tail_bias_off < 0) return SMAP_E_ARG;
                 if (!(o.head_acc_scale > 0.f) || !(o.tail_acc_scale > 0.f) || o.out_stride_c < o.tail_cout) return SMAP_E_ARG;
                 if ((int64_t)o.B * o.Ho * o.Wo * o.tail_cout * 2 >= ((int64_t)1 << 31)) return SMAP_E_ARG;
-            }
+            } else if (o.short_acc_scale != 0.f) return SMAP_E_ARG;      // (a zero-initialised op has no shortcut conv)
             if (o.tile >= 80 && o.tile < 90) {           // 3x3 + fused 1x1 tail: the op's Cout is the tile's whole N extent
                 const int bn2 = smap_conv_tile_tail_bn(o.tile);
                 if (o.ksize != 3 || o.stride != 1 || o.pad != 1 || o.out_fp32 || o.aux_off[0] >= 0 || o.Cout != bn || o.cout_pad != bn)
@@ -735,6 +739,8 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
                 a.bias0 = o.head_cin > 0 ? reinterpret_cast<const float*>(wb + o.head_bias_off) : nullptr;
                 a.head_cin = o.head_cin;
                 a.acc_scale0 = o.head_acc_scale;
+                a.wd = o.head_cin > 0 && o.short_acc_scale > 0.f ? reinterpret_cast<const _Float16*>(wb + o.short_w_off) : nullptr;
+                a.acc_scale_d = o.short_acc_scale;
                 int bm, bn;
                 smap_conv_tile_dims(o.tile, &bm, &bn);
                 a.m_tiles = (a.M + bm - 1) / bm;

@@ -50,12 +50,16 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          # 80..82: csrc/convf.hip, a Bottleneck's 3x3 (BN = all of its planes) with the following 1x1 fused in (TAIL_BN)
          80: (128, 64), 81: (128, 64), 82: (128, 128),
          # 90..91: csrc/convb.hip, a whole identity Bottleneck of 64 planes (1x1 -> 3x3 -> 1x1 + residual) per 4x16 / 8x16 pixel tile
-         90: (64, 64), 91: (128, 64)}
+         90: (64, 64), 91: (128, 64),
+         # 92..93: the same for the FIRST block of layer1 (64 input channels, 1x1 shortcut conv instead of the identity residual)
+         92: (64, 64), 93: (128, 64)}
 TAIL_DEFAULT = {}                          # Bottleneck planes -> fused tile id (empty: every block runs c2 and c3 as two launches)
-TAIL_BN = {80: 64, 81: 128, 82: 64, 90: 64, 91: 64}      # output channels per chunk of the fused 1x1 (csrc/convf.hip::smap_convf_tile_dims)
+TAIL_BN = {80: 64, 81: 128, 82: 64, 90: 64, 91: 64, 92: 64, 93: 64}      # output channels per chunk of the fused 1x1 (csrc/convf.hip::smap_convf_tile_dims)
 # Bottleneck planes -> tile id of the WHOLE-block launch (csrc/convb.hip) for stride-1 identity blocks in split precision; {} = off.
-# SMAP_BLOCK="64:91" overrides (A/B hook; "" = off).
+# SMAP_BLOCK="64:91" overrides (A/B hook; "" = off).  BLOCK_FIRST_DEFAULT / SMAP_BLOCK_FIRST="64:93": the same for the first block of
+# layer1 (the one with a shortcut conv; 64 input channels).
 BLOCK_DEFAULT = {}
+BLOCK_FIRST_DEFAULT = {}
 # (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
 #  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)
 
@@ -515,6 +519,41 @@ class Graph:
             w_ref=w3 if self.keep_ref else None, b_ref=b3 if self.keep_ref else None)))
         return out
 
+    def conv_block_first(self, name, pre, x, tile):
+        """The FIRST Bottleneck of layer1 (smap.py:48-77 with the 1x1 shortcut conv of :124-129; 64 input channels, stride 1) as ONE
+        launch (csrc/convb.hip, tile ids 92, 93): relu(c3(c2(c1(x))) + downsample(x)); x is read once."""
+        assert self.x3
+        w1, b1 = fold_conv_bn(self.sd, pre + ".conv_bn_relu1")
+        w3, b3 = fold_conv_bn(self.sd, pre + ".conv_bn_relu2")
+        wt, bt = fold_conv_bn(self.sd, pre + ".conv_bn_relu3")
+        wd, bd = fold_conv_bn(self.sd, pre + ".downsample")
+        P, Cin = w1.shape[0], w1.shape[1]
+        C = wt.shape[0]
+        assert P == 64 == Cin == x.C and C == 256 and tuple(wd.shape[:2]) == (C, Cin) and wd.shape[2] == 1 and w3.shape[2] == 3
+        M = self.B * x.H * x.W
+        hi, lo, sc1 = split_f16(w1.reshape(P, Cin))
+        wk1 = pack_halo_rows(torch.stack([hi, lo]), P, 1, Cin, True)                  # [1][2 chunks][1][64 rows][128 B]
+        hi, lo, sc3 = split_f16(w3.permute(0, 2, 3, 1).reshape(P, 9 * P))
+        wk3 = pack_halo_rows(torch.stack([hi, lo]), P, 9, P, True)
+        hi, lo, sct = split_f16(wt.reshape(C, P))
+        wkt = pack_halo_rows(torch.stack([hi, lo]), 64, 1, P, True)
+        hi, lo, scd = split_f16(wd.reshape(C, Cin))
+        wkd = pack_halo_rows(torch.stack([hi, lo]), 64, 1, Cin, True)                 # [4 n chunks][2 k chunks][1][64 rows][128 B]
+        out = self.tensor(name, x.H, x.W, C)
+        self.flops += 2 * M * (P * Cin + P * 9 * P + C * P + C * Cin)
+        self.alg_bytes += x.nbytes + out.nbytes + (wk1.numel() + wk3.numel() + wkt.numel() + wkd.numel()) * 2
+        keep = self.keep_ref
+        self.ops.append(Op(OP_CONV, out=out, inp=x, p=dict(
+            Cin=P, in_c_off=0, Cout=P, ksize=3, stride=1, pad=1, relu=1, cout_pad=P, tile=tile, out_fp32=0,
+            w_off=self._add_w(wk3), bias_off=self._add_w(b3.to(torch.float32)), acc_scale=sc3, frames=self.B, w_pairs=0,
+            head=dict(cin=Cin, w_off=self._add_w(wk1), bias_off=self._add_w(b1.to(torch.float32)), acc_scale=sc1,
+                      w_ref=w1 if keep else None, b_ref=b1 if keep else None),
+            tail=dict(cout=C, cout_pad=C, w_off=self._add_w(wkt), bias_off=self._add_w((bt + bd).to(torch.float32)), acc_scale=sct,
+                      w_ref=wt if keep else None, b_ref=bt if keep else None),
+            short=dict(w_off=self._add_w(wkd), acc_scale=scd, w_ref=wd if keep else None, b_ref=bd if keep else None),
+            w_ref=w3 if keep else None, b_ref=b3 if keep else None)))
+        return out
+
     def conv_block(self, name, pre, x, tile, add1=None, add2=None):
         """A whole stride-1 identity Bottleneck (smap.py:48-77: conv_bn_relu1 1x1 -> conv_bn_relu2 3x3 -> conv_bn_relu3 1x1, + x,
         ReLU, + add1, + add2) as ONE launch (csrc/convb.hip, tile ids 90..99, split precision): x is read once, the two
@@ -595,6 +634,10 @@ class Graph:
         blk = self.block_tile(planes, stride, has_ds)
         if blk is not None:         # c1 + c2 + c3 + residual in one launch (csrc/convb.hip)
             return self.conv_block(pre + ".c3", pre, x, blk, add1=add1, add2=add2)
+        spec = os.environ.get("SMAP_BLOCK_FIRST")
+        first = (BLOCK_FIRST_DEFAULT if spec is None else {int(k): int(v) for k, v in (kv.split(":") for kv in spec.split(",") if ":" in kv)}).get(planes)
+        if first is not None and self.x3 and has_ds and stride == 1 and x.C == 64 and planes == 64 and add1 is None and add2 is None:
+            return self.conv_block_first(pre + ".c3", pre, x, first)
         idn = self.conv(pre + ".downsample", [pre + ".downsample"], x, 1, stride, relu=False) if has_ds else x
         y = self.conv(pre + ".c1", [pre + ".conv_bn_relu1"], x, 1, 1, relu=True)
         tail = self.tail_tile(planes, stride)
@@ -773,6 +816,8 @@ class Graph:
                 if "head" in p:
                     hd = p["head"]
                     o.head_cin, o.head_acc_scale, o.head_w_off, o.head_bias_off = hd["cin"], hd["acc_scale"], hd["w_off"], hd["bias_off"]
+                if "short" in p:
+                    o.short_w_off, o.short_acc_scale = p["short"]["w_off"], p["short"]["acc_scale"]
                 o.in_off, o.out_off, o.w_off, o.bias_off = x.off, y.off, p["w_off"], p["bias_off"]
                 for nm in ("res", "add1", "add2"):
                     t = getattr(op, nm)

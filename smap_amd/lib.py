@@ -43,6 +43,7 @@ class SmapOp(C.Structure):
         ("tail_cout", C.c_int32), ("tail_cout_pad", C.c_int32), ("tail_acc_scale", C.c_float),
         ("tail_w_off", C.c_int64), ("tail_bias_off", C.c_int64),
         ("head_cin", C.c_int32), ("head_acc_scale", C.c_float), ("head_w_off", C.c_int64), ("head_bias_off", C.c_int64),
+        ("short_w_off", C.c_int64), ("short_acc_scale", C.c_float), ("reserved0", C.c_int32),
     ]
 
 

@@ -68,7 +68,7 @@ def test_plan_blob_round_trip_and_workspace_bytes():
         assert lib.smap_plan_create_from_blob(lied, len(lied), C.byref(plan), None) == -1
 
 
-@pytest.mark.parametrize("spec", ["", "64:90", "64:91"])
+@pytest.mark.parametrize("spec", ["", "64:90", "64:91", "64:91+64:93"])
 def test_library_accepts_the_full_size_schedules(monkeypatch, spec):
     """smap_plan_create on the benchmarked schedules (8 and 16 frames at 512x832, with and without the whole-Bottleneck launches
     of csrc/convb.hip): what the GPU box will be asked to run validates here, without a GPU."""
@@ -77,13 +77,15 @@ def test_library_accepts_the_full_size_schedules(monkeypatch, spec):
     from smap_amd import lib as L
     from smap_amd.engine import Graph
     from smap_amd.model.smap import SMAP
+    spec, _, first = spec.partition("+")
     monkeypatch.setenv("SMAP_BLOCK", spec)
+    monkeypatch.setenv("SMAP_BLOCK_FIRST", first)
     torch.manual_seed(0)
     sd = SMAP(make_cfg((128, 208))).state_dict()
     for B in (8, 16):
         g = Graph(sd, B, 512, 832, precision="x3")
         g.allocate()
-        assert sum(1 for op in g.ops if "head" in op.p) == (6 if spec else 0)
+        assert sum(1 for op in g.ops if "head" in op.p) == ((9 if first else 6) if spec else 0)
         h = C.c_void_p()
         assert L.load().smap_plan_create(g.emit(), len(g.ops), C.byref(h)) == 0, (spec, B)
         L.load().smap_plan_destroy(h)

@@ -353,6 +353,8 @@ TAIL_CASES = [
 
 
 def _run_block(B, H, W, tile, use_adds, seed=0, mode="full", relu=True, check=True):
+    if tile in (92, 93):
+        return _run_block_first(B, H, W, tile, seed=seed, mode=mode, check=check)
     """One whole-Bottleneck op (csrc/convb.hip, split precision): relu(W3 relu(W2 * relu(W1 x + b1) + b2) + b3 + x) [+ adds],
     P = 64 planes, C = 256 channels.  `mode` switches parts of the block off so that a failure names the phase
     (tools/debug/convb_probe.py): "residual" (W3 = b3 = 0: out = relu(x)), "no_c1" (W1 = 0: y1 = relu(b1) inside the image),
@@ -439,6 +441,81 @@ def _run_block(B, H, W, tile, use_adds, seed=0, mode="full", relu=True, check=Tr
     return got, y.float()
 
 
+def _run_block_first(B, H, W, tile, seed=0, mode="full", check=True):
+    """The FIRST block of layer1 in one launch (csrc/convb.hip, tile ids 92, 93): 64 input channels,
+    relu(W3 relu(W2 * relu(W1 x + b1) + b2) + b3 + Wd x + bd).  Modes: "residual" (W3 = 0: out = relu(Wd x + bd + b3)), "no_c1",
+    "centre_tap", "full"."""
+    from smap_amd import lib as L
+    from smap_amd.engine import ZERO_PAGE, pack_halo_rows, split_f16
+    lib = L.load()
+    P, Cin, Cc = 64, 64, 256
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w1 = torch.randn(P, Cin, 1, 1, generator=g) * (1.0 / Cin) ** 0.5
+    b1 = torch.randn(P, generator=g) * 0.5
+    w3 = torch.randn(P, P, 3, 3, generator=g) * (1.0 / (9 * P)) ** 0.5
+    b3 = torch.randn(P, generator=g) * 0.5
+    wt = torch.randn(Cc, P, 1, 1, generator=g) * (1.0 / P) ** 0.5
+    bt = torch.randn(Cc, generator=g)
+    wd = torch.randn(Cc, Cin, 1, 1, generator=g) * (1.0 / Cin) ** 0.5
+    bd = torch.randn(Cc, generator=g)
+    if mode == "residual":
+        wt = wt * 0
+    elif mode == "no_c1":
+        w1 = w1 * 0
+    elif mode == "centre_tap":
+        m = torch.zeros(3, 3)
+        m[1, 1] = 1
+        w3 = w3 * m
+    pk = lambda w2d, bn, taps, cin: pack_halo_rows(torch.stack(split_f16(w2d.double())[:2]), bn, taps, cin, True)
+    sc1, sc3, sct, scd = (split_f16(t.double())[2] for t in (w1.reshape(P, Cin), w3.permute(0, 2, 3, 1).reshape(P, 9 * P), wt.reshape(Cc, P), wd.reshape(Cc, Cin)))
+    wk1, wk3 = pk(w1.reshape(P, Cin), P, 1, Cin), pk(w3.permute(0, 2, 3, 1).reshape(P, 9 * P), P, 9, P)
+    wkt, wkd = pk(wt.reshape(Cc, P), 64, 1, P), pk(wd.reshape(Cc, Cin), 64, 1, Cin)
+    al = lambda n: (n + 255) // 256 * 256
+    raw8 = lambda t: t.contiguous().view(torch.uint8).reshape(-1)
+    chunks, woffs, cur = [raw8(wk3), raw8(b3), raw8(wkt), raw8(bt + bd), raw8(wk1), raw8(b1), raw8(wkd)], [], 0
+    for c in chunks:
+        woffs.append(cur)
+        cur += al(c.numel())
+    blob = torch.zeros(cur, dtype=torch.uint8)
+    for c, o in zip(chunks, woffs):
+        blob[o:o + c.numel()] = c
+    xs = _split(x)
+    in_off = ZERO_PAGE
+    out_off = in_off + al(xs.numel() * 2)
+    arena = torch.zeros(out_off + al(B * H * W * Cc * 4) + 256, dtype=torch.uint8)
+    arena[in_off:in_off + xs.numel() * 2] = raw8(xs)
+    op = L.SmapOp()
+    op.kind, op.B, op.H, op.W, op.Cin, op.in_stride_c, op.in_c_off = 0, B, H, W, P, Cin * 2, 0
+    op.Ho, op.Wo, op.Cout, op.ksize, op.stride, op.pad, op.relu = H, W, P, 3, 1, 1, 1
+    op.cout_pad, op.out_stride_c, op.out_c_off, op.out_fp32, op.tile = P, Cc * 2, 0, 0, tile
+    op.in_off, op.out_off, op.w_off, op.bias_off = in_off, out_off, woffs[0], woffs[1]
+    op.res_off = op.add1_off = op.add2_off = -1
+    op.precision, op.acc_scale = 1, sc3
+    op.tail_cout, op.tail_cout_pad, op.tail_acc_scale, op.tail_w_off, op.tail_bias_off = Cc, Cc, sct, woffs[2], woffs[3]
+    op.head_cin, op.head_acc_scale, op.head_w_off, op.head_bias_off = Cin, sc1, woffs[4], woffs[5]
+    op.short_w_off, op.short_acc_scale = woffs[6], scd
+    for i in range(3):
+        op.aux_off[i] = -1
+    op.ext_off = -1
+    h = C.c_void_p()
+    L.check(lib.smap_plan_create(C.byref(op), 1, C.byref(h)), "create")
+    arena_d, blob_d = arena.to(DEV), blob.to(DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.smap_plan_run(h, None, C.c_void_p(arena_d.data_ptr()), C.c_void_p(blob_d.data_ptr()), None, st), "run")
+    torch.cuda.synchronize()
+    lib.smap_plan_destroy(h)
+    if not check:
+        return None, None
+    got = arena_d[out_off:out_off + B * H * W * Cc * 4].cpu().view(torch.float16).view(B, H, W, 2, Cc).float()
+    got = got[..., 0, :] + got[..., 1, :]
+    xin = x.double().permute(0, 3, 1, 2)
+    y = F.relu(F.conv2d(xin, w1.double(), b1.double()))
+    y = F.relu(F.conv2d(y, w3.double(), b3.double(), padding=1))
+    y = F.relu(F.conv2d(y, wt.double(), bt.double()) + F.conv2d(xin, wd.double(), bd.double())).permute(0, 2, 3, 1)
+    return got, y.float()
+
+
 BLOCK_CASES = [
     # B, H,  W,  tile, adds
     (2, 16, 32, 90, False),
@@ -448,6 +525,12 @@ BLOCK_CASES = [
     (1, 13, 52, 91, True),           # ragged 8 x 16 tiles
     (3, 10, 14, 91, True),
     (1, 32, 208, 91, False),         # a full row of 13 tiles
+    # first block of a layer: 64 input channels, 1x1 shortcut conv (tile ids 92, 93)
+    (2, 16, 32, 92, False),
+    (1, 13, 52, 92, False),
+    (3, 10, 14, 93, False),
+    (2, 16, 32, 93, False),
+    (1, 13, 52, 93, False),
 ]
 
 
@@ -463,7 +546,7 @@ def test_whole_bottleneck_launch(case, mode):
     assert err.max().item() < tol, (err.max().item(), tol, np.unravel_index(err.argmax().item(), err.shape))
 
 
-@pytest.mark.parametrize("spec", ["64:90", "64:91"])
+@pytest.mark.parametrize("spec", ["64:90", "64:91", "64:91+64:93", "64:90+64:92"])
 def test_small_schedule_with_whole_bottleneck_launches(golden_dir, small, monkeypatch, spec):
     """Identity Bottlenecks of layer1 as ONE launch each (csrc/convb.hip): every stored tensor against the f64 interpretation
     of the SAME schedule, and the outputs against the golden outputs of the reference model."""
@@ -472,9 +555,12 @@ def test_small_schedule_with_whole_bottleneck_launches(golden_dir, small, monkey
     _, sd = small
     z = np.load(f"{golden_dir}/backbone_small.npz")
     x = torch.from_numpy(z["x"])
+    spec, _, first = spec.partition("+")
     monkeypatch.setenv("SMAP_BLOCK", spec)
+    monkeypatch.setenv("SMAP_BLOCK_FIRST", first)
     eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision="x3")
-    assert sum(1 for op in eng.graph.ops if op.kind == 0 and "head" in op.p) == 6
+    assert sum(1 for op in eng.graph.ops if op.kind == 0 and "head" in op.p) == (9 if first else 6)
+    assert sum(1 for op in eng.graph.ops if op.kind == 0 and "short" in op.p) == (3 if first else 0)
     assert not any(t.name.endswith((".c1", ".c2")) for t in eng.graph.tensors if ".layer1.1" in t.name or ".layer1.2" in t.name)
     outs = [o.cpu() for o in eng.run(x.to(DEV))]
     torch.cuda.synchronize()

@@ -18,7 +18,7 @@ import test_backbone_gpu as T  # noqa: E402
 
 
 def report(tile, mode, B=2, H=16, W=32, adds=False):
-    th = 4 if tile == 90 else 8
+    th = 4 if tile in (90, 92) else 8
     try:
         got, ref = T._run_block(B, H, W, tile, adds, seed=7, mode=mode)
     except Exception as e:                                   # noqa: BLE001
@@ -46,8 +46,8 @@ def report(tile, mode, B=2, H=16, W=32, adds=False):
 
 
 if __name__ == "__main__":
-    tiles = [int(t) for t in sys.argv[1:]] or [90, 91]
+    tiles = [int(t) for t in sys.argv[1:]] or [90, 91, 92, 93]
     for tile in tiles:
         for mode in ("residual", "no_c1", "centre_tap", "full"):
             report(tile, mode)
-        report(tile, "full", B=1, H=13, W=52, adds=True)
+        report(tile, "full", B=1, H=13, W=52, adds=tile < 92)

@@ -3,8 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r4v3; mkdir -p $O
 export TMPDIR=/tmp
-SMAP_HIP_LIB=$PWD/smap_amd/csrc/obj/libsmap_hip_trace.so timeout 300 python tools/trace_convb.py > $O/trace_convb.log 2>&1
-cat $O/trace_convb.log
+python -c "import torch; x = torch.ones(8, device='cuda:0'); print('gpu ok', float(x.sum()))" > $O/sanity.log 2>&1; cat $O/sanity.log
 timeout 300 python tools/debug/convb_probe.py > $O/probe.log 2>&1; echo "probe rc $?" >> $O/probe.log
 grep -v "^   " $O/probe.log | head -20
 timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "whole_bottleneck or flip_tta_end_to_end or fused_bottleneck_tail" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
