@@ -58,8 +58,10 @@ TAIL_BN = {80: 64, 81: 128, 82: 64, 90: 64, 91: 64, 92: 64, 93: 64}      # outpu
 # Bottleneck planes -> tile id of the WHOLE-block launch (csrc/convb.hip) for stride-1 identity blocks in split precision; {} = off.
 # SMAP_BLOCK="64:91" overrides (A/B hook; "" = off).  BLOCK_FIRST_DEFAULT / SMAP_BLOCK_FIRST="64:93": the same for the first block of
 # layer1 (the one with a shortcut conv; 64 input channels).
-BLOCK_DEFAULT = {}
-BLOCK_FIRST_DEFAULT = {}
+# Measured in situ (profiles/r4_v4_ab_whole_block_first.log, same box, interleaved): 781 -> 800 (identity blocks, 8 x 16 tiles) -> 821
+# frames/s (+ first blocks); 4 x 16 tiles: 816.
+BLOCK_DEFAULT = {64: 91}
+BLOCK_FIRST_DEFAULT = {64: 93}
 # (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
 #  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)
 

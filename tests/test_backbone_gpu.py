@@ -739,6 +739,8 @@ def test_small_schedule_with_fused_bottleneck_tails(golden_dir, small, monkeypat
     z = np.load(f"{golden_dir}/backbone_small.npz")
     x = torch.from_numpy(z["x"])
     monkeypatch.setenv("SMAP_TAIL", spec)
+    monkeypatch.setenv("SMAP_BLOCK", "")                 # (the whole-block launches would take layer1's blocks in split precision)
+    monkeypatch.setenv("SMAP_BLOCK_FIRST", "")
     eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision=precision)
     n_tail = sum(1 for op in eng.graph.ops if op.kind == 0 and "tail" in op.p)
     assert n_tail == 3 * (3 if spec == "64:80" else 3 + 3) and not any(t.name.endswith(".c2") for t in eng.graph.tensors if ".layer1.1" in t.name)

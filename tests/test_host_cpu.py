@@ -37,20 +37,26 @@ def test_split_f16_reconstructs_to_22_bits():
     assert z[2] == 1.0 and not z[0].any() and not z[1].any()
 
 
-def test_x3_graph_emits_split_strides_and_weights(small_sd):
+@pytest.mark.parametrize("blocks", [False, True], ids=["layer_by_layer", "whole_blocks"])
+def test_x3_graph_emits_split_strides_and_weights(small_sd, monkeypatch, blocks):
     from smap_amd.engine import Graph, OP_CONV, OP_HEADSUM, OP_MAXPOOL, OP_STEM, X3_TILES, ZERO_PAGE
+    if not blocks:                      # the layer-by-layer schedule: op for op the fp16 one (the default fuses layer1's Bottlenecks)
+        monkeypatch.setenv("SMAP_BLOCK", "")
+        monkeypatch.setenv("SMAP_BLOCK_FIRST", "")
     g16 = Graph(small_sd, 2, 64, 96)
     g = Graph(small_sd, 2, 64, 96, precision="x3")
     g.allocate()
     ops = g.emit()
-    assert len(g.ops) == len(g16.ops) and g.flops == g16.flops
+    n_blk = sum(1 for op in g.ops if "head" in op.p)
+    assert n_blk == (9 if blocks else 0)                  # 3 stages x (first block + two identity blocks) of layer1
+    assert len(g.ops) == len(g16.ops) - (3 * 3 + 2 * 6 if blocks else 0) and g.flops == g16.flops
     assert g.weight_blob().numel() > 1.9 * g16.weight_blob().numel()
     for op, o in zip(g.ops, ops):
         assert o.precision == 1
         if op.kind == OP_CONV:
             x, y = op.inp, op.out
             assert x.planes == 2 and o.in_stride_c == 2 * x.C and o.in_c_off + o.Cin <= x.C
-            assert o.tile in X3_TILES + (3,) + tuple(range(30, 40)) and o.acc_scale > 0
+            assert o.tile in X3_TILES + (3,) + tuple(range(30, 40)) + (91, 93) and o.acc_scale > 0
             assert (y.planes, o.out_stride_c) == ((1, y.C) if o.out_fp32 else (2, 2 * y.C))
             assert o.in_off >= ZERO_PAGE and o.Cin * 2 + o.in_stride_c + 16 <= ZERO_PAGE
             for t in (op.res, op.add1, op.add2):
@@ -61,9 +67,9 @@ def test_x3_graph_emits_split_strides_and_weights(small_sd):
             assert op.inp.planes == op.out.planes == 2
         elif op.kind == OP_HEADSUM:
             assert all(t.esize == 4 and t.planes == 1 for t in op.aux)
-    # arena: split tensors take twice the bytes
+    # arena: split tensors take twice the bytes (fewer of them are alive at once when layer1's intermediates stay on chip)
     g16.allocate()
-    assert g.arena_bytes > 1.8 * g16.arena_bytes
+    assert g.arena_bytes > (1.6 if blocks else 1.8) * g16.arena_bytes
 
 
 def test_flip_graph_runs_two_B_frames_and_merges_in_the_head_sum(small_sd):
@@ -230,6 +236,8 @@ def test_fused_bottleneck_tail_schedule_on_cpu(small_sd, monkeypatch):
     g0 = Graph(small_sd, 2, 64, 96, keep_ref=True)
     want, want_q = run_graph(g0, x.double(), quantize=False), run_graph(g0, x, quantize=True)
     monkeypatch.setenv("SMAP_TAIL", "64:80,128:82")
+    monkeypatch.setenv("SMAP_BLOCK", "")                 # (the whole-block launches would take layer1's blocks in split precision)
+    monkeypatch.setenv("SMAP_BLOCK_FIRST", "")
     for prec in ("f16", "x3"):
         g = Graph(small_sd, 2, 64, 96, keep_ref=True, precision=prec)
         tails = [op for op in g.ops if op.kind == OP_CONV and "tail" in op.p]

@@ -1,0 +1,42 @@
+#!/bin/bash
+# round 4, visit 5: whole-block launches ON by default -- the whole suite, the bench lines with timed-path parity, rocprofv3 stats of
+# the driver's command, per-layer trace, HBM traffic and MFMA utilisation from PMC passes (each its own run), host-budget rehearsal
+R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"
+O=$R/gpurun_out/r4v5; mkdir -p $O
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -8 $O/pytest.log
+timeout 400 python bench.py > $O/bench_x3.json 2> $O/bench_x3.err; echo "rc $?" >> $O/bench_x3.err
+timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_x3_driver_form.json 2>> $O/bench_x3.err
+timeout 400 python bench.py --flip --steps 40 > $O/bench_x3_flip.json 2> $O/bench_x3_flip.err
+timeout 400 python bench.py --refine --steps 60 > $O/bench_x3_refine.json 2> $O/bench_x3_refine.err
+timeout 300 python bench.py --forward-only --batch 1 --steps 200 --warmup 20 > $O/bench_x3_forward_b1.json 2>> $O/bench_x3.err
+timeout 300 python bench.py --precision f16 --steps 60 > $O/bench_f16.json 2>> $O/bench_x3.err
+python - <<'PY'
+import json
+for f in ("bench_x3", "bench_x3_driver_form", "bench_x3_flip", "bench_x3_refine", "bench_x3_forward_b1", "bench_f16"):
+    try:
+        d = json.load(open(f"gpurun_out/r4v5/{f}.json")); c = d["config"]; m = c.get("e2e_parity") or {}
+        print(f, round(d["value"], 1), "lf0", c.get("value_launch_frames_0"), "frac", round(d["roofline"]["frac"], 4),
+              {k: m.get(k) for k in ("peaks_differing", "peaks_clear_mismatch", "max_joint_err_cm", "joints_over_0.1cm_unexplained", "lifter_tie_events", "timed_records_equal_these_frames")})
+    except Exception as e:
+        print(f, "ERR", e)
+PY
+cd /tmp
+# rocprofv3 --kernel-trace --stats of the driver's command
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $O/prof_default -o smap -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/rocprof_default.log 2>&1
+db=$(find $O/prof_default -name "*.db" | head -1); python $R/tools/prof_export.py $db $O/kernel_stats_default.csv; cp $(find $O/prof_default -name "*kernel_stats.csv" | head -1) $O/rocprofv3_stats_native_default.csv 2>/dev/null; rm -rf $O/prof_default
+# per-layer, depth 1, one launch per step
+SMAP_PRECISION=x3 SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $O/prof_d1 -o smap -- python $R/bench.py --depth 1 --launch-frames 0 --steps 4 --warmup 2 --no-cpu-baseline > $O/rocprof_d1.log 2>&1
+db=$(find $O/prof_d1 -name "*.db" | head -1); (cd $R; SMAP_PRECISION=x3 python tools/prof_layers.py $db 8 > $O/layers_d1.txt 2>&1); python $R/tools/prof_export.py $db $O/kernel_stats_d1.csv; rm -rf $O/prof_d1
+# HBM traffic: two separate PMC passes
+SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o pmc -- python $R/bench.py --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
+SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o pmc -- python $R/bench.py --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
+python $R/tools/prof_traffic.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/hbm_traffic_x3.json; cat $O/hbm_traffic_x3.json
+rm -rf $O/pmc_fetch $O/pmc_write
+# MFMA pipe utilisation, depth 1
+SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o pmc -- python $R/bench.py --depth 1 --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_mfma.log 2>&1
+python $R/tools/prof_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) > $O/mfma_utilisation_pmc.log 2>&1; cat $O/mfma_utilisation_pmc.log
+rm -rf $O/pmc_mfma
+cd $R
+bash tools/host_budget.sh 24 > $O/host_budget.log 2>&1; cat $O/host_budget.log

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""MFMA pipe utilisation of one forward from a rocprofv3 PMC pass (its own run, with --kernel-trace only):
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d DIR -o pmc -- \
+        python bench.py --depth 1 --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline
+    python tools/prof_mfma.py DIR/.../pmc_counter_collection.csv
+Over the conv launches of the LAST complete forward: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8
+XCDs x 1024 SIMDs).  depth 1 so that kernels do not overlap."""
+import collections
+import csv
+import sys
+
+CONV = ("conv_igemm", "conv3x3_halo", "convp_kernel", "conv3_tail_kernel", "bottleneck_kernel", "bottleneck_first_kernel")
+rows = list(csv.DictReader(open(sys.argv[1])))
+by = collections.defaultdict(dict)
+for r in rows:
+    by[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+    by[int(r["Dispatch_Id"])]["name"] = r["Kernel_Name"]
+ids = sorted(by)
+stems = [i for i in ids if "stem_kernel" in by[i]["name"]]
+for last in reversed(stems):
+    seg = [i for i in ids if i >= last]
+    heads = [i for i in seg if "headsum" in by[i]["name"]][:3]
+    if len(heads) == 3:
+        break
+seg = [i for i in seg if i <= heads[-1]]
+conv = [i for i in seg if any(k in by[i]["name"] for k in CONV)]
+mf = sum(by[i].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for i in conv)
+ga = sum(by[i].get("GRBM_GUI_ACTIVE", 0) for i in conv)
+print(f"x3 depth 1: launches {len(seg)} conv {len(conv)} MFMA busy cycles (sum over SIMDs) {mf:.4g} GRBM_GUI_ACTIVE over conv kernels {ga:.4g}")
+print(f"   (rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs: {ga:.4g} / 8 = {ga / 8:.4g} cycles = {ga / 8 / 2.4e6:.2f} ms at 2.4 GHz, the serial conv time of one forward)")
+print(f"   MFMA pipe utilisation over the conv kernels = busy / (GUI_ACTIVE / 8 x 1024 SIMDs) = {mf / (ga / 8 * 1024):.3f}")
+blk = [i for i in conv if "bottleneck" in by[i]["name"]]
+if blk:
+    mfb = sum(by[i].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for i in blk)
+    gab = sum(by[i].get("GRBM_GUI_ACTIVE", 0) for i in blk)
+    print(f"   whole-Bottleneck launches alone ({len(blk)}): {mfb / (gab / 8 * 1024):.3f}")
