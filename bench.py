@@ -75,7 +75,13 @@ _CPU_CHILD = r"""
 # per-frame results the end-to-end parity figures are computed from (benchkit/parity.py).
 import sys, time, os, json, pickle, torch, numpy as np
 root, threads, frames, seed, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-flip = len(sys.argv) > 6 and sys.argv[6] == "flip"
+flip = "flip" in sys.argv[6:]
+refine = None
+if "refine" in sys.argv[6:]:                                   # BASELINE configs[4]: the same RefineNet (seed 1 default init) folded for the oracle
+    from smap_amd.model.refinenet import RefineNet
+    torch.manual_seed(1)
+    wt, bs = RefineNet().eval().folded("cpu")
+    refine = ([w.t().contiguous().numpy() for w in wt], [b.numpy() for b in bs])
 sys.path.insert(0, root)
 from benchkit import parity
 from benchkit.workload import make_cfg, people_state_dict, PEOPLE_CAM
@@ -89,9 +95,9 @@ fp = None
 if flip:                                                       # the reference's mirror tables (dataset/data_settings.py:22,33-34)
     from exps.stage3_root2.config import cfg
     fp = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [cfg.DATASET.KEYPOINT.NUM + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
-parity.reference_path(sd, x[:1], cams[:1], flip_pair=fp)       # warm-up (oneDNN primitive cache, page faults)
+parity.reference_path(sd, x[:1], cams[:1], flip_pair=fp, refine=refine)       # warm-up (oneDNN primitive cache, page faults)
 t0 = time.time()
-ref = parity.reference_path(sd, x, cams, flip_pair=fp)         # --flip: the reference's two forwards + channel loop (test.py:55-70)
+ref = parity.reference_path(sd, x, cams, flip_pair=fp, refine=refine)   # --flip: the reference's two forwards + channel loop (test.py:55-70)
 dt = (time.time() - t0) / frames
 # association + lifting alone: single thread (the reference's own path: its OpenMP pragmas are commented out,
 # association.cpp:79,100) and frame-parallel over the cores
@@ -110,7 +116,7 @@ pickle.dump({"ref": ref, "sec_per_frame": dt, "assoc_1thread_ms": t_as1 * 1e3, "
 """
 
 
-def cpu_reference(frames, seed, flip=False):
+def cpu_reference(frames, seed, flip=False, refine=False):
     """Runs _CPU_CHILD under a hard timeout (a mis-sized OpenMP team on the box's host CPU must not stall the bench).
     Returns its result dict or {"error": ...}."""
     import subprocess
@@ -118,7 +124,7 @@ def cpu_reference(frames, seed, flip=False):
     threads = usable_cpus(32)
     out = os.path.join(tempfile.mkdtemp(prefix="smap_bench_"), "ref.pkl")
     try:
-        r = subprocess.run([sys.executable, "-c", _CPU_CHILD, ROOT, str(threads), str(frames), str(seed), out] + (["flip"] if flip else []),
+        r = subprocess.run([sys.executable, "-c", _CPU_CHILD, ROOT, str(threads), str(frames), str(seed), out] + (["flip"] if flip else []) + (["refine"] if refine else []),
                            capture_output=True, text=True, timeout=240, cwd=ROOT)
         if r.returncode != 0:
             return {"error": r.stderr[-300:]}
@@ -397,11 +403,11 @@ def main():
     if want_ref:
         import concurrent.futures as cf
         nref = min(B, 8)
-        ref_future = cf.ThreadPoolExecutor(1).submit(cpu_reference, nref, SEED, args.flip)
+        ref_future = cf.ThreadPoolExecutor(1).submit(cpu_reference, nref, SEED, args.flip, args.refine)
         from benchkit import parity
         # the parity block reports THIS configuration: with --flip both sides run the flip-TTA (HIP: mirror + merge inside the schedule)
         fp = (list(run_cfg.DATASET.KEYPOINT.FLIP_ORDER) + [run_cfg.DATASET.KEYPOINT.NUM + c for c in run_cfg.DATASET.PAF.FLIP_CHANNEL]) if args.flip else None
-        hip_frames = parity.hip_path(net, imgs[:nref] if B == nref else imgs, cams, flip_pair=fp)[:nref] if B >= nref else None
+        hip_frames = parity.hip_path(net, imgs[:nref] if B == nref else imgs, cams, flip_pair=fp, refine=refine_w)[:nref] if B >= nref else None
 
     # batches of <= 8 frames are run two (or more) to a backbone launch: --launch-frames (smap_amd/pipeline.py::make_pipeline)
     pipe = make_pipeline(net, run_cfg, B, H, W, dev, launch_frames=args.launch_frames, refine_weights=refine_w, n_extra=1,

@@ -690,6 +690,8 @@ def test_small_schedule_split_precision_every_tensor(golden_dir, small, monkeypa
     _, sd = small
     if tile:
         monkeypatch.setenv("SMAP_X3_TILE", tile)
+    monkeypatch.setenv("SMAP_BLOCK", "")                 # layer by layer: this test is about the tiles of the single-conv kernels (the
+    monkeypatch.setenv("SMAP_BLOCK_FIRST", "")           # default schedule's whole-block launches: test_small_schedule_with_whole_bottleneck_launches)
     z = np.load(f"{golden_dir}/backbone_small.npz")
     x = torch.from_numpy(z["x"])
     eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision="x3")
