@@ -33,6 +33,10 @@
 #include "smap_hip.h"
 #include "plan.h"
 
+#ifndef SMAP_CONVB_ABLATE
+#define SMAP_CONVB_ABLATE 0      // diagnostics builds only (tools/build_ablate.py --convb N), identity kernel: 1 no x loads, 2 no MFMA,
+#endif                           // 4 no global stores, 8 no weight loads (W1 stages and the slot ring)
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -57,6 +61,17 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+}
+
+// (diagnostics: an MFMA that can be compiled out, keeping its operands alive)
+__device__ __forceinline__ f32x16 MFMA_(half8 x, half8 y, f32x16 c, int, int, int)
+{
+#if SMAP_CONVB_ABLATE & 2
+    c[0] += (float)x[0] + (float)y[1];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
+#endif
 }
 
 template <int TH>
@@ -137,11 +152,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
         char* sX = smem + st * ST1;
         const char* gA = arena + (unsigned)(ks * CH1 * 2);      // invalid rows: zero page + stage offset
 #pragma unroll
-        for (int i = 0; i < LA; ++i)
+        for (int i = 0; i < ((SMAP_CONVB_ABLATE & 1) ? 0 : LA); ++i)
             __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_off[i]), (lds_void*)(sX + (i * 64 + wave * 16) * ROW1), 16, 0, 0);
         const char* gW = w1g + (long long)ks * WS1 + (unsigned)(wave * 1024 + lane * 16);
 #pragma unroll
-        for (int i = 0; i < LB1; ++i)
+        for (int i = 0; i < ((SMAP_CONVB_ABLATE & 8) ? 0 : LB1); ++i)
             __builtin_amdgcn_global_load_lds((gbl_void*)(gW + i * 4096), (lds_void*)(sX + XS + i * 4096 + wave * 1024), 16, 0, 0);
     };
     // centre pixels of this lane in phases 2 and 3: p = wm*(MI*32) + mi*32 + l31 -> patch row of the pixel itself
@@ -210,19 +225,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
         }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {                        // small cross terms first, then hi*hi (conv3.hip's order)
-            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nb], xf[1], acc1[nb], 0, 0, 0);
-            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][nb], xf[0], acc1[nb], 0, 0, 0);
-            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nb], xf[0], acc1[nb], 0, 0, 0);
+            acc1[nb] = MFMA_(wf[0][nb], xf[1], acc1[nb], 0, 0, 0);
+            acc1[nb] = MFMA_(wf[1][nb], xf[0], acc1[nb], 0, 0, 0);
+            acc1[nb] = MFMA_(wf[0][nb], xf[0], acc1[nb], 0, 0, 0);
         }
         if (MB1 == 6) {                                         // the extra block's channel half is wave-uniform: a scalar branch, no copy
             if (xnb) {
-                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][1], xe[1], acc1[NB1 - 1], 0, 0, 0);
-                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][1], xe[0], acc1[NB1 - 1], 0, 0, 0);
-                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][1], xe[0], acc1[NB1 - 1], 0, 0, 0);
+                acc1[NB1 - 1] = MFMA_(wf[0][1], xe[1], acc1[NB1 - 1], 0, 0, 0);
+                acc1[NB1 - 1] = MFMA_(wf[1][1], xe[0], acc1[NB1 - 1], 0, 0, 0);
+                acc1[NB1 - 1] = MFMA_(wf[0][1], xe[0], acc1[NB1 - 1], 0, 0, 0);
             } else {
-                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][0], xe[1], acc1[NB1 - 1], 0, 0, 0);
-                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][0], xe[0], acc1[NB1 - 1], 0, 0, 0);
-                acc1[NB1 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][0], xe[0], acc1[NB1 - 1], 0, 0, 0);
+                acc1[NB1 - 1] = MFMA_(wf[0][0], xe[1], acc1[NB1 - 1], 0, 0, 0);
+                acc1[NB1 - 1] = MFMA_(wf[1][0], xe[0], acc1[NB1 - 1], 0, 0, 0);
+                acc1[NB1 - 1] = MFMA_(wf[0][0], xe[0], acc1[NB1 - 1], 0, 0, 0);
             }
         }
     }
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
         // slot s < 18: tap s / 2, chunk s % 2 of the 3x3 (conv3.hip's blocks are ordered [chunk][tap]); then [tail chunk][k chunk]
         const char* g = (s < NS2 ? w2g + (long long)((s % KC2) * NTAP + s / KC2) * SLOT : w3g + (long long)(s - NS2) * SLOT) + wlane;
 #pragma unroll
-        for (int i = 0; i < LS; ++i)
+        for (int i = 0; i < ((SMAP_CONVB_ABLATE & 8) ? 0 : LS); ++i)
             __builtin_amdgcn_global_load_lds((gbl_void*)(g + i * 4096), (lds_void*)(dst + i * 4096), 16, 0, 0);
     };
 #pragma unroll
@@ -328,9 +343,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[1][mi], acc2[mi], 0, 0, 0);
-                acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1], af[0][mi], acc2[mi], 0, 0, 0);
-                acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[0][mi], acc2[mi], 0, 0, 0);
+                acc2[mi] = MFMA_(bf[0], af[1][mi], acc2[mi], 0, 0, 0);
+                acc2[mi] = MFMA_(bf[1], af[0][mi], acc2[mi], 0, 0, 0);
+                acc2[mi] = MFMA_(bf[0], af[0][mi], acc2[mi], 0, 0, 0);
             }
         }
         wait_slots(s, s + 1 < NS2 ? s + 1 : s + 2);            // the last tap also waits for both slots of the first tail chunk
@@ -411,9 +426,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
                 }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    acc3[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], pf[1][mi], acc3[mi], 0, 0, 0);
-                    acc3[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1], pf[0][mi], acc3[mi], 0, 0, 0);
-                    acc3[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], pf[0][mi], acc3[mi], 0, 0, 0);
+                    acc3[mi] = MFMA_(wf[0], pf[1][mi], acc3[mi], 0, 0, 0);
+                    acc3[mi] = MFMA_(wf[1], pf[0][mi], acc3[mi], 0, 0, 0);
+                    acc3[mi] = MFMA_(wf[0], pf[0][mi], acc3[mi], 0, 0, 0);
                 }
             }
             if (kc == KC2 - 1) wait_slots(s, s + 2);            // both slots of the next chunk, BEFORE this chunk's stores
@@ -474,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
                     h[e] = (_Float16)acc3[mi][8 * j + e];
                     l[e] = (_Float16)(acc3[mi][8 * j + e] - (float)h[e]);
                 }
+                if (SMAP_CONVB_ABLATE & 4) { if (h[0] == (_Float16)123.25f && l[1] == (_Float16)77.5f) *reinterpret_cast<half8*>(op) = h; continue; }   // keep the values live
                 *reinterpret_cast<half8*>(op) = h;
                 *reinterpret_cast<half8*>(op + a.out_lo) = l;
             }

@@ -9,6 +9,16 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smap_amd import build as B  # noqa: E402
 
+if "--convb" in sys.argv:       # csrc/convb.hip's identity kernel with parts switched off (SMAP_CONVB_ABLATE bits: 1 no x loads, 2 no MFMA,
+    B.build_lib()                # 4 no stores, 8 no weight loads): libsmap_hip_convb<N>.so = the regular objects + an ablated convb.o
+    for n in [int(x) for x in sys.argv[sys.argv.index("--convb") + 1:]]:
+        op = os.path.join(B.OBJ, f"convb_abl{n}.o")
+        subprocess.check_call([B._hipcc()] + B.COMMON + [f"-DSMAP_CONVB_ABLATE={n}", "-c", os.path.join(B.CSRC, "convb.hip"), "-o", op])
+        objs = [os.path.join(B.OBJ, src.rsplit(".", 1)[0] + ".o") if src != "convb.hip" else op for src, _ in B.SOURCES]
+        out = os.path.join(B.OBJ, f"libsmap_hip_convb{n}.so")
+        subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+        print(out)
+    sys.exit(0)
 if "--timeline" in sys.argv:    # per-workgroup start/end stamps of every conv launch: libsmap_hip_timeline.so (tools/trace_pipeline.py)
     objs = []
     for src, extra in B.SOURCES:
