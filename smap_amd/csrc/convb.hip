@@ -33,6 +33,9 @@
 #include "smap_hip.h"
 #include "plan.h"
 
+#ifndef SMAP_CONVB_LDS_KB
+#define SMAP_CONVB_LDS_KB 80     // LDS per workgroup (two per CU); experiments: 64
+#endif
 #ifndef SMAP_CONVB_ABLATE
 #define SMAP_CONVB_ABLATE 0      // diagnostics builds only (tools/build_ablate.py --convb N), identity kernel: 1 no x loads, 2 no MFMA,
 #endif                           // 4 no global stores, 8 no weight loads (W1 stages and the slot ring)
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
     constexpr int Y1_BYTES = KC2 * PROWS * ROWB;                // 32 | 48 KiB
     constexpr int Y2_BYTES = KC2 * BM * ROWB;                   // 16 | 32 KiB: y2 takes over the start of y1's region
     static_assert(Y2_BYTES + C * 4 <= Y1_BYTES && C == 256, "room for the tail-bias table; one bias value per thread");
-    constexpr int LDS_BYTES = 80 * 1024;
+    constexpr int LDS_BYTES = SMAP_CONVB_LDS_KB * 1024;
     // phase 1 stages 16 channels at a time (64-byte rows [hi16 | lo16], one MFMA K step per stage): a 12 | 16 KiB stage, so that
     // 5 | 4 of them are in flight behind the one being multiplied -- x comes from HBM, and with 32-channel stages (3 | 2 of them in
     // 80 KiB) a workgroup waited a full memory latency per stage (profiles/r4_v2_*: 172 us per block)
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_first_kernel(const ConvArgs
     constexpr int Y1_BYTES = KC2 * PROWS * ROWB;                // 32 | 48 KiB
     constexpr int Y2_BYTES = KC2 * BM * ROWB;                   // 16 | 32 KiB: y2 takes over the start of y1's region
     static_assert(Y2_BYTES + C * 4 + P * 4 <= Y1_BYTES && C == 256, "room for the bias tables; one tail-bias value per thread");
-    constexpr int LDS_BYTES = 80 * 1024;
+    constexpr int LDS_BYTES = SMAP_CONVB_LDS_KB * 1024;
     constexpr int SLOT = P * ROWB;                              // 8 KiB weight slot of phases 2 and 3: 64 rows x one 32-channel chunk
     constexpr int NS = (LDS_BYTES - Y1_BYTES) / SLOT;           // ring slots behind y1: 6 | 4
     constexpr int LS = SLOT / 4096;                             // 2 per thread
@@ -975,6 +978,21 @@ int smap_convb_tile_dims(int tile, int* bm, int* bn, int* bn2)
         case 93: *bm = 128; *bn = 64; *bn2 = 64; return 0;      //   8 x 16
         default: return -1;
     }
+}
+
+// tools only (not part of include/smap_hip.h): resident workgroups per CU the runtime reports for a tile id's kernel
+extern "C" int smap_debug_convb_occupancy(int tile)
+{
+    int n = -1;
+    hipError_t e = hipErrorInvalidValue;
+    switch (tile) {
+        case 90: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bottleneck_kernel<4>, 256, 0); break;
+        case 91: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bottleneck_kernel<8>, 256, 0); break;
+        case 92: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bottleneck_first_kernel<4>, 256, 0); break;
+        case 93: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bottleneck_first_kernel<8>, 256, 0); break;
+        default: break;
+    }
+    return e == hipSuccess ? n : -1000 - (int)e;
 }
 
 hipError_t smap_launch_convb(const ConvArgs& a, int tile, hipStream_t st)

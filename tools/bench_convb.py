@@ -49,7 +49,8 @@ def main():
             run()
         e1.record()
         torch.cuda.synchronize()
-        print(f"{os.path.basename(L.SO_PATH):28s} tile {tile} ({g.ops[idx].out.name}): {e0.elapsed_time(e1) / n * 1e3:8.1f} us per launch (warm, back to back)")
+        occ = lib.smap_debug_convb_occupancy(tile) if hasattr(lib, "smap_debug_convb_occupancy") else None
+        print(f"{os.path.basename(L.SO_PATH):28s} occupancy {occ} tile {tile} ({g.ops[idx].out.name}): {e0.elapsed_time(e1) / n * 1e3:8.1f} us per launch (warm, back to back)")
         lib.smap_plan_destroy(h)
 
 

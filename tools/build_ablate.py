@@ -11,9 +11,10 @@ from smap_amd import build as B  # noqa: E402
 
 if "--convb" in sys.argv:       # csrc/convb.hip's identity kernel with parts switched off (SMAP_CONVB_ABLATE bits: 1 no x loads, 2 no MFMA,
     B.build_lib()                # 4 no stores, 8 no weight loads): libsmap_hip_convb<N>.so = the regular objects + an ablated convb.o
-    for n in [int(x) for x in sys.argv[sys.argv.index("--convb") + 1:]]:
+    for n in [x for x in sys.argv[sys.argv.index("--convb") + 1:]]:     # "3" = ablation bits; "lds64" = 64 KiB of LDS per workgroup
         op = os.path.join(B.OBJ, f"convb_abl{n}.o")
-        subprocess.check_call([B._hipcc()] + B.COMMON + [f"-DSMAP_CONVB_ABLATE={n}", "-c", os.path.join(B.CSRC, "convb.hip"), "-o", op])
+        flag = f"-DSMAP_CONVB_LDS_KB={n[3:]}" if n.startswith("lds") else f"-DSMAP_CONVB_ABLATE={n}"
+        subprocess.check_call([B._hipcc()] + B.COMMON + [flag, "-c", os.path.join(B.CSRC, "convb.hip"), "-o", op])
         objs = [os.path.join(B.OBJ, src.rsplit(".", 1)[0] + ".o") if src != "convb.hip" else op for src, _ in B.SOURCES]
         out = os.path.join(B.OBJ, f"libsmap_hip_convb{n}.so")
         subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
