@@ -569,6 +569,8 @@ def main():
                                       f"per step)" if pipe.frames_per_launch > B else "")
                                    + "; one end-of-run gather of the records",
                        "frames_per_launch": pipe.frames_per_launch,
+                       # layer1's Bottlenecks as ONE launch each (csrc/convb.hip): conv launches per forward 206 -> 185
+                       "whole_block_launches": sum(1 for op in pipe.engine.graph.ops if "head" in op.p),
                        # the same steps with ONE backbone launch per step (no coalescing: a batch's records are not held
                        # back for its group), timed in this process right after the headline region
                        "value_launch_frames_0": fps_lf0 if fps_lf0 is not None else (fps if pipe.frames_per_launch == B * (2 if args.flip else 1) else None),
@@ -586,8 +588,8 @@ def main():
                        "host_timeline_ms": {"submit_loop_done": t_loop * 1e3, "flush_done": t_flush * 1e3, "total": dt * 1e3}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "conv_igemm_kernel / conv3x3_halo_kernel (all backbone launches; HIP events: per-schedule span "
-                                   "below, rate = algorithmic FLOPs of the timed region / its duration when depth > 1)",
+                         "kernel": "conv_igemm_kernel / conv3x3_halo_kernel / convp_kernel / bottleneck_kernel (all backbone launches; HIP "
+                                   "events: per-schedule span below, rate = algorithmic FLOPs of the timed region / its duration when depth > 1)",
                          "mfma_flops_executed_per_algorithmic_flop": 3 if x3 else 1,
                          "mfma_pipe_frac": (3 if x3 else 1) * achieved / PEAK_F16_TFLOPS,
                          # the same schedule against the other roof (the launches are bound by the CU's memory
