@@ -461,7 +461,7 @@ extern "C" int smap_conv_tile_bk(int tile, int precision)
 {
     int bm, bn;
     if (smap_conv_tile_dims(tile, &bm, &bn)) return 0;
-    if ((tile >= 30 && tile < 40) || (tile >= 80 && tile < 100)) return precision ? 32 : 64;
+    if ((tile >= 30 && tile < 50) || (tile >= 80 && tile < 100)) return precision ? 32 : 64;
     if (tile >= 60 && tile < 80) return 32;
     if (precision) return (tile <= 4 || tile == 52) ? 64 : 32;
     return ((tile >= 20 && tile <= 27) || tile == 50 || tile == 51 || tile == 53 || tile == 54 || tile == 55) ? 32 : 64;
@@ -479,7 +479,7 @@ extern "C" int smap_conv_tile_tail_bn(int tile)
 //   0..4 : 2-stage (double-buffered) variants; 5..9 : the same tiles with deeper LDS-DMA pipelines
 extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
 {
-    if (tile >= 30 && tile < 40) return smap_conv3_tile_dims(tile, bm, bn);
+    if (tile >= 30 && tile < 50) return smap_conv3_tile_dims(tile, bm, bn);
     if (tile >= 60 && tile < 80) return smap_convp_tile_dims(tile, bm, bn);
     if (tile >= 80 && tile < 90) { int bn2; return smap_convf_tile_dims(tile, bm, bn, &bn2); }
     if (tile >= 90 && tile < 100) { int bn2; return smap_convb_tile_dims(tile, bm, bn, &bn2); }
@@ -504,7 +504,7 @@ extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
 // tiles that have a split-precision instance (plan.hip::validate asks)
 int smap_conv_tile_has_x3(int tile)
 {
-    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 39) || (tile >= 50 && tile <= 55) || (tile >= 60 && tile <= 65) ||
+    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 45) || (tile >= 50 && tile <= 55) || (tile >= 60 && tile <= 65) ||
            (tile >= 80 && tile <= 82) || (tile >= 90 && tile <= 93);
 }
 
@@ -514,7 +514,7 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
     if (tile >= 80 && tile < 90) return smap_launch_convf(a, tile, st);      // 3x3 + fused 1x1 tail, both precisions
     if (tile >= 90 && tile < 100) return smap_launch_convb(a, tile, st);     // whole identity Bottleneck, split precision
     if (a.x3) {
-        if (tile >= 30 && tile < 40) return smap_launch_conv3(a, tile, st);     // halo-tiled 3x3, split-precision instance
+        if (tile >= 30 && tile < 50) return smap_launch_conv3(a, tile, st);     // halo-tiled 3x3, split-precision instance
         switch (tile) {                                     // LDS = max(STAGES * 2 * (BM + BN) * row bytes, fp32 epilogue tile)
             case 0: return launch_x3<128, 128, 2, 2, 2, 64>(a, st);   // 128 KiB: BK = 64, half the barriers per K
             case 1: return launch_x3<128, 64, 2, 2, 2, 64>(a, st);    // 96 KiB
@@ -538,7 +538,7 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
             default: return hipErrorInvalidValue;
         }
     }
-    if (tile >= 30 && tile < 40) return smap_launch_conv3(a, tile, st);
+    if (tile >= 30 && tile < 50) return smap_launch_conv3(a, tile, st);
     switch (tile) {
         case 20: return launch<128, 128, 2, 2, 2, 32>(a, st);   // 64 KiB (fp32 epilogue tile)
         case 21: return launch<128, 64, 2, 2, 2, 32>(a, st);    // 32 KiB

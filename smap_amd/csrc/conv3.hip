@@ -51,26 +51,48 @@ __device__ __forceinline__ void wait_vm(int n)
 
 // ONE = the layer has a single 64-channel chunk (Cin = 64: the layer1 3x3s): no second patch buffer, which takes the
 // workgroup from 80 to 52 KB of LDS (three per CU instead of two; residency is what these kernels are short of).
-template <int BN, int TW, int NB, bool ONE, bool X3>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int tiles_x, int tiles_y)
+// BM = TH x TW output pixels per workgroup (128, or 256 with eight waves), NWV = 4 or 8 waves in a WM x WN grid.  The eight-wave
+// shapes are for the 64x104 / 32x52 levels (round 4): a wave is blocked ~240 cycles per LDS-DMA instruction it issues, so what a wave
+// can multiply between two barriers is bounded by the bytes it has to request for it.  256 pixels x 128 channels halves the weight
+// bytes per MFMA (one workgroup per CU, two waves per SIMD); 128 x 128 with eight waves halves the requests per wave (two
+// workgroups per CU, four waves per SIMD).
+//
+// STAG (eight waves, one workgroup per CU): the two waves of a SIMD (w and w + 4) run HALF AN ITERATION APART.  An iteration is two
+// phases {fragment reads (+ LDS-DMA issue / vmcnt wait) ; barrier ; MFMAs ; barrier}; waves 4..7 pass one extra barrier before the
+// loop (waves 0..3 one after it), so in every barrier interval one wave of each SIMD multiplies while the other reads -- in lockstep
+// both waves expose every LDS and barrier latency to an idle matrix pipe (measured: 40 % of the pipe at best).  Order rules that
+// make it safe (intervals I_k between consecutive barriers; tile T = weight tile of iteration T):
+//   reads of T    : group 0 in I_{4T-1}, I_{4T+1}; group 1 in I_{4T}, I_{4T+2}; each retired (lgkmcnt(0)) BEFORE the reader's next barrier
+//   publish  T    : every wave waits for its slice of T in phase 1 of iteration T-1, before that phase's first barrier (group 1: #4T-1)
+//   refill        : the buffer of T is free from I_{4T+3}; B(T+D+1) = B(it+D) goes into it in phase 0 of it = T+1 (I_{4T+3} / I_{4T+4})
+//   patches       : the same with chunk granularity (issued in phase 0 of tap 0, awaited in phase 1 of tap 8)
+template <int BM, int BN, int TW, int NB, int NWV, int WN, int WPE, bool ONE, bool X3, bool STAG = false>
+__global__ __launch_bounds__(NWV * 64, WPE) void conv3x3_halo_kernel(const ConvArgs a, int tiles_x, int tiles_y)
 {
+    static_assert(!STAG || (NWV == 8 && !ONE), "staggered schedule: eight waves");
+    static_assert(!STAG || (BN / (NWV * 8)) % 2 == 0, "staggered schedule: a weight tile is requested in two halves");
     constexpr int CH = X3 ? 32 : 64;                            // channels per chunk
     constexpr int NPL = X3 ? 2 : 1;
     static_assert(!(ONE && X3), "split precision: Cin = 64 is two chunks");
-    constexpr int BM = 128, TH = BM / TW, PW = TW + 2, PH = TH + 2;
-    constexpr int PROWS = ((PH * PW + 31) / 32) * 32;          // patch rows rounded to a DMA round (32 rows)
-    constexpr int LA = PROWS / 32, LB = BN / 32;
+    static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
+    constexpr int NT = NWV * 64, RND = NWV * 8;                 // threads; rows one round of wave-wide LDS-DMA instructions covers
+    constexpr int TH = BM / TW, PW = TW + 2, PH = TH + 2;
+    static_assert(TH * TW == BM, "pixel tile");
+    constexpr int PROWS = ((PH * PW + RND - 1) / RND) * RND;    // patch rows rounded to a DMA round
+    constexpr int LA = PROWS / RND, LB = BN / RND;
+    static_assert(LB >= 1 && LB * RND == BN, "BN is a multiple of the DMA round");
     constexpr int ROWB = 128;
     constexpr int A_BYTES = PROWS * ROWB, B_BYTES = BN * ROWB;
     constexpr int D = NB - 1;                                   // weight tiles in flight ahead of the one being multiplied
-    static_assert(D >= 1 && D <= 8 && (D - 1) * LB + LA <= 63, "vmcnt is 6 bits");
+    static_assert(D >= 1 && D <= 8 && (D - 1) * LB + LA <= 24, "wait_vm covers 0..24");
     constexpr int NA = ONE ? 1 : 2;                              // patch buffers
     constexpr int PIPE = NA * A_BYTES + NB * B_BYTES;
     constexpr int LDS_BYTES = PIPE > BM * BN * 4 ? PIPE : BM * BN * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;           // 2 x 2 waves (wave tile 64 px x BN/2), or 4 x 1 for BN = 32
+    constexpr int WM = NWV / WN;                                // 2 x 2 waves (wave tile 64 px x BN/2), 4 x 1 for BN = 32, 4 x 2 / 2 x 4 of eight
+    static_assert(WM * WN == NWV, "wave grid");
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
-    static_assert(NI >= 1 && MI >= 1, "BN >= 32");
+    static_assert(NI >= 1 && MI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN, "wave tile");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     SMAP_TL_BEGIN
@@ -93,7 +115,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     // ---- staging offsets (uniform base + 32-bit lane offset; 0 = zero page of the arena)
     const int lrow = lane >> 3, lslot = lane & 7;
     const int srow = wave * 8 + lrow;
-    const int gl = lslot ^ ((srow >> 1) & 7);                   // (prow>>1)&7 == (srow>>1)&7: rounds are 32 rows
+    const int gl = lslot ^ ((srow >> 1) & 7);                   // (prow>>1)&7 == (srow>>1)&7: rounds are 32 / 64 rows
     const int gch = X3 ? (gl & 3) : gl;                         // channel granule inside the chunk ...
     const int gpl = X3 ? (gl >> 2) : 0;                         // ... of plane 0 (hi) / 1 (lo)
     const char* __restrict__ arena = reinterpret_cast<const char*>(a.arena);
@@ -104,21 +126,21 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     const char* __restrict__ wt_tile = wt + (long long)n_tile * w_chunks * 9 * B_BYTES;           // wave-uniform
     unsigned w_off[LB];                                         // per-lane 32-bit offsets inside a block
 #pragma unroll
-    for (int i = 0; i < LB; ++i) w_off[i] = (unsigned)((i * 32 + wave * 8) * ROWB + lane * 16);
+    for (int i = 0; i < LB; ++i) w_off[i] = (unsigned)((i * RND + wave * 8) * ROWB + lane * 16);
     auto issue_b = [&](int buf, int blk) {                      // blk = cc * 9 + tap
         char* sB = smem + NA * A_BYTES + buf * B_BYTES;
         const char* gB = wt_tile + (long long)blk * B_BYTES;
         if (SMAP_ABLATE & 1) return;
 #pragma unroll
         for (int i = 0; i < LB; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + w_off[i]), (lds_void*)(sB + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gB + w_off[i]), (lds_void*)(sB + (i * RND + wave * 8) * ROWB), 16, 0, 0);
     };
     issue_b(0, 0);                                              // weights of (cc 0, tap 0): no pixel math needed
 
     unsigned a_off[LA];                                         // patch pixel -> byte offset of its channel granule gch
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int prow = i * 32 + srow;
+        const int prow = i * RND + srow;
         const int py = prow / PW, px = prow - py * PW;
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
         a_off[i] = 0;
@@ -134,9 +156,22 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
         if (SMAP_ABLATE & 1) return;
 #pragma unroll
         for (int i = 0; i < LA; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_off[i]), (lds_void*)(sA + (i * 32 + wave * 8) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_off[i]), (lds_void*)(sA + (i * RND + wave * 8) * ROWB), 16, 0, 0);
     };
     issue_a(0, 0);
+    auto issue_b_half = [&](int buf, int blk, int half) {       // staggered schedule: pieces [half * LB / 2, (half + 1) * LB / 2) of a weight tile
+        char* sB = smem + NA * A_BYTES + buf * B_BYTES;
+        const char* gB = wt_tile + (long long)blk * B_BYTES;
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            if (i / ((LB + 1) / 2) == half)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(gB + w_off[i]), (lds_void*)(sB + (i * RND + wave * 8) * ROWB), 16, 0, 0);
+    };
+    auto issue_a_piece = [&](int buf, int cc, int i) {
+        char* sA = smem + buf * A_BYTES;
+        const char* gA = arena + (unsigned)(cc * CH * 2);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_off[i]), (lds_void*)(sA + (i * RND + wave * 8) * ROWB), 16, 0, 0);
+    };
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -166,6 +201,81 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     const int n_iter = cchunks * 9;
 #pragma unroll
     for (int d = 1; d < D; ++d) issue_b(d, d);                              // taps 1..D-1 of chunk 0 (D <= 9)
+    if constexpr (STAG) {
+        constexpr int KPP = CH / 32;                                        // k16 steps per phase (two phases per iteration)
+        const int grp = wave >> 2;
+        wait_vm((D - 1) * LB);                                              // B(0), A(0) (issued before B(1..D-1))
+        __builtin_amdgcn_s_barrier();
+        if (grp) __builtin_amdgcn_s_barrier();                              // waves 4..7: half an iteration behind
+        asm volatile("" ::: "memory");
+        for (int cc = 0; cc < cchunks; ++cc) {
+            const bool last = cc + 1 == cchunks;
+            const char* sA = smem + (cc & 1) * A_BYTES;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int it = cc * 9 + tap;
+                const char* sB = smem + NA * A_BYTES + (it % NB) * B_BYTES;
+                const int shift = (tap / 3) * PW + (tap % 3);
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    half8 af[KPP][NPL][MI], bf[KPP][NPL][NI];
+#pragma unroll
+                    for (int kq = 0; kq < KPP; ++kq) {
+                        const int g = (ph * KPP + kq) * 2 + lhi;
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) {
+                                const int prow = prow0[mi] + shift;
+                                af[kq][pl][mi] = *reinterpret_cast<const half8*>(sA + prow * ROWB + (((g + 4 * pl) ^ ((prow >> 1) & 7)) << 4));
+                            }
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni)
+                                bf[kq][pl][ni] = *reinterpret_cast<const half8*>(sB + (b_row0 + ni * 32) * ROWB + (((g + 4 * pl) ^ bswz) << 4));
+                        }
+                    }
+                    // LDS-DMA requests, spread over the read phases (a wave is blocked ~240 cycles per request while the other group
+                    // multiplies for ~384): half of weight tile it+D per phase (buffer of tile it-1: free, see above), and piece
+                    // i = 2 * tap + ph of the next patch in the first LA phases of a chunk.  Loads retire in issue order.
+                    {
+                        const int nt = tap + D;
+                        const int ncc = cc + nt / 9, ntap = nt % 9;
+                        if (ncc < cchunks) issue_b_half((it + D) % NB, ncc * 9 + ntap, ph);
+                        if (2 * tap + ph < LA && !last) issue_a_piece((cc + 1) & 1, cc + 1, 2 * tap + ph);
+                    }
+                    if (ph == 1) {                                          // publish tile it+1 (tap 8: the next patch is older than it)
+                        // requests younger than the last piece of B(it+1) (issued in phase 1 of iteration it+1-D): D-1 whole tiles and
+                        // the patch pieces of phases 2*(tap+1-D)+1 .. 2*tap+1
+                        const int lo_ = 2 * (tap + 1 - D) + 1, hi_ = 2 * tap + 1;
+                        const int na = (hi_ < LA - 1 ? hi_ : LA - 1) - (lo_ > 0 ? lo_ : 0) + 1;
+                        if (last) wait_vm((D - 1 < 7 - tap ? D - 1 : (7 - tap > 0 ? 7 - tap : 0)) * LB);
+                        else wait_vm((D - 1) * LB + (na > 0 ? na : 0));
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this phase's reads are done before anyone refills
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int kq = 0; kq < KPP; ++kq)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) {
+                                if (X3) {
+                                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kq][NPL - 1][mi], bf[kq][0][ni], acc[mi][ni], 0, 0, 0);
+                                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kq][0][mi], bf[kq][NPL - 1][ni], acc[mi][ni], 0, 0, 0);
+                                }
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kq][0][mi], bf[kq][0][ni], acc[mi][ni], 0, 0, 0);
+                            }
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
+        }
+        if (!grp) __builtin_amdgcn_s_barrier();
+    } else
     for (int cc = 0; cc < cchunks; ++cc) {
         const bool last = cc + 1 == cchunks;
         const char* sA = smem + (cc & 1) * A_BYTES;
@@ -242,10 +352,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
             }
     }
     __syncthreads();
-    constexpr int CG = BN / 8, PASSES = BM * CG / 256;
+    constexpr int CG = BN / 8, PASSES = BM * CG / NT;
+    static_assert(PASSES * NT == BM * CG, "tile / thread mismatch");
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-        const int idx = p * 256 + tid;
+        const int idx = p * NT + tid;
         const int row = idx / CG, cg = idx - row * CG;
         const int oy = oy0 + row / TW, ox = ox0 + row % TW, n = n0 + cg * 8;
         if (oy >= a.Ho || ox >= a.Wo || n >= a.Cout8) continue;
@@ -278,33 +389,37 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a, int
     SMAP_TL_END(a)
 }
 
-template <int BN, int TW, int NB>
+template <int BN, int TW, int NB, int BM = 128, int NWV = 4, int WN = (BN >= 64 ? 2 : 1), int WPE = 1, bool STAG = false>
 hipError_t launch3(const ConvArgs& a, hipStream_t st)
 {
-    constexpr int TH = 128 / TW;
+    constexpr int TH = BM / TW;
     const int B = a.M / (a.Ho * a.Wo);
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    const dim3 grid(tiles_x * tiles_y * B * a.n_tiles), block(NWV * 64);
     if (a.x3)
-        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB, false, true>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a,
-                           tiles_x, tiles_y);
-    else if (a.Cin == 64)
-        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB, true, false>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a,
-                           tiles_x, tiles_y);
-    else
-        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, NB, false, false>), dim3(tiles_x * tiles_y * B * a.n_tiles), dim3(256), 0, st, a,
-                           tiles_x, tiles_y);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, TW, NB, NWV, WN, WPE, false, true, STAG>), grid, block, 0, st, a, tiles_x, tiles_y);
+    else if constexpr (NWV == 4) {
+        if (a.Cin == 64)
+            hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, TW, NB, NWV, WN, WPE, true, false>), grid, block, 0, st, a, tiles_x, tiles_y);
+        else
+            hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, TW, NB, NWV, WN, WPE, false, false>), grid, block, 0, st, a, tiles_x, tiles_y);
+    } else
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, TW, NB, NWV, WN, WPE, false, false, STAG>), grid, block, 0, st, a, tiles_x, tiles_y);
     return hipGetLastError();
 }
 
 }  // namespace
 
-// tile ids 30..39: halo-tiled 3x3 (BM is always 128 output pixels)
+// tile ids 30..49: halo-tiled 3x3 (30..39: 128 output pixels, four waves; 40..49: eight waves, 128 or 256 pixels)
 int smap_conv3_tile_dims(int tile, int* bm, int* bn)
 {
     switch (tile) {
         case 30: case 32: case 34: case 36: *bm = 128; *bn = 64; return 0;       // 8x16 / 4x32 pixel tiles
         case 31: case 33: case 35: case 37: *bm = 128; *bn = 128; return 0;
         case 38: case 39: *bm = 128; *bn = 32; return 0;
+        case 40: *bm = 128; *bn = 128; return 0;                                   // 40..43: eight waves
+        case 41: case 43: case 44: case 45: *bm = 256; *bn = 128; return 0;       // 44, 45: 41, 43 with the staggered schedule
+        case 42: *bm = 256; *bn = 64; return 0;
         default: return -1;
     }
 }
@@ -325,6 +440,12 @@ hipError_t smap_launch_conv3(const ConvArgs& a, int tile, hipStream_t st)
         case 37: return launch3<128, 32, 3>(a, st);     // 104 KiB: two
         case 38: return launch3<32, 16, 4>(a, st);      //  64 KiB: Cout <= 32 heads, 4 x 1 waves
         case 39: return launch3<32, 32, 4>(a, st);      //  72 KiB
+        case 40: return launch3<128, 16, 2, 128, 8, 2, 4>(a, st);   //  80 KiB: 8x16 pixels, waves of 32 px x 64 ch, two workgroups per CU (64 x 32 waves spill at 128 VGPRs)
+        case 41: return launch3<128, 16, 3, 256, 8, 2, 2>(a, st);   // 144 KiB: 16x16 pixels, waves of 64 x 64, two weight tiles in flight
+        case 42: return launch3<64, 16, 4, 256, 8, 2, 2>(a, st);    // 128 KiB: 16x16 pixels x 64 channels (the 43-channel heads), waves of 64 x 32
+        case 43: return launch3<128, 32, 3, 256, 8, 2, 2>(a, st);   // 144 KiB: 8x32 pixels
+        case 44: return launch3<128, 16, 3, 256, 8, 2, 2, true>(a, st);   // 41, the two waves of a SIMD half an iteration apart
+        case 45: return launch3<128, 32, 3, 256, 8, 2, 2, true>(a, st);   // 43, staggered
         default: return hipErrorInvalidValue;
     }
 }

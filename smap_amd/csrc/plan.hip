@@ -545,7 +545,7 @@ static int validate(const smap_op& o)
             }
             if (o.ksize != 1 && o.ksize != 3) return SMAP_E_ARG;
             if (o.w_pairs != 0 && o.w_pairs != 1) return SMAP_E_ARG;
-            if (o.tile >= 30 && o.tile < 40 && (o.ksize != 3 || o.stride != 1 || o.pad != 1 || o.res_off >= 0 || o.add1_off >= 0 ||
+            if (o.tile >= 30 && o.tile < 50 && (o.ksize != 3 || o.stride != 1 || o.pad != 1 || o.res_off >= 0 || o.add1_off >= 0 ||
                                  o.add2_off >= 0 || o.aux_off[0] >= 0))
                 return SMAP_E_ARG;                       // halo-tiled kernel: plain 3x3 stride-1 convs only
             if ((o.tile >= 80 && o.tile < 100) != (o.tail_cout > 0)) return SMAP_E_ARG;

@@ -41,6 +41,9 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          30: (128, 64), 31: (128, 128), 32: (128, 64), 33: (128, 128),
          34: (128, 64), 35: (128, 128), 36: (128, 64), 37: (128, 128),     # 34..37: deeper weight pipeline
          38: (128, 32), 39: (128, 32),                                     # Cout <= 32 heads
+         # 40..43: the same kernel with EIGHT waves: 8x16 pixels (two workgroups per CU), 16x16 / 16x16 x 64 channels / 8x32 (one)
+         40: (128, 128), 41: (256, 128), 42: (256, 64), 43: (256, 128),
+         44: (256, 128), 45: (256, 128),                                   # 41 / 43 with the two waves of a SIMD half an iteration apart
          # 50..54: csrc/conv.hip with EIGHT waves per workgroup (two per SIMD from one workgroup: the low-resolution layers)
          50: (128, 128), 51: (128, 128), 52: (128, 128), 53: (256, 128), 54: (128, 256),
          # 55: 4-stage pipeline (three K tiles in flight per workgroup: bytes in flight, not occupancy, for the streaming layers)
@@ -109,7 +112,7 @@ def _table_entry(v):
 
 def tile_legal(tile, *, cout, cout_pad=None, plain3=True, up=False, out_fp32=False):
     """Can tile id `tile` run an op with these properties?  Mirrors csrc/plan.hip::validate."""
-    if 30 <= tile < 40:
+    if 30 <= tile < 50:
         return plain3
     if 80 <= tile < 100:
         return False                     # only Graph.conv_tail / Graph.conv_block build these
@@ -155,7 +158,7 @@ def pick_tile_x3(M, cout, key=None):
 def tile_family(tile):
     """Which kernel a tile id selects: "halo" (csrc/conv3.hip; csrc/convf.hip = the same 3x3 with a fused 1x1 tail),
     "persist" (csrc/convp.hip) or "igemm" (csrc/conv.hip)."""
-    return "halo" if (30 <= tile < 40 or 80 <= tile < 100) else "persist" if 60 <= tile < 80 else "igemm"
+    return "halo" if (30 <= tile < 50 or 80 <= tile < 100) else "persist" if 60 <= tile < 80 else "igemm"
 
 
 def tile_bk(tile, x3):

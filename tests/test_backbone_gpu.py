@@ -175,6 +175,15 @@ CASES = [
     (1, 12, 20, 192, 256, 3, 1, 35, True, False, False),
     (1, 16, 36, 64, 64, 3, 1, 36, True, False, False),
     (1, 16, 36, 128, 256, 3, 1, 37, False, False, False),
+    # ... with eight waves (tile ids 40..43): 8x16 pixels, 16x16, 16x16 x 64 channels, 8x32
+    (2, 16, 24, 128, 128, 3, 1, 40, True, False, False),
+    (3, 10, 14, 192, 320, 3, 1, 41, True, False, False),     # ragged in both directions, Cout not a tile multiple
+    (1, 16, 24, 256, 43, 3, 1, 42, False, False, False),
+    (2, 13, 52, 64, 256, 3, 1, 43, True, False, False),      # one 64-channel chunk
+    (1, 32, 52, 256, 256, 3, 1, 41, True, False, False),
+    (3, 10, 14, 192, 320, 3, 1, 44, True, False, False),     # staggered schedule
+    (2, 13, 52, 64, 256, 3, 1, 45, True, False, False),
+    (2, 32, 52, 256, 256, 3, 1, 45, True, False, False),
 ]
 
 
@@ -237,6 +246,17 @@ X3_CASES = [
     (1, 16, 36, 128, 256, 3, 1, 37, False, False, False),
     (1, 16, 24, 256, 14, 3, 1, 38, False, False, False),
     (2, 10, 40, 128, 1, 3, 1, 39, False, False, False),
+    # ... with eight waves (tile ids 40..43)
+    (2, 16, 24, 128, 128, 3, 1, 40, True, False, False),
+    (3, 10, 14, 192, 320, 3, 1, 41, True, False, False),
+    (1, 16, 24, 256, 43, 3, 1, 42, False, False, False),
+    (2, 13, 52, 64, 256, 3, 1, 43, True, False, False),
+    (1, 32, 52, 256, 256, 3, 1, 41, True, False, False),
+    (2, 17, 33, 128, 128, 3, 1, 43, True, False, False),
+    (3, 10, 14, 192, 320, 3, 1, 44, True, False, False),     # staggered schedule: odd sizes, two n tiles, 6 chunks
+    (2, 13, 52, 64, 256, 3, 1, 45, True, False, False),      # two chunks (the shortest pipeline)
+    (2, 32, 52, 256, 256, 3, 1, 45, True, False, False),
+    (1, 32, 52, 256, 256, 3, 1, 44, False, False, False),
 ]
 
 
@@ -603,7 +623,7 @@ def test_split_precision_fp32_out_and_channel_slice():
     assert (got[..., :cout] - ref).abs().max().item() < 3e-6 * ref.abs().max().item() + 1e-6
 
 
-@pytest.mark.parametrize("tile", [30, 36, 38])
+@pytest.mark.parametrize("tile", [30, 36, 38, 42])
 def test_halo_conv_split_precision_fp32_out_and_channel_slice(tile):
     cout = 14 if tile == 38 else 43
     got, ref, cout = _run_single_conv(1, 16, 24, 256, cout, 3, 1, tile, False, False, False, out_fp32=True,
@@ -632,7 +652,7 @@ def test_halo_conv_rejects_fused_epilogues():
     with pytest.raises(SmapError):
         _run_single_conv(1, 16, 24, 64, 64, 1, 1, 30, True, False, False)
     with pytest.raises(SmapError):                     # tile ids of kernels that are no longer in the product build
-        _run_single_conv(1, 16, 24, 64, 256, 1, 1, 40, True, False, False)
+        _run_single_conv(1, 16, 24, 64, 256, 1, 1, 45, True, False, False)
     with pytest.raises(SmapError):
         _run_single_conv(1, 16, 24, 64, 256, 1, 1, 12, True, False, False)
     with pytest.raises(SmapError):                     # split precision only on the tiles that have an X3 instance
@@ -696,7 +716,7 @@ def test_small_schedule_split_precision_every_tensor(golden_dir, small, monkeypa
     x = torch.from_numpy(z["x"])
     eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision="x3")
     from smap_amd.engine import X3_TILES
-    assert all(op.p["tile"] in X3_TILES + (3,) + tuple(range(30, 40)) for op in eng.graph.ops if op.kind == 0)
+    assert all(op.p["tile"] in X3_TILES + (3,) + tuple(range(30, 46)) for op in eng.graph.ops if op.kind == 0)
     outs = [o.cpu() for o in eng.run(x.to(DEV))]
     torch.cuda.synchronize()
     g = Graph(sd, 2, 64, 96, keep_ref=True)
@@ -724,7 +744,7 @@ def test_small_schedule_split_precision_with_halo_kernel(golden_dir, small, monk
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision="x3")
-    assert any(30 <= op.p["tile"] < 40 for op in eng.graph.ops if op.kind == 0)
+    assert any(30 <= op.p["tile"] < 50 for op in eng.graph.ops if op.kind == 0)
     outs = [o.cpu() for o in eng.run(torch.from_numpy(z["x"]).to(DEV))]
     for a, k in zip(outs, ("hms", "det_d", "root_d")):
         assert np.abs(a.numpy() - z[k]).max() < 2e-5 * np.abs(z[k]).max(), k

@@ -56,7 +56,7 @@ def test_x3_graph_emits_split_strides_and_weights(small_sd, monkeypatch, blocks)
         if op.kind == OP_CONV:
             x, y = op.inp, op.out
             assert x.planes == 2 and o.in_stride_c == 2 * x.C and o.in_c_off + o.Cin <= x.C
-            assert o.tile in X3_TILES + (3,) + tuple(range(30, 40)) + (91, 93) and o.acc_scale > 0
+            assert o.tile in X3_TILES + (3,) + tuple(range(30, 46)) + (91, 93) and o.acc_scale > 0
             assert (y.planes, o.out_stride_c) == ((1, y.C) if o.out_fp32 else (2, 2 * y.C))
             assert o.in_off >= ZERO_PAGE and o.Cin * 2 + o.in_stride_c + 16 <= ZERO_PAGE
             for t in (op.res, op.add1, op.add2):
@@ -145,7 +145,7 @@ def test_tile_tables_name_existing_tiles():
     t16 = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table.json")))
     tx3 = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table_x3.json")))
     assert t16 and all(t in TILES for v in t16.values() for t in _table_entry(v))
-    assert tx3 and all(t in X3_TILES + (3,) + tuple(range(30, 40)) for v in tx3.values() for t in _table_entry(v))
+    assert tx3 and all(t in X3_TILES + (3,) + tuple(range(30, 46)) for v in tx3.values() for t in _table_entry(v))
     for key, v in tx3.items():
         B, H, W, cin, cout, k, s = map(int, key.split(",")[:7])              # optional 8th field: "up" (ops with a fused bilinear add)
         assert key.split(",")[7:] in ([], ["up"])
