@@ -586,18 +586,20 @@ def main():
                                             "busiest_threads_cpu_ms": [[n, round(v, 2)] for n, v in busiest]},
                        "host_submit_ms_quantiles": [float(np.percentile(host["steps"], q)) for q in (0, 10, 50, 90, 100)],
                        "host_timeline_ms": {"submit_loop_done": t_loop * 1e3, "flush_done": t_flush * 1e3, "total": dt * 1e3}},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            # The roof the schedule is under is the CU's memory path (HBM / Infinity Cache reads and writes plus the L2 -> LDS staging
+            # stream add up per launch: DESIGN.md 6, EXPERIMENTS R3.2 / R4.2b: with two forwards in flight the frames/s follow the bytes
+            # and are insensitive to how well a launch uses the matrix pipe), so `bound` is "hbm": algorithmic bytes of the launches
+            # (fused launches count what THEY must move: x + out + weights) / time.  The MFMA view of the same region is under "mfma".
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / step_s / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": alg_bytes / step_s / 1e9 / PEAK_HBM_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_batch": alg_bytes,
                          "kernel": "conv_igemm_kernel / conv3x3_halo_kernel / convp_kernel / bottleneck_kernel (all backbone launches; HIP "
-                                   "events: per-schedule span below, rate = algorithmic FLOPs of the timed region / its duration when depth > 1)",
-                         "mfma_flops_executed_per_algorithmic_flop": 3 if x3 else 1,
-                         "mfma_pipe_frac": (3 if x3 else 1) * achieved / PEAK_F16_TFLOPS,
-                         # the same schedule against the other roof (the launches are bound by the CU's memory
-                         # path, not by the MFMA pipe): unfused algorithmic bytes of the conv launches / time per batch
-                         "memory_path": {"algorithmic_bytes_per_batch": alg_bytes, "achieved_GBps": alg_bytes / step_s / 1e9,
-                                         "peak_GBps": PEAK_HBM_GBPS, "frac_of_hbm_peak": alg_bytes / step_s / 1e9 / PEAK_HBM_GBPS,
-                                         "measured_ceilings_GBps": {"hbm_read": 5300, "hbm_write": 6200, "hbm_mixed": 5200,
-                                                                    "source": "profiles/r2_v17_ubench_hbm_read_write_mix.log"}},
+                                   "events: per-schedule span below, rate = algorithmic bytes of the timed region / its duration when depth > 1)",
+                         "measured_ceilings_GBps": {"hbm_read": 5300, "hbm_write": 6200, "hbm_mixed": 5200,
+                                                    "source": "profiles/r2_v17_ubench_hbm_read_write_mix.log"},
+                         "mfma": {"achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
+                                  "flops_executed_per_algorithmic_flop": 3 if x3 else 1,
+                                  "pipe_frac": (3 if x3 else 1) * achieved / PEAK_F16_TFLOPS},
                          "backbone_ms_per_launch": bb * 1e3,
                          "backbone_stream_idle_ms_between_batches": float(np.mean(gap_ms)) if gap_ms else None,
                          "algorithmic_gflop_per_frame": ALG_GFLOP_PER_FRAME},

@@ -17,7 +17,7 @@ import json
 for f in ("bench_x3", "bench_x3_driver_form", "bench_x3_flip", "bench_x3_refine", "bench_x3_forward_b1", "bench_f16"):
     try:
         d = json.load(open(f"gpurun_out/r4v5/{f}.json")); c = d["config"]; m = c.get("e2e_parity") or {}
-        print(f, round(d["value"], 1), "lf0", c.get("value_launch_frames_0"), "frac", round(d["roofline"]["frac"], 4),
+        print(f, round(d["value"], 1), "lf0", c.get("value_launch_frames_0"), "frac", round(d["roofline"]["frac"], 4), "mfma", round(d["roofline"].get("mfma", {}).get("frac", 0), 4),
               {k: m.get(k) for k in ("peaks_differing", "peaks_clear_mismatch", "max_joint_err_cm", "joints_over_0.1cm_unexplained", "lifter_tie_events", "timed_records_equal_these_frames")})
     except Exception as e:
         print(f, "ERR", e)
