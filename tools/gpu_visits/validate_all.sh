@@ -1,22 +1,26 @@
 #!/bin/bash
-# round 4, visit 5: whole-block launches ON by default -- the whole suite, the bench lines with timed-path parity, rocprofv3 stats of
-# the driver's command, per-layer trace, HBM traffic and MFMA utilisation from PMC passes (each its own run), host-budget rehearsal
+# The round-end validation, one visit: the whole GPU suite, smoke(), the bench lines with timed-path parity (default, driver form, flip,
+# RefineNet, batch-1 forward, f16), rocprofv3 --kernel-trace --stats of the driver's command, per-layer trace at depth 1, HBM traffic and
+# MFMA utilisation from PMC passes (each its own run, with --kernel-trace only), host-budget rehearsal.
+#     bash tools/gpu_visits/validate_all.sh <tag>      -> gpurun_out/<tag>/   (profiles/<round>_final_* are copies of these files)
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"
-O=$R/gpurun_out/r4v5; mkdir -p $O
+TAG=${1:-final}
+O=$R/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
 tail -8 $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 timeout 400 python bench.py > $O/bench_x3.json 2> $O/bench_x3.err; echo "rc $?" >> $O/bench_x3.err
 timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_x3_driver_form.json 2>> $O/bench_x3.err
 timeout 400 python bench.py --flip --steps 40 > $O/bench_x3_flip.json 2> $O/bench_x3_flip.err
 timeout 400 python bench.py --refine --steps 60 > $O/bench_x3_refine.json 2> $O/bench_x3_refine.err
 timeout 300 python bench.py --forward-only --batch 1 --steps 200 --warmup 20 > $O/bench_x3_forward_b1.json 2>> $O/bench_x3.err
 timeout 300 python bench.py --precision f16 --steps 60 > $O/bench_f16.json 2>> $O/bench_x3.err
-python - <<'PY'
-import json
+TAG=$TAG python - <<'PY'
+import json, os
 for f in ("bench_x3", "bench_x3_driver_form", "bench_x3_flip", "bench_x3_refine", "bench_x3_forward_b1", "bench_f16"):
     try:
-        d = json.load(open(f"gpurun_out/r4v5/{f}.json")); c = d["config"]; m = c.get("e2e_parity") or {}
+        d = json.load(open("gpurun_out/%s/%s.json" % (os.environ["TAG"], f))); c = d["config"]; m = c.get("e2e_parity") or {}
         print(f, round(d["value"], 1), "lf0", c.get("value_launch_frames_0"), "frac", round(d["roofline"]["frac"], 4), "mfma", round(d["roofline"].get("mfma", {}).get("frac", 0), 4),
               {k: m.get(k) for k in ("peaks_differing", "peaks_clear_mismatch", "max_joint_err_cm", "joints_over_0.1cm_unexplained", "lifter_tie_events", "timed_records_equal_these_frames")})
     except Exception as e:
