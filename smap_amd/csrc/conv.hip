@@ -47,8 +47,9 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 //              (A hi, A lo, W hi, W lo); the epilogue re-splits the fp32 result.  3x the MFMA work and 2x the bytes of
 //              the fp16 mode, ~1e-6 relative error instead of ~1e-3: the mode whose output meets the reference's fp32.
 // WM x WN = 4 or 8 waves.  Eight waves (two per SIMD from ONE workgroup) are for the low-resolution layers whose grids
-// do not fill the chip: a lone wave issues an MFMA only every ~80 cycles, two waves per SIMD reach the pipe rate
-// (tools/ubench/mfma_clock.hip), and with <= 256 workgroups of 4 waves there is no second wave on the SIMD.
+// do not fill the chip: with <= 256 workgroups of 4 waves there is no second wave on the SIMD to multiply while the first
+// one waits for its fragments, its LDS-DMA requests or the barrier (a lone wave CAN issue an MFMA every 32 cycles:
+// tools/ubench/mfma_issue.hip; what it cannot do is hide its own stalls).
 template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a)
 {

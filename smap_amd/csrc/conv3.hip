@@ -27,7 +27,7 @@
 #include "plan.h"
 
 #ifndef SMAP_ABLATE
-#define SMAP_ABLATE 0      // diagnostics builds only (tools/build_ablate.py): 1 no LDS-DMA, 2 no MFMA, 8 no epilogue, 16 no ds_read
+#define SMAP_ABLATE 0      // diagnostics builds only (tools/build_ablate.py [--conv3]): 1 no LDS-DMA, 2 no MFMA, 8 no epilogue, 16 no ds_read, 32 no barriers in the staggered loop
 #endif
 
 namespace {
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void conv3x3_halo_kernel(const ConvA
     auto issue_b_half = [&](int buf, int blk, int half) {       // staggered schedule: pieces [half * LB / 2, (half + 1) * LB / 2) of a weight tile
         char* sB = smem + NA * A_BYTES + buf * B_BYTES;
         const char* gB = wt_tile + (long long)blk * B_BYTES;
+        if (SMAP_ABLATE & 1) return;
 #pragma unroll
         for (int i = 0; i < LB; ++i)
             if (i / ((LB + 1) / 2) == half)
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void conv3x3_halo_kernel(const ConvA
     auto issue_a_piece = [&](int buf, int cc, int i) {
         char* sA = smem + buf * A_BYTES;
         const char* gA = arena + (unsigned)(cc * CH * 2);
+        if (SMAP_ABLATE & 1) return;
         __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_off[i]), (lds_void*)(sA + (i * RND + wave * 8) * ROWB), 16, 0, 0);
     };
 
@@ -227,11 +229,14 @@ __global__ __launch_bounds__(NWV * 64, WPE) void conv3x3_halo_kernel(const ConvA
 #pragma unroll
                             for (int mi = 0; mi < MI; ++mi) {
                                 const int prow = prow0[mi] + shift;
+                                if (SMAP_ABLATE & 16) { for (int e = 0; e < 8; ++e) af[kq][pl][mi][e] = (_Float16)(float)(lane + g); continue; }
                                 af[kq][pl][mi] = *reinterpret_cast<const half8*>(sA + prow * ROWB + (((g + 4 * pl) ^ ((prow >> 1) & 7)) << 4));
                             }
 #pragma unroll
-                            for (int ni = 0; ni < NI; ++ni)
+                            for (int ni = 0; ni < NI; ++ni) {
+                                if (SMAP_ABLATE & 16) { for (int e = 0; e < 8; ++e) bf[kq][pl][ni][e] = (_Float16)(float)(tap + g); continue; }
                                 bf[kq][pl][ni] = *reinterpret_cast<const half8*>(sB + (b_row0 + ni * 32) * ROWB + (((g + 4 * pl) ^ bswz) << 4));
+                            }
                         }
                     }
                     // LDS-DMA requests, spread over the read phases (a wave is blocked ~240 cycles per request while the other group
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void conv3x3_halo_kernel(const ConvA
                         else wait_vm((D - 1) * LB + (na > 0 ? na : 0));
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this phase's reads are done before anyone refills
-                    __builtin_amdgcn_s_barrier();
+                    if (!(SMAP_ABLATE & 32)) __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void conv3x3_halo_kernel(const ConvA
                         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                             for (int ni = 0; ni < NI; ++ni) {
+                                if (SMAP_ABLATE & 2) { acc[mi][ni][kq + ph] += (float)af[kq][0][mi][0] + (float)bf[kq][0][ni][1] + (float)af[kq][NPL - 1][mi][2] + (float)bf[kq][NPL - 1][ni][3]; continue; }
                                 if (X3) {
                                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kq][NPL - 1][mi], bf[kq][0][ni], acc[mi][ni], 0, 0, 0);
                                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kq][0][mi], bf[kq][NPL - 1][ni], acc[mi][ni], 0, 0, 0);
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void conv3x3_halo_kernel(const ConvA
                             }
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_barrier();
+                    if (!(SMAP_ABLATE & 32)) __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
             }

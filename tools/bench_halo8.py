@@ -27,19 +27,25 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--precision", choices=("f16", "x3"), default="x3")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="", help="H,W,Cin,Cout: this shape only")
+    ap.add_argument("--tiles", default="", help="comma-separated tile ids instead of the default candidate list (ablation builds: SMAP_HIP_LIB=...)")
     args = ap.parse_args()
     x3 = args.precision == "x3"
     table = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table_x3.json" if x3 else "tile_table.json")))
     dev = torch.device("cuda:0")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     lib = L.load()
-    for H, W, Cin, Cout in SHAPES:
+    shapes = [tuple(int(v) for v in args.only.split(","))] if args.only else SHAPES
+    for H, W, Cin, Cout in shapes:
         key = f"{args.batch},{H},{W},{Cin},{Cout},3,1"
         shipped = _table_entry(table[key])[:2] if key in table else []
         new = [t for t in (40, 41, 42, 43, 44, 45) if not (Cout <= 64 and TILES[t][1] > 64) and not (Cout > 64 and TILES[t][1] == 64)]
         res = {}
-        for t in shipped + [t for t in (31, 35, 34, 36, 52, 60) if t not in shipped and not (Cout <= 64 and TILES[t][1] > 64)
-                            and not (Cout > 64 and TILES[t][1] == 64)] + new:
+        cands = shipped + [t for t in (31, 35, 34, 36, 52, 60) if t not in shipped and not (Cout <= 64 and TILES[t][1] > 64)
+                           and not (Cout > 64 and TILES[t][1] == 64)] + new
+        if args.tiles:
+            cands = [int(t) for t in args.tiles.split(",")]
+        for t in cands:
             try:
                 _, h, arena, blob, flops, byts = build(args.batch, H, W, Cin, Cout, 3, 1, t, 0, dev, x3=x3)
             except L.SmapError:

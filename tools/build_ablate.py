@@ -20,6 +20,16 @@ if "--convb" in sys.argv:       # csrc/convb.hip's identity kernel with parts sw
         subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
         print(out)
     sys.exit(0)
+if "--conv3" in sys.argv:       # csrc/conv3.hip alone with SMAP_ABLATE bits (1 no LDS-DMA, 2 no MFMA, 8 no epilogue, 16 no ds_read, 32 no barriers in the
+    B.build_lib()                # staggered loop): libsmap_hip_conv3abl<N>.so = the regular objects + an ablated conv3.o
+    for n in sys.argv[sys.argv.index("--conv3") + 1:]:
+        op = os.path.join(B.OBJ, f"conv3_abl{n}.o")
+        subprocess.check_call([B._hipcc()] + B.COMMON + [f"-DSMAP_ABLATE={n}", "-c", os.path.join(B.CSRC, "conv3.hip"), "-o", op])
+        objs = [os.path.join(B.OBJ, src.rsplit(".", 1)[0] + ".o") if src != "conv3.hip" else op for src, _ in B.SOURCES]
+        out = os.path.join(B.OBJ, f"libsmap_hip_conv3abl{n}.so")
+        subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+        print(out)
+    sys.exit(0)
 if "--timeline" in sys.argv:    # per-workgroup start/end stamps of every conv launch: libsmap_hip_timeline.so (tools/trace_pipeline.py)
     objs = []
     for src, extra in B.SOURCES:
