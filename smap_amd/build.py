@@ -23,6 +23,7 @@ SOURCES = [
     ("convp.hip", []),
     ("convf.hip", []),
     ("convb.hip", []),
+    ("convc.hip", []),
     ("plan.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),

@@ -506,7 +506,7 @@ extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
 int smap_conv_tile_has_x3(int tile)
 {
     return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 45) || (tile >= 50 && tile <= 55) || (tile >= 60 && tile <= 65) ||
-           (tile >= 80 && tile <= 82) || (tile >= 90 && tile <= 93);
+           (tile >= 80 && tile <= 82) || (tile >= 90 && tile <= 94);
 }
 
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)

@@ -26,6 +26,12 @@
 #include "smap_hip.h"
 #include "plan.h"
 
+#ifndef SMAP_STAG_DMA_IN_MFMA
+#define SMAP_STAG_DMA_IN_MFMA 0   // staggered schedule: LDS-DMA requests issued from inside the MFMA burst instead of the read phase
+#endif
+#ifndef SMAP_STAG_DMA_POS
+#define SMAP_STAG_DMA_POS 3       // ... in front of the MFMAs of accumulator POS (0..3) of the burst's first K step; 10 + POS: weight half there, patch piece before accumulator 3
+#endif
 #ifndef SMAP_ABLATE
 #define SMAP_ABLATE 0      // diagnostics builds only (tools/build_ablate.py [--conv3]): 1 no LDS-DMA, 2 no MFMA, 8 no epilogue, 16 no ds_read, 32 no barriers in the staggered loop
 #endif
@@ -239,22 +245,31 @@ __global__ __launch_bounds__(NWV * 64, WPE) void conv3x3_halo_kernel(const ConvA
                             }
                         }
                     }
-                    // LDS-DMA requests, spread over the read phases (a wave is blocked ~240 cycles per request while the other group
-                    // multiplies for ~384): half of weight tile it+D per phase (buffer of tile it-1: free, see above), and piece
+                    // LDS-DMA requests: half of weight tile it+D per phase (buffer of tile it-1: free, see above), and piece
                     // i = 2 * tap + ph of the next patch in the first LA phases of a chunk.  Loads retire in issue order.
-                    {
+                    auto requests = [&](int what = 3) {                     // 1: the weight half, 2: the patch piece
                         const int nt = tap + D;
                         const int ncc = cc + nt / 9, ntap = nt % 9;
-                        if (ncc < cchunks) issue_b_half((it + D) % NB, ncc * 9 + ntap, ph);
-                        if (2 * tap + ph < LA && !last) issue_a_piece((cc + 1) & 1, cc + 1, 2 * tap + ph);
-                    }
+                        if ((what & 1) && ncc < cchunks) issue_b_half((it + D) % NB, ncc * 9 + ntap, ph);
+                        if ((what & 2) && 2 * tap + ph < LA && !last) issue_a_piece((cc + 1) & 1, cc + 1, 2 * tap + ph);
+                    };
+                    if (!SMAP_STAG_DMA_IN_MFMA) requests();                 // in the read phase (a wave is held ~240 cycles per request there)
                     if (ph == 1) {                                          // publish tile it+1 (tap 8: the next patch is older than it)
-                        // requests younger than the last piece of B(it+1) (issued in phase 1 of iteration it+1-D): D-1 whole tiles and
-                        // the patch pieces of phases 2*(tap+1-D)+1 .. 2*tap+1
-                        const int lo_ = 2 * (tap + 1 - D) + 1, hi_ = 2 * tap + 1;
-                        const int na = (hi_ < LA - 1 ? hi_ : LA - 1) - (lo_ > 0 ? lo_ : 0) + 1;
-                        if (last) wait_vm((D - 1 < 7 - tap ? D - 1 : (7 - tap > 0 ? 7 - tap : 0)) * LB);
-                        else wait_vm((D - 1) * LB + (na > 0 ? na : 0));
+                        if (SMAP_STAG_DMA_IN_MFMA) {
+                            // D = 2, requests of phase (it, ph) issued inside that phase's MFMA burst: younger than the last piece of
+                            // B(it+1) (burst of (it-1, 1)) are the patch piece of that burst, and B(it+2)'s first half + patch piece of burst (it, 0)
+                            static_assert(!SMAP_STAG_DMA_IN_MFMA || D == 2, "derived for two weight tiles in flight");
+                            const int na = ((2 * tap - 1 >= 0 && 2 * tap - 1 < LA) ? 1 : 0) + ((2 * tap < LA) ? 1 : 0);
+                            if (last) wait_vm(tap + 2 <= 8 ? LB / 2 : 0);
+                            else wait_vm(LB / 2 + na);
+                        } else {
+                            // requests younger than the last piece of B(it+1) (issued in phase 1 of iteration it+1-D): D-1 whole tiles and
+                            // the patch pieces of phases 2*(tap+1-D)+1 .. 2*tap+1
+                            const int lo_ = 2 * (tap + 1 - D) + 1, hi_ = 2 * tap + 1;
+                            const int na = (hi_ < LA - 1 ? hi_ : LA - 1) - (lo_ > 0 ? lo_ : 0) + 1;
+                            if (last) wait_vm((D - 1 < 7 - tap ? D - 1 : (7 - tap > 0 ? 7 - tap : 0)) * LB);
+                            else wait_vm((D - 1) * LB + (na > 0 ? na : 0));
+                        }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this phase's reads are done before anyone refills
                     if (!(SMAP_ABLATE & 32)) __builtin_amdgcn_s_barrier();
@@ -266,6 +281,15 @@ __global__ __launch_bounds__(NWV * 64, WPE) void conv3x3_halo_kernel(const ConvA
                         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                             for (int ni = 0; ni < NI; ++ni) {
+                                if (SMAP_STAG_DMA_IN_MFMA && kq == 0) {
+                                    constexpr int pos = SMAP_STAG_DMA_POS % 10, split = SMAP_STAG_DMA_POS >= 10;
+                                    const int idx = mi * NI + ni;
+                                    if (idx == pos || (split && idx == MI * NI - 1)) {
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        requests(!split ? 3 : idx == pos ? 1 : 2);
+                                        __builtin_amdgcn_sched_barrier(0);
+                                    }
+                                }
                                 if (SMAP_ABLATE & 2) { acc[mi][ni][kq + ph] += (float)af[kq][0][mi][0] + (float)bf[kq][0][ni][1] + (float)af[kq][NPL - 1][mi][2] + (float)bf[kq][NPL - 1][ni][3]; continue; }
                                 if (X3) {
                                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kq][NPL - 1][mi], bf[kq][0][ni], acc[mi][ni], 0, 0, 0);

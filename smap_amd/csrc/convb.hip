@@ -976,6 +976,7 @@ int smap_convb_tile_dims(int tile, int* bm, int* bn, int* bn2)
         case 91: *bm = 128; *bn = 64; *bn2 = 64; return 0;      // 8 x 16
         case 92: *bm = 64; *bn = 64; *bn2 = 64; return 0;       // FIRST block of a layer (64 input channels, 1x1 shortcut conv): 4 x 16
         case 93: *bm = 128; *bn = 64; *bn2 = 64; return 0;      //   8 x 16
+        case 94: *bm = 128; *bn = 128; *bn2 = 128; return 0;    // csrc/convc.hip: identity blocks of 128 planes / 512 channels, 8 x 16
         default: return -1;
     }
 }
@@ -997,6 +998,7 @@ extern "C" int smap_debug_convb_occupancy(int tile)
 
 hipError_t smap_launch_convb(const ConvArgs& a, int tile, hipStream_t st)
 {
+    if (tile == 94) return smap_launch_convc(a, st);
     if (!a.x3 || a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.up || a.out_fp32 || !a.w0 || !a.w2 || a.Cin != 64 ||
         a.tail_cout8 != 256 || a.H != a.Ho || a.W != a.Wo)
         return hipErrorInvalidValue;

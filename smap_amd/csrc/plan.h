@@ -77,6 +77,7 @@ int smap_convf_tile_dims(int tile, int* bm, int* bn, int* bn2);             // c
 hipError_t smap_launch_convf(const ConvArgs& a, int tile, hipStream_t st);
 int smap_convb_tile_dims(int tile, int* bm, int* bn, int* bn2);             // convb.hip (tile ids 90..99, whole identity Bottleneck)
 hipError_t smap_launch_convb(const ConvArgs& a, int tile, hipStream_t st);
+hipError_t smap_launch_convc(const ConvArgs& a, hipStream_t st);           // convc.hip (tile id 94: the same for 128 planes / 512 channels)
 
 #ifdef SMAP_TIMELINE
 // every workgroup of a conv kernel calls these two (first / last statement): 100 MHz device-wide clock

@@ -553,7 +553,9 @@ static int validate(const smap_op& o)
             if (o.tile >= 90 && o.tile < 100) {          // whole Bottleneck (convb.hip): split precision, P = 64 planes, 256 output channels
                 const bool first = o.tile == 92 || o.tile == 93;       // a layer's FIRST block: 64 input channels, 1x1 shortcut conv instead of + x
                 if (o.precision != 1 || o.ksize != 3 || o.stride != 1 || o.pad != 1 || o.out_fp32 || o.aux_off[0] >= 0) return SMAP_E_ARG;
-                if (o.Cin != 64 || o.Cout != 64 || o.cout_pad != 64 || o.head_cin != (first ? 64 : 256) || o.tail_cout != 256 || o.tail_cout_pad != 256)
+                const int planes = o.tile == 94 ? 128 : 64;            // 94: csrc/convc.hip, 128 planes / 512 channels
+                if (o.Cin != planes || o.Cout != planes || o.cout_pad != planes || o.head_cin != (first ? 64 : 4 * planes) || o.tail_cout != 4 * planes ||
+                    o.tail_cout_pad != 4 * planes)
                     return SMAP_E_ARG;
                 if (o.in_stride_c != 2 * o.head_cin || o.in_c_off != 0) return SMAP_E_ARG;
                 if (first ? (o.res_off >= 0 || o.add1_off >= 0 || o.add2_off >= 0 || o.short_w_off < 0 || !(o.short_acc_scale > 0.f))

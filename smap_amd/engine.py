@@ -55,9 +55,11 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          # 90..91: csrc/convb.hip, a whole identity Bottleneck of 64 planes (1x1 -> 3x3 -> 1x1 + residual) per 4x16 / 8x16 pixel tile
          90: (64, 64), 91: (128, 64),
          # 92..93: the same for the FIRST block of layer1 (64 input channels, 1x1 shortcut conv instead of the identity residual)
-         92: (64, 64), 93: (128, 64)}
+         92: (64, 64), 93: (128, 64),
+         # 94: csrc/convc.hip, the whole identity Bottleneck of 128 planes / 512 channels (layer2) per 8x16 pixel tile, eight waves
+         94: (128, 128)}
 TAIL_DEFAULT = {}                          # Bottleneck planes -> fused tile id (empty: every block runs c2 and c3 as two launches)
-TAIL_BN = {80: 64, 81: 128, 82: 64, 90: 64, 91: 64, 92: 64, 93: 64}      # output channels per chunk of the fused 1x1 (csrc/convf.hip::smap_convf_tile_dims)
+TAIL_BN = {80: 64, 81: 128, 82: 64, 90: 64, 91: 64, 92: 64, 93: 64, 94: 128}      # output channels per chunk of the fused 1x1 (csrc/convf.hip::smap_convf_tile_dims)
 # Bottleneck planes -> tile id of the WHOLE-block launch (csrc/convb.hip) for stride-1 identity blocks in split precision; {} = off.
 # SMAP_BLOCK="64:91" overrides (A/B hook; "" = off).  BLOCK_FIRST_DEFAULT / SMAP_BLOCK_FIRST="64:93": the same for the first block of
 # layer1 (the one with a shortcut conv; 64 input channels).
@@ -569,10 +571,14 @@ class Graph:
         wt, bt = fold_conv_bn(self.sd, pre + ".conv_bn_relu3")
         P, C = w1.shape[0], w1.shape[1]
         bn2 = TAIL_BN[tile]
-        assert P == 64 and C == 4 * P == x.C == wt.shape[0] and w3.shape[:2] == (P, P) and w3.shape[2] == 3 and wt.shape[1] == P
+        assert P == TILES[tile][1] and C == 4 * P == x.C == wt.shape[0] and w3.shape[:2] == (P, P) and w3.shape[2] == 3 and wt.shape[1] == P
+        assert (P == 128) == (tile == 94) and P in (64, 128)
         M = self.B * x.H * x.W
         hi, lo, sc1 = split_f16(w1.reshape(P, C))
-        wk1 = pack_rows16(torch.stack([hi, lo]))                                      # [C/16 stages][P rows][64 B]
+        if P == 64:
+            wk1 = pack_rows16(torch.stack([hi, lo]))                                  # [C/16 stages][P rows][64 B]
+        else:
+            wk1 = pack_halo_rows(torch.stack([hi, lo]), P, 1, C, True)                # csrc/convc.hip: [1][C/32 chunks][1][P rows][128 B]
         hi, lo, sc3 = split_f16(w3.permute(0, 2, 3, 1).reshape(P, 9 * P))
         wk3 = pack_halo_rows(torch.stack([hi, lo]), P, 9, P, True)                    # [1][P/32][9 taps][P rows][128 B]
         hi, lo, sct = split_f16(wt.reshape(C, P))

@@ -68,7 +68,7 @@ def test_plan_blob_round_trip_and_workspace_bytes():
         assert lib.smap_plan_create_from_blob(lied, len(lied), C.byref(plan), None) == -1
 
 
-@pytest.mark.parametrize("spec", ["", "64:90", "64:91", "64:91+64:93"])
+@pytest.mark.parametrize("spec", ["", "64:90", "64:91", "64:91+64:93", "64:91,128:94+64:93"])
 def test_library_accepts_the_full_size_schedules(monkeypatch, spec):
     """smap_plan_create on the benchmarked schedules (8 and 16 frames at 512x832, with and without the whole-Bottleneck launches
     of csrc/convb.hip): what the GPU box will be asked to run validates here, without a GPU."""
@@ -85,7 +85,7 @@ def test_library_accepts_the_full_size_schedules(monkeypatch, spec):
     for B in (8, 16):
         g = Graph(sd, B, 512, 832, precision="x3")
         g.allocate()
-        assert sum(1 for op in g.ops if "head" in op.p) == ((9 if first else 6) if spec else 0)
+        assert sum(1 for op in g.ops if "head" in op.p) == ((9 if first else 6) if spec else 0) + (9 if "128:" in spec else 0)
         h = C.c_void_p()
         assert L.load().smap_plan_create(g.emit(), len(g.ops), C.byref(h)) == 0, (spec, B)
         L.load().smap_plan_destroy(h)

@@ -382,7 +382,7 @@ def _run_block(B, H, W, tile, use_adds, seed=0, mode="full", relu=True, check=Tr
     from smap_amd import lib as L
     from smap_amd.engine import TAIL_BN, ZERO_PAGE, pack_halo_rows, pack_rows16, split_f16
     lib = L.load()
-    P, Cc = 64, 256
+    P, Cc = (128, 512) if tile == 94 else (64, 256)           # 94: csrc/convc.hip (layer2's width)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, H, W, Cc, generator=g)
     w1 = torch.randn(P, Cc, 1, 1, generator=g) * (1.0 / Cc) ** 0.5
@@ -403,7 +403,7 @@ def _run_block(B, H, W, tile, use_adds, seed=0, mode="full", relu=True, check=Tr
         w3 = w3 * m
     bn2 = TAIL_BN[tile]
     hi, lo, sc1 = split_f16(w1.reshape(P, Cc).double())
-    wk1 = pack_rows16(torch.stack([hi, lo]))
+    wk1 = pack_rows16(torch.stack([hi, lo])) if P == 64 else pack_halo_rows(torch.stack([hi, lo]), P, 1, Cc, True)
     hi, lo, sc3 = split_f16(w3.permute(0, 2, 3, 1).reshape(P, 9 * P).double())
     wk3 = pack_halo_rows(torch.stack([hi, lo]), P, 9, P, True)
     hi, lo, sct = split_f16(wt.reshape(Cc, P).double())
@@ -551,6 +551,11 @@ BLOCK_CASES = [
     (3, 10, 14, 93, False),
     (2, 16, 32, 93, False),
     (1, 13, 52, 93, False),
+    # 128 planes / 512 channels (csrc/convc.hip, tile id 94: layer2's identity blocks), 8 x 16 tiles, eight waves
+    (2, 16, 32, 94, False),
+    (1, 13, 52, 94, True),           # ragged tiles, skip adds
+    (3, 10, 14, 94, True),           # narrower than one tile
+    (1, 24, 104, 94, False),         # a full row of 7 tiles (the last one ragged)
 ]
 
 
@@ -566,7 +571,7 @@ def test_whole_bottleneck_launch(case, mode):
     assert err.max().item() < tol, (err.max().item(), tol, np.unravel_index(err.argmax().item(), err.shape))
 
 
-@pytest.mark.parametrize("spec", ["64:90", "64:91", "64:91+64:93", "64:90+64:92"])
+@pytest.mark.parametrize("spec", ["64:90", "64:91", "64:91+64:93", "64:90+64:92", "64:91,128:94+64:93"])
 def test_small_schedule_with_whole_bottleneck_launches(golden_dir, small, monkeypatch, spec):
     """Identity Bottlenecks of layer1 as ONE launch each (csrc/convb.hip): every stored tensor against the f64 interpretation
     of the SAME schedule, and the outputs against the golden outputs of the reference model."""
@@ -579,7 +584,8 @@ def test_small_schedule_with_whole_bottleneck_launches(golden_dir, small, monkey
     monkeypatch.setenv("SMAP_BLOCK", spec)
     monkeypatch.setenv("SMAP_BLOCK_FIRST", first)
     eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision="x3")
-    assert sum(1 for op in eng.graph.ops if op.kind == 0 and "head" in op.p) == (9 if first else 6)
+    n2 = 9 if "128:" in spec else 0                          # layer2: three identity blocks per stage
+    assert sum(1 for op in eng.graph.ops if op.kind == 0 and "head" in op.p) == (9 if first else 6) + n2
     assert sum(1 for op in eng.graph.ops if op.kind == 0 and "short" in op.p) == (3 if first else 0)
     assert not any(t.name.endswith((".c1", ".c2")) for t in eng.graph.tensors if ".layer1.1" in t.name or ".layer1.2" in t.name)
     outs = [o.cpu() for o in eng.run(x.to(DEV))]

@@ -28,11 +28,11 @@ def main():
     dev = torch.device("cuda:0")
     for tile in tiles:
         first = tile in (92, 93)
-        os.environ["SMAP_BLOCK"], os.environ["SMAP_BLOCK_FIRST"] = ("64:91", f"64:{tile}") if first else (f"64:{tile}", "")
+        os.environ["SMAP_BLOCK"], os.environ["SMAP_BLOCK_FIRST"] = ("64:91", f"64:{tile}") if first else (f"128:{tile}" if tile == 94 else f"64:{tile}", "")
         g = Graph(sd, 8, 512, 832, precision="x3")
         g.allocate()
         ops = g.emit()
-        idx = next(i for i, op in enumerate(g.ops) if "head" in op.p and (("short" in op.p) == first))
+        idx = next(i for i, op in enumerate(g.ops) if "head" in op.p and (("short" in op.p) == first))       # (tile 94: layer2's first identity block)
         one = (L.SmapOp * 1)(ops[idx])
         h = C.c_void_p()
         L.check(lib.smap_plan_create(one, 1, C.byref(h)), "create")
@@ -49,7 +49,7 @@ def main():
             run()
         e1.record()
         torch.cuda.synchronize()
-        occ = lib.smap_debug_convb_occupancy(tile) if hasattr(lib, "smap_debug_convb_occupancy") else None
+        occ = lib.smap_debug_convc_occupancy() if tile == 94 else lib.smap_debug_convb_occupancy(tile)
         print(f"{os.path.basename(L.SO_PATH):28s} occupancy {occ} tile {tile} ({g.ops[idx].out.name}): {e0.elapsed_time(e1) / n * 1e3:8.1f} us per launch (warm, back to back)")
         lib.smap_plan_destroy(h)
 

@@ -20,11 +20,26 @@ if "--convb" in sys.argv:       # csrc/convb.hip's identity kernel with parts sw
         subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
         print(out)
     sys.exit(0)
+if "--one" in sys.argv:         # --one SRC NAME=VALUE[,NAME=VALUE] ...: libsmap_hip_<src>_<tag>.so = the regular objects + SRC compiled with those -D switches
+    B.build_lib()
+    src = sys.argv[sys.argv.index("--one") + 1]
+    for spec in sys.argv[sys.argv.index("--one") + 2:]:
+        tag = spec.replace("=", "").replace("SMAP_", "").replace(",", "_").lower()
+        op = os.path.join(B.OBJ, f"{src.rsplit('.', 1)[0]}_{tag}.o")
+        subprocess.check_call([B._hipcc()] + B.COMMON + ["-D" + d for d in spec.split(",")] + ["-c", os.path.join(B.CSRC, src), "-o", op])
+        objs = [os.path.join(B.OBJ, s_.rsplit(".", 1)[0] + ".o") if s_ != src else op for s_, _ in B.SOURCES]
+        out = os.path.join(B.OBJ, f"libsmap_hip_{src.rsplit('.', 1)[0]}_{tag}.so")
+        subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+        print(out)
+    sys.exit(0)
 if "--conv3" in sys.argv:       # csrc/conv3.hip alone with SMAP_ABLATE bits (1 no LDS-DMA, 2 no MFMA, 8 no epilogue, 16 no ds_read, 32 no barriers in the
     B.build_lib()                # staggered loop): libsmap_hip_conv3abl<N>.so = the regular objects + an ablated conv3.o
     for n in sys.argv[sys.argv.index("--conv3") + 1:]:
         op = os.path.join(B.OBJ, f"conv3_abl{n}.o")
-        subprocess.check_call([B._hipcc()] + B.COMMON + [f"-DSMAP_ABLATE={n}", "-c", os.path.join(B.CSRC, "conv3.hip"), "-o", op])
+        flag = ["-D" + d for d in n[2:].split(",")] if n.startswith("D:") else [f"-DSMAP_ABLATE={n}"]     # "D:NAME=VALUE[,NAME=VALUE]": other switches of conv3.hip
+        n = n[2:].replace("=", "").replace("SMAP_", "").replace(",", "_").lower() if n.startswith("D:") else n
+        op = os.path.join(B.OBJ, f"conv3_abl{n}.o")
+        subprocess.check_call([B._hipcc()] + B.COMMON + flag + ["-c", os.path.join(B.CSRC, "conv3.hip"), "-o", op])
         objs = [os.path.join(B.OBJ, src.rsplit(".", 1)[0] + ".o") if src != "conv3.hip" else op for src, _ in B.SOURCES]
         out = os.path.join(B.OBJ, f"libsmap_hip_conv3abl{n}.so")
         subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)

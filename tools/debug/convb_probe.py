@@ -32,10 +32,11 @@ def report(tile, mode, B=2, H=16, W=32, adds=False):
     if not bad.any():
         return
     e = err.numpy()
-    by_row = e.reshape(B, H // th if H % th == 0 else -1, th, W, 256).max((0, 1, 3, 4)) if H % th == 0 else None
-    by_col = e.reshape(B, H, W // 16, 16, 256).max((0, 1, 2, 4)) if W % 16 == 0 else None
-    by_ch32 = e.reshape(B, H, W, 8, 32).max((0, 1, 2, 4))
-    by_ch8 = e.reshape(B, H, W, 32, 8).max((0, 1, 2, 4))
+    C = e.shape[-1]                                          # 256, or 512 for csrc/convc.hip (tile 94)
+    by_row = e.reshape(B, H // th if H % th == 0 else -1, th, W, C).max((0, 1, 3, 4)) if H % th == 0 else None
+    by_col = e.reshape(B, H, W // 16, 16, C).max((0, 1, 2, 4)) if W % 16 == 0 else None
+    by_ch32 = e.reshape(B, H, W, C // 32, 32).max((0, 1, 2, 4))
+    by_ch8 = e.reshape(B, H, W, C // 8, 8).max((0, 1, 2, 4))
     print("   max err by row inside the tile :", None if by_row is None else np.array2string(by_row, precision=2))
     print("   max err by col inside the tile :", None if by_col is None else np.array2string(by_col, precision=2))
     print("   max err by 32-channel block    :", np.array2string(by_ch32, precision=2))
@@ -50,4 +51,4 @@ if __name__ == "__main__":
     for tile in tiles:
         for mode in ("residual", "no_c1", "centre_tap", "full"):
             report(tile, mode)
-        report(tile, "full", B=1, H=13, W=52, adds=tile < 92)
+        report(tile, "full", B=1, H=13, W=52, adds=tile < 92 or tile == 94)
