@@ -569,7 +569,7 @@ def main():
                                       f"per step)" if pipe.frames_per_launch > B else "")
                                    + "; one end-of-run gather of the records",
                        "frames_per_launch": pipe.frames_per_launch,
-                       # layer1's Bottlenecks as ONE launch each (csrc/convb.hip): conv launches per forward 206 -> 185
+                       # layer1's Bottlenecks and layer2's identity Bottlenecks as ONE launch each (csrc/convb.hip, convc.hip): conv launches per forward 206 -> 167
                        "whole_block_launches": sum(1 for op in pipe.engine.graph.ops if "head" in op.p),
                        # the same steps with ONE backbone launch per step (no coalescing: a batch's records are not held
                        # back for its group), timed in this process right after the headline region
@@ -593,7 +593,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": alg_bytes / step_s / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": alg_bytes / step_s / 1e9 / PEAK_HBM_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_batch": alg_bytes,
-                         "kernel": "conv_igemm_kernel / conv3x3_halo_kernel / convp_kernel / bottleneck_kernel (all backbone launches; HIP "
+                         "kernel": "conv_igemm_kernel / conv3x3_halo_kernel / convp_kernel / bottleneck_kernel / bottleneck128_kernel (all backbone launches; HIP "
                                    "events: per-schedule span below, rate = algorithmic bytes of the timed region / its duration when depth > 1)",
                          "measured_ceilings_GBps": {"hbm_read": 5300, "hbm_write": 6200, "hbm_mixed": 5200,
                                                     "source": "profiles/r2_v17_ubench_hbm_read_write_mix.log"},

@@ -57,9 +57,8 @@ __device__ __forceinline__ f32x16 MFMA_(half8 x, half8 y, f32x16 c) { c[0] += (f
 #else
 #define MFMA_(x, y, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0)
 #endif
-#ifndef SMAP_CONVC_DMA_IN_MFMA
-#define SMAP_CONVC_DMA_IN_MFMA 0   // (measured: no difference, profiles/r4_v21_*) LDS-DMA requests of a barrier interval issued behind its first K step's MFMAs instead of right after the barrier
-#endif
+// (Measured and removed, EXPERIMENTS R4.1b: conv3.hip's staggered schedule for phases 2 and 3 -- the two pixel halves half a slot apart,
+//  bit-identical, 138 vs 137-142 us; LDS-DMA requests issued from inside the MFMA bursts -- 144-152 vs 145-146 us.)
 
 __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a, int tiles_x, int tiles_y)
 {
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
         if (ks + NS1 - 1 <= KS1) wait_vm((NS1 - 2) * LPT1);     // stage ks has landed; younger stages stay in flight
         else wait_vm((KS1 - 1 - ks) * LPT1);
         lds_barrier();
-        if (!SMAP_CONVC_DMA_IN_MFMA && ks + NS1 - 1 < KS1) issue1((ks + NS1 - 1) % NS1, ks + NS1 - 1);     // into the buffer stage ks-1 was read from
+        if (ks + NS1 - 1 < KS1) issue1((ks + NS1 - 1) % NS1, ks + NS1 - 1);     // into the buffer stage ks-1 was read from
         const char* sX = smem + (ks % NS1) * ST1;
         const char* sW = sX + XS;
         if ((ks >> 2) < NRS && (ks & 3) == wn) {                // this wave's residual channels: nc*128 + wn*32 + .. = stage 4 nc + wn
@@ -204,11 +203,6 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
                 acc1[j] = MFMA_(wf[0], xl, acc1[j]);
                 acc1[j] = MFMA_(wf[1], xh, acc1[j]);
                 acc1[j] = MFMA_(wf[0], xh, acc1[j]);
-            }
-            if (SMAP_CONVC_DMA_IN_MFMA && kk == 0 && ks + NS1 - 1 < KS1) {      // (a wave is held per request: here the matrix pipe has work queued)
-                __builtin_amdgcn_sched_barrier(0);
-                issue1((ks + NS1 - 1) % NS1, ks + NS1 - 1);
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -288,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
 #pragma unroll
     for (int s = 0; s < NS2; ++s) {
         lds_barrier();                                          // slot s landed for every wave; y1 complete (s = 0); slot s-1's buffer is free
-        if (!SMAP_CONVC_DMA_IN_MFMA && s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
+        if (s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
         const char* sB = ring + (s % NS) * SLOT;
         const int tap = s / KC, cc = s % KC;
         const int shift = (tap / 3) * PW + (tap % 3);
@@ -310,11 +304,6 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
                 acc2[mi] = MFMA_(bf[0], af[1][mi], acc2[mi]);
                 acc2[mi] = MFMA_(bf[1], af[0][mi], acc2[mi]);
                 acc2[mi] = MFMA_(bf[0], af[0][mi], acc2[mi]);
-            }
-            if (SMAP_CONVC_DMA_IN_MFMA && kk == 0 && s + NS - 1 < NSLOT) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue_slot(s + NS - 1);
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         wait_next(s);
@@ -367,19 +356,20 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             const int s = NS2 + nc * KC + kc;
-            lds_barrier();                                      // slot s landed for every wave; y2 + bias table complete (first slot); slot s-1's buffer is free
-            if (!SMAP_CONVC_DMA_IN_MFMA && s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
-            if (!SMAP_CONVC_DMA_IN_MFMA && nc >= NRS && kc == 0) {      // (after the slot request: younger than every LDS-DMA the counted waits below name)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int pl = 0; pl < 2; ++pl)
-                            rl[mi][j][pl] = *reinterpret_cast<const half8*>(a.res + m_dense[mi] + (unsigned)(nc * P + wn * 32 + 8 * lhi + 16 * j) + pl * a.tail_cout8);
-            }
             const char* sW = ring + (s % NS) * SLOT;
-            if (kc == 0) {
+            auto requests = [&]() {
+                if (s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
+                if (nc >= NRS && kc == 0) {                     // (after the slot request: younger than every LDS-DMA the counted waits below name)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int pl = 0; pl < 2; ++pl)
+                                rl[mi][j][pl] = *reinterpret_cast<const half8*>(a.res + m_dense[mi] + (unsigned)(nc * P + wn * 32 + 8 * lhi + 16 * j) + pl * a.tail_cout8);
+                }
+            };
+            auto init_acc = [&]() {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 b4 = *reinterpret_cast<const float4*>(sB3 + nc * P + wn * 32 + 8 * q + 4 * lhi);
@@ -388,7 +378,10 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
                         acc3[mi][4 * q + 0] = b4.x; acc3[mi][4 * q + 1] = b4.y; acc3[mi][4 * q + 2] = b4.z; acc3[mi][4 * q + 3] = b4.w;
                     }
                 }
-            }
+            };
+            lds_barrier();                                      // slot s landed for every wave; y2 + bias table complete (first slot); slot s-1's buffer is free
+            requests();
+            if (kc == 0) init_acc();
 #pragma unroll
             for (int kk = 0; kk < CH / 16; ++kk) {
                 const int g = kk * 2 + lhi;
@@ -405,20 +398,6 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
                     acc3[mi] = MFMA_(wf[0], pf[1][mi], acc3[mi]);
                     acc3[mi] = MFMA_(wf[1], pf[0][mi], acc3[mi]);
                     acc3[mi] = MFMA_(wf[0], pf[0][mi], acc3[mi]);
-                }
-                if (SMAP_CONVC_DMA_IN_MFMA && kk == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
-                    if (nc >= NRS && kc == 0) {                 // (after the slot request: younger than every LDS-DMA the counted waits below name)
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                                for (int pl = 0; pl < 2; ++pl)
-                                    rl[mi][j][pl] = *reinterpret_cast<const half8*>(a.res + m_dense[mi] + (unsigned)(nc * P + wn * 32 + 8 * lhi + 16 * j) + pl * a.tail_cout8);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             wait_next(s, nc >= NRS ? MI * 4 : 0);               // (last k chunk: BEFORE this chunk's stores -- a counted vmcnt also counts stores)

@@ -65,7 +65,7 @@ TAIL_BN = {80: 64, 81: 128, 82: 64, 90: 64, 91: 64, 92: 64, 93: 64, 94: 128}    
 # layer1 (the one with a shortcut conv; 64 input channels).
 # Measured in situ (profiles/r4_v4_ab_whole_block_first.log, same box, interleaved): 781 -> 800 (identity blocks, 8 x 16 tiles) -> 821
 # frames/s (+ first blocks); 4 x 16 tiles: 816.
-BLOCK_DEFAULT = {64: 91}
+BLOCK_DEFAULT = {64: 91, 128: 94}       # layer1 (csrc/convb.hip) and layer2 (csrc/convc.hip) identity blocks
 BLOCK_FIRST_DEFAULT = {64: 93}
 # (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
 #  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)

@@ -48,15 +48,15 @@ def test_x3_graph_emits_split_strides_and_weights(small_sd, monkeypatch, blocks)
     g.allocate()
     ops = g.emit()
     n_blk = sum(1 for op in g.ops if "head" in op.p)
-    assert n_blk == (9 if blocks else 0)                  # 3 stages x (first block + two identity blocks) of layer1
-    assert len(g.ops) == len(g16.ops) - (3 * 3 + 2 * 6 if blocks else 0) and g.flops == g16.flops
+    assert n_blk == (18 if blocks else 0)                 # 3 stages x (first block + two identity blocks of layer1 + three identity blocks of layer2)
+    assert len(g.ops) == len(g16.ops) - (3 * 3 + 2 * 6 + 2 * 9 if blocks else 0) and g.flops == g16.flops
     assert g.weight_blob().numel() > 1.9 * g16.weight_blob().numel()
     for op, o in zip(g.ops, ops):
         assert o.precision == 1
         if op.kind == OP_CONV:
             x, y = op.inp, op.out
             assert x.planes == 2 and o.in_stride_c == 2 * x.C and o.in_c_off + o.Cin <= x.C
-            assert o.tile in X3_TILES + (3,) + tuple(range(30, 46)) + (91, 93) and o.acc_scale > 0
+            assert o.tile in X3_TILES + (3,) + tuple(range(30, 46)) + (91, 93, 94) and o.acc_scale > 0
             assert (y.planes, o.out_stride_c) == ((1, y.C) if o.out_fp32 else (2, 2 * y.C))
             assert o.in_off >= ZERO_PAGE and o.Cin * 2 + o.in_stride_c + 16 <= ZERO_PAGE
             for t in (op.res, op.add1, op.add2):

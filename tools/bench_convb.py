@@ -40,8 +40,11 @@ def main():
         blob = g.weight_blob().to(dev)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         run = lambda: L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()), None, st), "run")
-        for _ in range(3):
+        sums = set()
+        for _ in range(3 if "--check" not in sys.argv else 12):     # --check: the launch must reproduce itself bit for bit (and other builds: compare the printed sums)
             run()
+            if "--check" in sys.argv:
+                sums.add(int(arena.view(torch.int64).sum().item()))
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -50,6 +53,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         occ = lib.smap_debug_convc_occupancy() if tile == 94 else lib.smap_debug_convb_occupancy(tile)
+        if sums:
+            print(f"   checksum(s) of the arena after each of 12 launches: {sorted(sums)}")
         print(f"{os.path.basename(L.SO_PATH):28s} occupancy {occ} tile {tile} ({g.ops[idx].out.name}): {e0.elapsed_time(e1) / n * 1e3:8.1f} us per launch (warm, back to back)")
         lib.smap_plan_destroy(h)
 

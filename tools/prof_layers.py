@@ -23,7 +23,7 @@ def main():
     torch.manual_seed(0)
     g = Graph(SMAP(cfg).state_dict(), B, 512, 832, precision=os.environ.get("SMAP_PRECISION", "f16"))
     # kernel-name fragments per op kind (conv ops run conv.hip, conv2.hip, conv3.hip or conv1.hip kernels, by tile id)
-    names = {OP_CONV: ("conv_igemm", "conv3x3_halo", "conv1x1_ws", "convp_kernel", "conv3_tail_kernel", "bottleneck_kernel", "bottleneck_first_kernel"), OP_STEM: ("stem_kernel",), OP_STEMPOOL: ("stem_pool_kernel",), OP_MAXPOOL: ("maxpool",),
+    names = {OP_CONV: ("conv_igemm", "conv3x3_halo", "conv1x1_ws", "convp_kernel", "conv3_tail_kernel", "bottleneck_kernel", "bottleneck_first_kernel", "bottleneck128_kernel"), OP_STEM: ("stem_kernel",), OP_STEMPOOL: ("stem_pool_kernel",), OP_MAXPOOL: ("maxpool",),
              OP_UPADD: ("upadd",), OP_HEADSUM: ("headsum",)}       # set SMAP_NO_UPADD_FUSION=1 for pre-fusion traces
     con = sqlite3.connect(db)
     rows = con.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()

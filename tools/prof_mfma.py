@@ -9,7 +9,7 @@ import collections
 import csv
 import sys
 
-CONV = ("conv_igemm", "conv3x3_halo", "convp_kernel", "conv3_tail_kernel", "bottleneck_kernel", "bottleneck_first_kernel")
+CONV = ("conv_igemm", "conv3x3_halo", "convp_kernel", "conv3_tail_kernel", "bottleneck_kernel", "bottleneck_first_kernel", "bottleneck128_kernel")
 rows = list(csv.DictReader(open(sys.argv[1])))
 by = collections.defaultdict(dict)
 for r in rows:

@@ -9,7 +9,7 @@ import csv
 import json
 import sys
 
-CONV = ("conv_igemm", "conv3x3_halo", "conv1x1_ws", "convp_kernel", "conv3_tail_kernel", "bottleneck_kernel", "bottleneck_first_kernel")
+CONV = ("conv_igemm", "conv3x3_halo", "conv1x1_ws", "convp_kernel", "conv3_tail_kernel", "bottleneck_kernel", "bottleneck_first_kernel", "bottleneck128_kernel")
 
 
 def total(path, counter):
@@ -33,7 +33,7 @@ def main():
     assert n1 == n2, (n1, n2)
     out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, with --kernel-trace only) over "
                      f"`python bench.py --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline`, summed over the {n1} conv launches "
-                     f"(conv.hip + conv3.hip + convp.hip + convb.hip kernels) of one 8-frame forward",
+                     f"(conv.hip + conv3.hip + convp.hip + convb.hip + convc.hip kernels) of one 8-frame forward",
            "fetch_size_kb_sum": f_kb, "write_size_kb_sum": w_kb,
            "hbm_read_bytes_per_batch": 2.0 * f_kb * 1024, "hbm_write_bytes_per_batch": w_kb * 1024,
            "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads; calibrated in "
