@@ -150,7 +150,7 @@ typedef struct smap_op {
                                        BN = the N extent of `tile` (smap_conv_tile_dims), K tile = smap_conv_tile_bk(tile,
                                        precision) halves in K order, slot s of row r = K granule s ^ ((r>>1)&7) (64-half
                                        tiles) or s ^ ((r>>2)&3) (32-half tiles; with w_pairs = 1 those are stored in PAIRS,
-                                       [n tile][pair][plane][BN rows][tile 2p (64 B) | tile 2p+1 (64 B)]: 128-byte rows); halo tiles 30..39: blocks ordered
+                                       [n tile][pair][plane][BN rows][tile 2p (64 B) | tile 2p+1 (64 B)]: 128-byte rows); halo tiles 30..49: blocks ordered
                                        [n tile][channel chunk][tap], 128-byte rows of 64 channels (precision 1: of 32
                                        channels as granules 0..3 = hi, 4..7 = lo), slot s = granule s ^ ((r>>1)&7).
                                        Reference packer: smap_amd/engine.py::pack_conv_weights.  + fp32 bias [cout_pad].
@@ -196,13 +196,14 @@ typedef struct smap_op {
     int64_t tail_w_off;             /* weight-blob byte offsets of the 1x1: blocks [n chunk][k chunk][BN2 rows][128 B], rows */
     int64_t tail_bias_off;          /* in the halo tiles' format (64 channels, or hi32 | lo32); fp32 bias [tail_cout_pad] */
     int32_t head_cin;               /* CONV, tile ids 90..99 only (else 0): the op is a WHOLE stride-1 identity Bottleneck in one launch
-                                       (smap.py:48-77; csrc/convb.hip, split precision): a LEADING 1x1 conv head_cin -> Cin (bias +
+                                       (smap.py:48-77; csrc/convb.hip: Cin = 64 planes, tile ids 90..93; csrc/convc.hip: 128 planes, tile id 94;
+                                       split precision): a LEADING 1x1 conv head_cin -> Cin (bias +
                                        ReLU, never stored, recomputed on the 3x3's halo) in front of the 3x3 and its tail.  The input
                                        tensor then has head_cin channels (in_stride_c = 2 * head_cin), is read once, and is also
                                        the residual: res_off must equal in_off and tail_cout = head_cin. */
     float head_acc_scale;           /* 2^-s of the leading 1x1's weights */
     int64_t head_w_off;             /* weight-blob byte offsets of the leading 1x1: blocks [k chunk][Cin rows][128 B] in the halo */
-    int64_t head_bias_off;          /* tiles' row format (hi32 | lo32 of 32 input channels; tile ids 90, 91: 16-channel stages, 64-byte rows,
+    int64_t head_bias_off;          /* tiles' row format (hi32 | lo32 of 32 input channels: tile ids 92..94; tile ids 90, 91: 16-channel stages, 64-byte rows,
                                        smap_amd/engine.py::pack_rows16); fp32 bias [Cin] */
     int64_t short_w_off;            /* tile ids 92, 93 only (present iff short_acc_scale > 0): the FIRST block of a layer (smap.py:124-129) -- head_cin = 64 input
                                        channels and, instead of "+ input", a 1x1 SHORTCUT conv head_cin -> tail_cout (folded BN, no ReLU) on
