@@ -32,6 +32,9 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -(1000 + (int)e);
 //   37x38x3 input patch (B operand) both sit in LDS; D[n][pixel] puts 4 consecutive channels of
 //   one pixel in a lane, so the NHWC store is 8 bytes per lane with no transposition.
 // One 16x16 output tile per workgroup, 64 pixels x 64 channels per wave (4 accumulators).
+#ifndef SMAP_STEM_STORE16
+#define SMAP_STEM_STORE16 1
+#endif
 constexpr int ST_T = 16, ST_PH = ST_T * 2 + 5, ST_PW = 40;     // tile edge, patch rows, padded patch row (halves)
 constexpr int ST_K = 176;                                      // 22 granules x 8
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -129,12 +132,45 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemIn in, const _Float
                 acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][nt], pf[0][t], acc[nt][t], 0, 0, 0);
             }
     }
-    // D[n][pixel]: lane = pixel (col l31), reg r -> channel nt*32 + (r&3) + 8*(r>>2) + 4*lhi
+    // D[n][pixel]: lane = pixel (col l31), reg r -> channel nt*32 + (r&3) + 8*(r>>2) + 4*lhi.  The half-wave swap of convp.hip's
+    // register epilogue turns a lane's 4 + 4 channels (8 apart) into 8 consecutive ones: 16-byte NHWC stores instead of 8-byte ones
+    // (SMAP_STEM_STORE16 = 0: the round-1 form).
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int oy = oy0 + 4 * wave + 2 * t + (l31 >> 4), ox = ox0 + (l31 & 15);
-        if (oy >= Ho || ox >= Wo) continue;
-        _Float16* op = out + (((size_t)b * Ho + oy) * Wo + ox) * (NPL * 64);
+        const bool ok = oy < Ho && ox < Wo;
+        _Float16* op = out + (((size_t)b * Ho + (ok ? oy : 0)) * Wo + (ok ? ox : 0)) * (NPL * 64);
+#if SMAP_STEM_STORE16
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xf = acc[nt][t][8 * j + e], yf = acc[nt][t][8 * j + 4 + e];    // channels 16j + e + 4 lhi and + 8
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf), __float_as_uint(yf), false, false);
+                    const unsigned s0 = sw[0], s1 = sw[1];
+                    v[e] = __uint_as_float(s0);
+                    v[4 + e] = __uint_as_float(s1);
+                }
+                const int n0 = nt * 32 + 16 * j + 8 * lhi;     // this lane now holds channels n0 .. n0 + 7 of its pixel
+                const float4 b0 = *reinterpret_cast<const float4*>(bias + n0), b1 = *reinterpret_cast<const float4*>(bias + n0 + 4);
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                half8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = X3 ? v[e] * acc_scale + bb[e] : v[e] + bb[e];
+                    x = x < 0.f ? 0.f : x;                     // NaN stays NaN (torch's ReLU)
+                    h[e] = (_Float16)x;
+                    l[e] = (_Float16)(x - (float)h[e]);
+                }
+                if (!ok) continue;
+                *reinterpret_cast<half8*>(op + n0) = h;
+                if (X3) *reinterpret_cast<half8*>(op + 64 + n0) = l;
+            }
+#else
+        if (!ok) continue;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -153,6 +189,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemIn in, const _Float
                 *reinterpret_cast<half4*>(op + n0) = h;
                 if (X3) *reinterpret_cast<half4*>(op + 64 + n0) = l;
             }
+#endif
     }
 }
 
