@@ -232,5 +232,56 @@ export TMPDIR=/tmp
 bash tools/gpu_visits/ab_bench.sh $O/ab_halo8.log 3 "--no-cpu-baseline --steps 40 --warmup 6" "SMAP_TILE_TABLE_X3=tools/tile_table_x3_r3.json" ""
 }
 
-if [ -z "${1:-}" ] || ! declare -F "v$1" > /dev/null; then echo "usage: $0 <visit: 1 2 3 4 6 7 8 9 10 11 12 13>"; exit 2; fi
+v15() {
+# visit 15: issue interval of the matrix instructions per wave (hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_issue.hip -o tools/ubench/mfma_issue first)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; O=gpurun_out/r4v15; mkdir -p $O
+timeout 120 tools/ubench/mfma_issue > $O/mfma_issue.log 2>&1; cat $O/mfma_issue.log
+}
+
+v16() {
+# visit 16: ablation builds of the staggered halo loop (python tools/build_ablate.py --conv3 1 2 16 8 3 18 19 51 27 59 first)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; O=gpurun_out/r4v16; mkdir -p $O; export TMPDIR=/tmp
+for n in 0 1 2 16 8 3 18 19 51 27 59; do
+  lib=$PWD/smap_amd/csrc/obj/libsmap_hip_conv3abl$n.so; [ $n = 0 ] && lib=$PWD/smap_amd/libsmap_hip.so
+  echo "ablate $n" >> $O/conv3_ablation.log
+  SMAP_HIP_LIB=$lib timeout 100 python tools/bench_halo8.py --batch 16 --only 32,52,256,256 --tiles 45,43 2>&1 | grep -v amdgpu.ids >> $O/conv3_ablation.log
+  SMAP_HIP_LIB=$lib timeout 100 python tools/bench_halo8.py --batch 16 --only 64,104,128,128 --tiles 44,31 2>&1 | grep -v amdgpu.ids >> $O/conv3_ablation.log
+done; cat $O/conv3_ablation.log
+}
+
+v18() {
+# visits 17, 18: LDS-DMA requests of the staggered halo loop issued from inside the MFMA burst, by position
+# (python tools/build_ablate.py --conv3 "D:SMAP_STAG_DMA_IN_MFMA=1,SMAP_STAG_DMA_POS=3" ... POS=2 1 0 11 first)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; O=gpurun_out/r4v18; mkdir -p $O; export TMPDIR=/tmp
+for rep in 1 2; do for lib in smap_amd/libsmap_hip.so smap_amd/csrc/obj/libsmap_hip_conv3ablstag_dma_in_mfma1_stag_dma_pos*.so; do
+  echo "lib $(basename $lib)" >> $O/ab.log
+  [ $rep = 1 ] && SMAP_HIP_LIB=$PWD/$lib timeout 100 python tools/debug/halo_stag_race.py --runs 4 2>&1 | grep "RACE" >> $O/ab.log
+  SMAP_HIP_LIB=$PWD/$lib timeout 100 python tools/bench_halo8.py --batch 16 --only 32,52,256,256 --tiles 45,44 2>&1 | grep -v amdgpu.ids >> $O/ab.log
+  SMAP_HIP_LIB=$PWD/$lib timeout 100 python tools/bench_halo8.py --batch 16 --only 64,104,128,128 --tiles 44,45 2>&1 | grep -v amdgpu.ids >> $O/ab.log
+done; done; cat $O/ab.log
+}
+
+v20() {
+# visits 19-23: csrc/convc.hip (tile 94): probe, its tests, isolated timing (ablation / schedule variants: tools/build_ablate.py --one convc.hip
+# SMAP_CONVC_ABLATE=N ..., selected with SMAP_HIP_LIB), in-situ A/B against the schedule without it
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; O=gpurun_out/r4v20; mkdir -p $O; export TMPDIR=/tmp
+timeout 120 python tools/debug/convb_probe.py 94 2>&1 | grep -v amdgpu.ids > $O/probe.log; cat $O/probe.log
+timeout 300 python -m pytest tests/test_backbone_gpu.py -q -x -m gpu -k "x94 or 128:94" > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+timeout 120 python tools/bench_convb.py 94 91 --check 2>&1 | grep -v amdgpu.ids > $O/bench_convb.log; cat $O/bench_convb.log
+bash tools/gpu_visits/ab_bench.sh $O/ab_block2.log 2 "--no-cpu-baseline --steps 40 --warmup 6" "SMAP_BLOCK=64:91" "" > /dev/null; cat $O/ab_block2.log
+bash tools/gpu_visits/ab_bench.sh $O/ab_block2_d1.log 1 "--no-cpu-baseline --steps 30 --depth 1 --launch-frames 0" "SMAP_BLOCK=64:91" "" > /dev/null; cat $O/ab_block2_d1.log
+}
+
+v26() {
+# visits 25, 26: 16 vs 32 frames per launch on the final schedule; the stem with 8- and 16-byte stores
+# (python tools/build_ablate.py --one plan.hip SMAP_STEM_STORE16=0 first)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; O=gpurun_out/r4v26; mkdir -p $O; export TMPDIR=/tmp
+for rep in 1 2; do for lf in 16 32; do bash tools/gpu_visits/ab_bench.sh $O/ab_lf.log 1 "--no-cpu-baseline --steps 64 --warmup 8 --launch-frames $lf" "" > /dev/null; done; done; cat $O/ab_lf.log
+for rep in 1 2; do for lib in smap_amd/libsmap_hip.so smap_amd/csrc/obj/libsmap_hip_plan_stem_store160.so; do
+  SMAP_HIP_LIB=$PWD/$lib timeout 100 python tools/bench_stem.py 2>&1 | grep -v amdgpu.ids >> $O/stem.log
+done; done; cat $O/stem.log
+}
+
+# visits 5, 14, 24, 27: bash tools/gpu_visits/validate_all.sh <tag>
+if [ -z "${1:-}" ] || ! declare -F "v$1" > /dev/null; then echo "usage: $0 <visit: 1 2 3 4 6 7 8 9 10 11 12 13 15 16 18 20 26>"; exit 2; fi
 "v$1"
