@@ -1,14 +1,16 @@
 // convc.hip -- a whole stride-1 identity Bottleneck of 128 planes / 512 channels (layer2, model/smap.py:48-77) in ONE launch, split
 // precision: convb.hip's scheme re-planned for twice the width.
 //     y1 = relu(W1 x + b1)   1x1, 512 -> 128       y2 = relu(W2 * y1 + b2)   3x3 pad 1, 128 -> 128       out = relu(W3 y2 + b3 + x) (+ skip adds)
-// As three launches the block moves 8192 bytes per pixel through the fabric; here x is read once and out written once: 4096.
+// As three launches the block moves 8192 bytes per pixel through the fabric; here x is read once (a quarter of it twice, see below) and out
+// written once: 4608.
 //
 // One workgroup of EIGHT waves per CU (y1 on the halo patch alone is 96 KiB), 160 KiB of LDS, an 8 x 16 tile of output pixels:
 //   phase 1  c1 on the 10 x 18 halo patch (192 GEMM rows): K = 512 in 32-channel stages, each staged as conv3.hip rows
 //            [192][hi32 | lo32] (x, 24 KiB) + [128][hi32 | lo32] (W1, 16 KiB) by LDS-DMA in a ring of 4 stages over the whole LDS.
 //            A wave owns 3 of the 24 32 x 32 blocks of y1: channel block wave & 3, patch-row blocks 3 (wave >> 2) + {0, 1, 2}.
-//            While x streams past, every wave copies the centre pixels' values its last epilogue will add into REGISTERS
-//            (128 per lane: the register file holds the 256 KiB of the tile's residual that LDS cannot).
+//            While x streams past, every wave copies the centre pixels' values its last epilogue will add into REGISTERS: three of
+//            the four 128-channel chunks (96 registers per lane; the fourth would need scratch next to the 48 accumulators of this
+//            phase, so the last chunk's residual is loaded again while that chunk is multiplied).
 //   phase 2  the 3x3 as nine shifted views of y1 ([4 chunks][192 rows][128 B]), 16 KiB weight slots (128 rows of one 32-channel
 //            chunk of one tap) in a ring of 4 behind y1; 2 x 4 waves: pixel half wave >> 2, channel block wave & 3; y2 over y1.
 //   phase 3  the tail 1x1 in four chunks of 128 output channels (four 16 KiB k-chunk slots each, same ring), register epilogue:
