@@ -42,6 +42,7 @@ import torch.distributed as dist  # noqa: E402
 
 ALG_GFLOP_PER_FRAME = 300.628      # SURVEY.md 8d / BASELINE.md 3: inference-live conv FLOPs (2*MAC)
 PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+SURVEY_GB_PER_FRAME_FP16 = 1.854   # minimum unfused activation + weight traffic per frame, fp16 (3.707 GB at fp32 size)
 PEAK_HBM_GBPS = 8000.0             # HBM3E (same guide); the measured ceilings are lower and reported beside it
 H, W = 512, 832
 
@@ -534,6 +535,15 @@ def main():
             t = json.load(open(tj))
             traffic = t["hbm_read_bytes_per_batch"] + t["hbm_write_bytes_per_batch"]
             traffic_src = t["source"]
+        mfma_ctr, mfma_src = None, None                         # MFMA pipe utilisation by counters (separate PMC pass, depth 1)
+        mj = os.path.join(ROOT, "profiles", "mfma_utilisation_x3.json" if x3 else "mfma_utilisation.json")
+        if os.path.exists(mj) and B == 8:
+            t = json.load(open(mj))
+            mfma_ctr, mfma_src = t["pipe_utilisation"], t["source"]
+
+        def hbm_view(nbytes):                                   # bytes per step -> GB/s over the timed region and its share of the HBM peak
+            g = nbytes / step_s / 1e9
+            return {"bytes_per_step": nbytes, "achieved": g, "frac": g / PEAK_HBM_GBPS}
         n_rec = len(collected) if gathered is None else sum(len(pickle.loads(b)) for b in gathered)
         # every timed step runs the SAME frames (and one of four synthetic scenes): records with one image_path must be identical, bit
         # for bit, whatever ran next to them on the GPU -- a guard the overlapped pipeline lacked until round 3 (EXPERIMENTS R3.6)
@@ -586,20 +596,26 @@ def main():
                                             "busiest_threads_cpu_ms": [[n, round(v, 2)] for n, v in busiest]},
                        "host_submit_ms_quantiles": [float(np.percentile(host["steps"], q)) for q in (0, 10, 50, 90, 100)],
                        "host_timeline_ms": {"submit_loop_done": t_loop * 1e3, "flush_done": t_flush * 1e3, "total": dt * 1e3}},
-            # The roof the schedule is under is the CU's memory path (HBM / Infinity Cache reads and writes plus the L2 -> LDS staging
-            # stream add up per launch: DESIGN.md 6, EXPERIMENTS R3.2 / R4.2b: with two forwards in flight the frames/s follow the bytes
-            # and are insensitive to how well a launch uses the matrix pipe), so `bound` is "hbm": algorithmic bytes of the launches
-            # (fused launches count what THEY must move: x + out + weights) / time.  The MFMA view of the same region is under "mfma".
-            "roofline": {"bound": "hbm", "achieved": alg_bytes / step_s / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": alg_bytes / step_s / 1e9 / PEAK_HBM_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_batch": alg_bytes,
+            # Headline = SURVEY.md 8d: the backbone's bounding roof is the matrix pipe, achieved = 300.628 GFLOP x frames / time against the
+            # dense fp16 MFMA peak (`frac`); the split-precision mode EXECUTES three MFMAs per algorithmic one (`pipe_frac`), and the
+            # counter figure of the committed PMC pass stands beside it.  `hbm` is the other view of the same region: bytes / time
+            # against the 8 TB/s HBM peak, with SURVEY 8d's unfused per-frame traffic (1.854 GB fp16, 3.707 GB fp32-sized) AND this
+            # build's own count (x3 storage = fp32-sized; a fused launch counts what IT must move: x + out + weights).
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F16_TFLOPS,
+                         "flops_executed_per_algorithmic_flop": 3 if x3 else 1,
+                         "pipe_frac": (3 if x3 else 1) * achieved / PEAK_F16_TFLOPS,
+                         "pipe_frac_counters": mfma_ctr, "pipe_frac_counters_source": mfma_src,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "conv_igemm_kernel / conv3x3_halo_kernel / convp_kernel / bottleneck_kernel / bottleneck128_kernel (all backbone launches; HIP "
-                                   "events: per-schedule span below, rate = algorithmic bytes of the timed region / its duration when depth > 1)",
-                         "measured_ceilings_GBps": {"hbm_read": 5300, "hbm_write": 6200, "hbm_mixed": 5200,
-                                                    "source": "profiles/r2_v17_ubench_hbm_read_write_mix.log"},
-                         "mfma": {"achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
-                                  "flops_executed_per_algorithmic_flop": 3 if x3 else 1,
-                                  "pipe_frac": (3 if x3 else 1) * achieved / PEAK_F16_TFLOPS},
+                                   "events: per-schedule span below, rate = algorithmic work of the timed region / its duration when depth > 1)",
+                         "hbm": {"peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                 "survey_8d_fp16": hbm_view(SURVEY_GB_PER_FRAME_FP16 * 1e9 * B),
+                                 "survey_8d_fp32_sized": hbm_view(2 * SURVEY_GB_PER_FRAME_FP16 * 1e9 * B),
+                                 "this_schedule": hbm_view(alg_bytes),
+                                 "measured_traffic": hbm_view(traffic) if traffic else None,
+                                 "measured_ceilings_GBps": {"hbm_read": 5300, "hbm_write": 6200, "hbm_mixed": 5200,
+                                                            "source": "profiles/r2_v17_ubench_hbm_read_write_mix.log"}},
                          "backbone_ms_per_launch": bb * 1e3,
                          "backbone_stream_idle_ms_between_batches": float(np.mean(gap_ms)) if gap_ms else None,
                          "algorithmic_gflop_per_frame": ALG_GFLOP_PER_FRAME},

@@ -475,10 +475,13 @@ class Graph:
         bk = torch.zeros((cout_pad,), dtype=torch.float32)
         bk[:cout] = b.to(torch.float32)
         out = self.tensor(name, Ho, Wo, _rup(cout, 8), 4 if out_fp32 else 2)
-        self.flops += 2 * M * cout * K
-        self.alg_bytes += (nfr * x.H * x.W * cin * 2 * x.planes + nfr * Ho * Wo * out.C * out.esize * out.planes
-                           + wk.numel() * 2 + sum(t.nbytes * nfr // self.B for t in (res, add1, add2, up) if t is not None))
+        fl = 2 * M * cout * K
+        by = (nfr * x.H * x.W * cin * 2 * x.planes + nfr * Ho * Wo * out.C * out.esize * out.planes
+              + wk.numel() * 2 + sum(t.nbytes * nfr // self.B for t in (res, add1, add2, up) if t is not None))
+        self.flops += fl
+        self.alg_bytes += by
         self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, aux=[up] if up is not None else [], p=dict(
+            flops=fl, alg_bytes=by, kinds="1x1" if ksize == 1 else "3x3",
             Cin=cin, in_c_off=in_c_off, Cout=cout, ksize=ksize, stride=stride, pad=pad, relu=int(relu),
             cout_pad=cout_pad, tile=tile, out_fp32=int(out_fp32), w_off=self._add_w(wk), bias_off=self._add_w(bk),
             acc_scale=acc_scale, frames=nfr, w_pairs=w_pairs,
@@ -515,10 +518,13 @@ class Graph:
         bk1 = torch.zeros((cout_pad,), dtype=torch.float32)
         bk1[:cout] = b1.to(torch.float32)
         out = self.tensor(name, x.H, x.W, cout)
-        self.flops += 2 * M * (P * K3 + cout * P)
-        self.alg_bytes += (x.nbytes + out.nbytes + (wk3.numel() + wk1.numel()) * 2
-                           + sum(t.nbytes for t in (res, add1, add2) if t is not None))
+        fl = 2 * M * (P * K3 + cout * P)
+        by = (x.nbytes + out.nbytes + (wk3.numel() + wk1.numel()) * 2
+              + sum(t.nbytes for t in (res, add1, add2) if t is not None))
+        self.flops += fl
+        self.alg_bytes += by
         self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, p=dict(
+            flops=fl, alg_bytes=by, kinds="3x3+1x1",
             Cin=cin, in_c_off=0, Cout=P, ksize=3, stride=1, pad=1, relu=1, cout_pad=P, tile=tile, out_fp32=0,
             w_off=self._add_w(wk3), bias_off=self._add_w(b3.to(torch.float32)), acc_scale=sc3, frames=self.B, w_pairs=0,
             tail=dict(cout=cout, cout_pad=cout_pad, w_off=self._add_w(wk1), bias_off=self._add_w(bk1), acc_scale=sc1,
@@ -547,10 +553,13 @@ class Graph:
         hi, lo, scd = split_f16(wd.reshape(C, Cin))
         wkd = pack_halo_rows(torch.stack([hi, lo]), 64, 1, Cin, True)                 # [4 n chunks][2 k chunks][1][64 rows][128 B]
         out = self.tensor(name, x.H, x.W, C)
-        self.flops += 2 * M * (P * Cin + P * 9 * P + C * P + C * Cin)
-        self.alg_bytes += x.nbytes + out.nbytes + (wk1.numel() + wk3.numel() + wkt.numel() + wkd.numel()) * 2
+        fl = 2 * M * (P * Cin + P * 9 * P + C * P + C * Cin)
+        by = x.nbytes + out.nbytes + (wk1.numel() + wk3.numel() + wkt.numel() + wkd.numel()) * 2
+        self.flops += fl
+        self.alg_bytes += by
         keep = self.keep_ref
         self.ops.append(Op(OP_CONV, out=out, inp=x, p=dict(
+            flops=fl, alg_bytes=by, kinds="block",
             Cin=P, in_c_off=0, Cout=P, ksize=3, stride=1, pad=1, relu=1, cout_pad=P, tile=tile, out_fp32=0,
             w_off=self._add_w(wk3), bias_off=self._add_w(b3.to(torch.float32)), acc_scale=sc3, frames=self.B, w_pairs=0,
             head=dict(cin=Cin, w_off=self._add_w(wk1), bias_off=self._add_w(b1.to(torch.float32)), acc_scale=sc1,
@@ -584,11 +593,14 @@ class Graph:
         hi, lo, sct = split_f16(wt.reshape(C, P))
         wkt = pack_halo_rows(torch.stack([hi, lo]), bn2, 1, P, True)                  # [C/64][P/32][1][64 rows][128 B]
         out = self.tensor(name, x.H, x.W, C)
-        self.flops += 2 * M * (P * C + P * 9 * P + C * P)
-        self.alg_bytes += (x.nbytes + out.nbytes + (wk1.numel() + wk3.numel() + wkt.numel()) * 2
-                           + sum(t.nbytes for t in (add1, add2) if t is not None))
+        fl = 2 * M * (P * C + P * 9 * P + C * P)
+        by = (x.nbytes + out.nbytes + (wk1.numel() + wk3.numel() + wkt.numel()) * 2
+              + sum(t.nbytes for t in (add1, add2) if t is not None))
+        self.flops += fl
+        self.alg_bytes += by
         keep = self.keep_ref
         self.ops.append(Op(OP_CONV, out=out, inp=x, res=x, add1=add1, add2=add2, p=dict(
+            flops=fl, alg_bytes=by, kinds="block",
             Cin=P, in_c_off=0, Cout=P, ksize=3, stride=1, pad=1, relu=1, cout_pad=P, tile=tile, out_fp32=0,
             w_off=self._add_w(wk3), bias_off=self._add_w(b3.to(torch.float32)), acc_scale=sc3, frames=self.B, w_pairs=0,
             head=dict(cin=C, w_off=self._add_w(wk1), bias_off=self._add_w(b1.to(torch.float32)), acc_scale=sc1,

@@ -21,7 +21,7 @@ import json, os
 for f in ("bench_x3", "bench_x3_driver_form", "bench_x3_flip", "bench_x3_refine", "bench_x3_forward_b1", "bench_f16"):
     try:
         d = json.load(open("gpurun_out/%s/%s.json" % (os.environ["TAG"], f))); c = d["config"]; m = c.get("e2e_parity") or {}
-        print(f, round(d["value"], 1), "lf0", c.get("value_launch_frames_0"), "frac", round(d["roofline"]["frac"], 4), "mfma", round(d["roofline"].get("mfma", {}).get("frac", 0), 4),
+        print(f, round(d["value"], 1), "lf0", c.get("value_launch_frames_0"), "mfma frac", round(d["roofline"]["frac"], 4), "pipe", round(d["roofline"].get("pipe_frac", 0), 4),
               {k: m.get(k) for k in ("peaks_differing", "peaks_clear_mismatch", "max_joint_err_cm", "joints_over_0.1cm_unexplained", "lifter_tie_events", "timed_records_equal_these_frames")})
     except Exception as e:
         print(f, "ERR", e)
@@ -40,7 +40,7 @@ python $R/tools/prof_traffic.py $(find $O/pmc_fetch -name "*counter_collection.c
 rm -rf $O/pmc_fetch $O/pmc_write
 # MFMA pipe utilisation, depth 1
 SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o pmc -- python $R/bench.py --depth 1 --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_mfma.log 2>&1
-python $R/tools/prof_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) > $O/mfma_utilisation_pmc.log 2>&1; cat $O/mfma_utilisation_pmc.log
+python $R/tools/prof_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) $O/mfma_utilisation_x3.json > $O/mfma_utilisation_pmc.log 2>&1; cat $O/mfma_utilisation_pmc.log
 rm -rf $O/pmc_mfma
 cd $R
 bash tools/host_budget.sh 24 > $O/host_budget.log 2>&1; cat $O/host_budget.log

@@ -32,7 +32,7 @@ def main():
     g = Graph(SMAP(cfg).state_dict(), B, 512, 832, precision="x3")
     meas = {}
     for line in open(path):
-        m = re.match(r"\s*(\d+)\s+(\S+)\s+(M\d+ N\d+ K\d+ k\ds\d)\s+(\S+)#(\d+)\s+([\d.]+)", line)
+        m = re.match(r"\s*(\d+)\s+(\S+)\s+(M\d+ N\d+ K\d+ k\ds\d(?: [a-z0-9+]+)?)\s+(\S+)#(\d+)\s+([\d.]+)", line)
         if m:
             meas[int(m.group(1))] = (m.group(2), int(m.group(5)), float(m.group(6)))
     rows, tot_m, tot_p, parts = [], 0.0, 0.0, [0.0, 0.0, 0.0, 0.0]
@@ -57,7 +57,16 @@ def main():
             extra = extra - 3 * y.nbytes * nfr // g.B                                    # fabric: the low-res tensor is 1/4 of the output
         fabric = inb + extra + wbytes * min(8, mt * nt)
         written = nfr * y.H * y.W * y.C * y.esize * (planes if y.esize == 2 else 1)
-        if tile_family(tile) == "halo":
+        flops = p.get("flops", 2.0 * M * cout * K)
+        if p.get("kinds") == "block":              # whole Bottleneck (convb / convc): x patch with halo once, every weight of the block per workgroup
+            hc = p["head"]["cin"]
+            th, tw = (4, 16) if tile in (90, 92) else (8, 16)
+            wgs = -(-y.W // tw) * -(-y.H // th) * nfr
+            wall = (cin * hc + 9 * cin * cin + y.C * cin + (y.C * hc if "short" in p else 0)) * 2 * planes
+            inb = nfr * x.H * x.W * hc * 2 * planes
+            fabric = inb + extra - (op.res.nbytes if op.res is not None else 0) + wall * min(8, wgs)    # the residual IS the input: read once
+            l2lds = wgs * ((th + 2) * (tw + 2) * hc * 2 * planes + wall)
+        elif tile_family(tile) == "halo":
             tw = 16 if tile in (30, 31, 34, 35, 38) else 32
             th = 128 // tw
             prow = -(-((th + 2) * (tw + 2)) // 32) * 32
@@ -69,7 +78,7 @@ def main():
         if op.aux:
             l2lds += 4 * written                                                         # the bilinear taps come through the same path
         t_mem = fabric / R + written / W + l2lds / S
-        t_mfma = 3 * 2.0 * M * cout * K / (P * min(1.0, wgs / CUS))
+        t_mfma = 3 * flops / (P * min(1.0, wgs / CUS))
         t = max(t_mem, t_mfma) + LAUNCH
         rows.append((i, y.name[-42:], f"M{M} N{cout} K{K}", tile, us, t * 1e6, fabric / R * 1e6, written / W * 1e6, l2lds / S * 1e6, t_mfma * 1e6))
         tot_m += us

@@ -39,6 +39,7 @@ def main():
             acc[i].append((k[2] - k[1]) / 1e3)
     tot = 0
     agg = {}
+    buckets = {}
     print(f"{'op':4} {'name':44} {'shape':34} {'tile':8} {'us':>8} {'TF/s':>7} {'GB/s':>7}")
     for i, op in enumerate(g.ops):
         d = sorted(acc[i])[len(acc[i]) // 2]
@@ -49,10 +50,11 @@ def main():
             p, x, y = op.p, op.inp, op.out
             M = B * y.H * y.W
             K = p["ksize"] ** 2 * p["Cin"]
-            fl = 2 * M * p["Cout"] * K
-            by = B * x.H * x.W * p["Cin"] * 2 * x.planes + y.nbytes + p["cout_pad"] * K * 2 * (2 if g.x3 else 1)
-            by += sum(t.nbytes for t in (op.res, op.add1, op.add2) if t is not None)
-            shape = f"M{M} N{p['Cout']} K{K} k{p['ksize']}s{p['stride']}"
+            fl, by = p["flops"], p["alg_bytes"]          # what the LAUNCH does: a whole-block op counts its three (four) convs
+            shape = f"M{M} N{p['Cout']} K{K} k{p['ksize']}s{p['stride']}" + ("" if p["kinds"] in ("1x1", "3x3") else " " + p["kinds"])
+            bk = ("whole-block launches" if p["kinds"] == "block" else f"{p['kinds']} s{p['stride']}") + f" at {y.H}x{y.W}"
+            b_ = buckets.setdefault(bk, [0, 0.0, 0.0, 0.0])
+            b_[0] += 1; b_[1] += d; b_[2] += fl; b_[3] += by
             tile = "x".join(map(str, TILES[p["tile"]])) + f"#{p['tile']}"
             key = (shape, tile)
             a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
@@ -63,6 +65,13 @@ def main():
     print("\n== by shape")
     for (shape, tile), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"{shape:36} {tile:8} n={a[0]:3d} us={a[1]:8.1f} TF/s={a[2] / a[1] / 1e6:7.1f} GB/s={a[3] / a[1] / 1e3:7.0f}")
+
+
+    conv_us = sum(b[1] for b in buckets.values())
+    x3 = 3 if g.x3 else 1
+    print(f"\n== buckets (conv launches: {sum(b[0] for b in buckets.values())}, {conv_us:.1f} us per forward; TF/s algorithmic, pipe = x{x3} / 2500)")
+    for k, b in sorted(buckets.items(), key=lambda kv: -kv[1][1]):
+        print(f"{k:34} n={b[0]:3d} us={b[1]:8.1f} {100 * b[1] / conv_us:5.1f} %  TF/s={b[2] / b[1] / 1e6:7.1f} pipe={x3 * b[2] / b[1] / 1e6 / 2500:5.3f} GB/s={b[3] / b[1] / 1e3:7.0f}")
 
 
 if __name__ == "__main__":
