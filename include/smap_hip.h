@@ -211,6 +211,18 @@ typedef struct smap_op {
                                        the tail's; its bias is folded into the tail's bias by the packer; res_off = -1 */
     float short_acc_scale;          /* 2^-s of the shortcut conv's weights; 0 = the op has no shortcut conv */
     int32_t reserved0;
+    /* N SEGMENTS: several 1x1 convs that read the SAME input as one launch with up to three outputs (Upsample_unit, smap.py:210-241:
+       u_skip and skip1 both read x; skip2, cross_conv / res_conv1 and the next unit's up_conv all read `out`).  The weight
+       matrix [cout_pad][K] is the concatenation of the convs' rows, every segment starting on a multiple of the tile's N extent
+       (rows in between are zero); segment 0 = rows [0, seg_n[0]) is described by the op's own fields (Cout, out_off, relu,
+       acc_scale, res / add / aux: those apply to segment 0 only); segment j = 1, 2 = rows [seg_n[j-1], seg_n[j] or cout_pad)
+       writes seg_cout[j-1] channels (multiple of 8) to the dense fp16 tensor at seg_out_off[j-1] (channel stride
+       seg_out_stride_c[j-1]) with its own ReLU flag and accumulator scale.  seg_n[0] = 0: a plain conv.  Tile ids of
+       csrc/conv.hip only (0..9, 20..27, 50..55), ksize 1, fp16 outputs. */
+    int32_t seg_n[2];
+    int32_t seg_cout[2], seg_relu[2], seg_out_stride_c[2];
+    float seg_acc_scale[2];
+    int64_t seg_out_off[2];
 } smap_op;
 
 /* sizeof(smap_op) as compiled: lets a foreign-language binding verify its struct mirror. */

@@ -81,6 +81,14 @@ def run_graph(g, imgs, quantize, keep=False):
             if op.add2 is not None:
                 y = y + T[op.add2.name]
             T[op.out.name] = y if p["out_fp32"] else _q(y, quantize)
+            for sg, t in zip(p.get("segs", []), op.outs):        # N segments: further 1x1 convs on the same input, one output tensor each
+                if quantize:
+                    ws = wk[sg["n0"]:sg["n0"] + sg["cout"]].float().view(sg["cout"], k, k, cin).permute(0, 3, 1, 2).contiguous()
+                    bs = blob[p["bias_off"]:p["bias_off"] + p["cout_pad"] * 4].view(torch.float32)[sg["n0"]:sg["n0"] + sg["cout"]].clone()
+                else:
+                    ws, bs = sg["w_ref"].to(dt), sg["b_ref"].to(dt)
+                ys = F.conv2d(x, ws.to(dev), bs.to(dev))
+                T[t.name] = _q(F.relu(ys) if sg["relu"] else ys, quantize)
         elif op.kind == OP_UPADD:
             a, t = T[op.inp.name], T[op.aux[0].name]
             y = a + up(t, a.shape[-2:])

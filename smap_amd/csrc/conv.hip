@@ -95,6 +95,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     }
     const int m_tile = logical / a.n_tiles, n_tile = logical - m_tile * a.n_tiles;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
+    // ---- N segments (smap_op.seg_*: several 1x1 convs on one input as one launch): the output tensor, channel count, ReLU flag and
+    //      accumulator scale of this workgroup's rows of the weight matrix.  Wave-uniform (from blockIdx): SGPR selects.  Residual,
+    //      post-ReLU addends and the fused bilinear add belong to segment 0.
+    const int seg = (n0 >= a.seg_n1 ? 1 : 0) + (n0 >= a.seg_n2 ? 1 : 0);
+    const int nb = n0 - (seg == 0 ? 0 : seg == 1 ? a.seg_n1 : a.seg_n2);           // first channel of this tile inside its output tensor
+    void* const o_out = seg == 0 ? a.out : seg == 1 ? a.seg_out1 : a.seg_out2;
+    const int o_cout8 = seg == 0 ? a.Cout8 : seg == 1 ? a.seg_cout8_1 : a.seg_cout8_2;
+    const int o_stride = seg == 0 ? a.out_stride_c : seg == 1 ? a.seg_stride1 : a.seg_stride2;
+    const int o_c_off = seg == 0 ? a.out_c_off : 0;
+    const int o_relu = seg == 0 ? a.relu : seg == 1 ? a.seg_relu1 : a.seg_relu2;
+    const float o_scale = seg == 0 ? a.acc_scale : seg == 1 ? a.seg_scale1 : a.seg_scale2;
+    const int o_lo = o_stride >> 1;
+    const _Float16* const o_res = seg == 0 ? a.res : nullptr;
+    const _Float16* const o_up = seg == 0 ? a.up : nullptr;
+    const _Float16* const o_add1 = seg == 0 ? a.add1 : nullptr;
+    const _Float16* const o_add2 = seg == 0 ? a.add2 : nullptr;
 
     // ---- per-thread staging geometry.  Every global address of the K loop is
     //      (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset in one VGPR): the A base is
@@ -212,16 +228,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     constexpr int PASSES = BM * CG / NT;
     static_assert(BM * CG % NT == 0, "tile/thread mismatch");
     half8 rres[PASSES][NPL];
-    if (a.res) {
+    if (o_res) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int idx = p * NT + tid;
             const int row = idx / CG, cg = idx - row * CG;
-            const int m = m0 + row, n = n0 + cg * 8;
-            const unsigned dense = (m < a.M && n < a.Cout8) ? (unsigned)m * (unsigned)(NPL * a.Cout8) + (unsigned)n : 0u;   // < 2^31 elements per tensor
+            const int m = m0 + row, n = nb + cg * 8;
+            const unsigned dense = (m < a.M && n < o_cout8) ? (unsigned)m * (unsigned)(NPL * o_cout8) + (unsigned)n : 0u;   // < 2^31 elements per tensor
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl)
-                rres[p][pl] = *reinterpret_cast<const half8*>(a.res + dense + pl * a.Cout8);
+                rres[p][pl] = *reinterpret_cast<const half8*>(o_res + dense + pl * o_cout8);
         }
     }
 
@@ -309,7 +325,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * (BM / WM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                Cs[row * BN + col] = X3 ? acc[mi][ni][r] * a.acc_scale + bias : acc[mi][ni][r] + bias;
+                Cs[row * BN + col] = X3 ? acc[mi][ni][r] * o_scale + bias : acc[mi][ni][r] + bias;
             }
     }
     __syncthreads();
@@ -327,33 +343,33 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         const int idx = p * NT + tid;
         x.row = idx / CG;
         x.cg = idx - x.row * CG;
-        const int m = m0 + x.row, n = n0 + x.cg * 8;
-        x.ok = m < a.M && n < a.Cout8 && !((SMAP_ABLATE & 4) && a.M != 7);
+        const int m = m0 + x.row, n = nb + x.cg * 8;
+        x.ok = m < a.M && n < o_cout8 && !((SMAP_ABLATE & 4) && a.M != 7);
         const int ms = x.ok ? m : 0, ns = x.ok ? n : 0;            // clamped: loads stay in bounds
         // 32-bit element offsets from the (uniform, 64-bit) tensor bases: a tensor has < 2^31 elements (plan.hip::validate)
-        const unsigned dense = (unsigned)ms * (unsigned)(TS * a.Cout8) + (unsigned)ns;     // res/add tensors are dense [M][Cout8] (x planes)
-        x.o = (unsigned)ms * (unsigned)a.out_stride_c + (unsigned)(a.out_c_off + ns);
-        if (FULL && a.up) {
+        const unsigned dense = (unsigned)ms * (unsigned)(TS * o_cout8) + (unsigned)ns;     // res/add tensors are dense [M][Cout8] (x planes)
+        x.o = (unsigned)ms * (unsigned)o_stride + (unsigned)(o_c_off + ns);
+        if (FULL && o_up) {
             const int b = (SMAP_ABLATE & 64) ? 0 : ms / HoWo, rem = ms - b * HoWo;
             const int oy = (SMAP_ABLATE & 64) ? (ms & 63) : rem / a.Wo, ox = (SMAP_ABLATE & 64) ? (ms & 127) : rem - oy * a.Wo;
             Lerp ly = lerp_index(oy, a.up_h, a.Ho), lx = lerp_index(ox, a.up_w, a.Wo);
             if (SMAP_ABLATE & 64) { ly.i0 = oy >> 1; ly.i1 = ly.i0; ly.l0 = 0.5f; ly.l1 = 0.5f; lx.i0 = ox >> 1; lx.i1 = lx.i0; lx.l0 = 0.5f; lx.l1 = 0.5f; }
-            const int us = TS * a.Cout8;
+            const int us = TS * o_cout8;
             const unsigned tb0 = (unsigned)b * (unsigned)(a.up_h * a.up_w) * (unsigned)us + (unsigned)ns;
-            const _Float16* __restrict__ tb = a.up;
+            const _Float16* __restrict__ tb = o_up;
 #pragma unroll
             for (int pl = 0; pl < ((SMAP_ABLATE & 32) ? 0 : NPL); ++pl) {
-                x.t00[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i0 * a.up_w + lx.i0) * (unsigned)us + (unsigned)(pl * a.Cout8)));
-                x.t01[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i0 * a.up_w + lx.i1) * (unsigned)us + (unsigned)(pl * a.Cout8)));
-                x.t10[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i1 * a.up_w + lx.i0) * (unsigned)us + (unsigned)(pl * a.Cout8)));
-                x.t11[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i1 * a.up_w + lx.i1) * (unsigned)us + (unsigned)(pl * a.Cout8)));
+                x.t00[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i0 * a.up_w + lx.i0) * (unsigned)us + (unsigned)(pl * o_cout8)));
+                x.t01[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i0 * a.up_w + lx.i1) * (unsigned)us + (unsigned)(pl * o_cout8)));
+                x.t10[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i1 * a.up_w + lx.i0) * (unsigned)us + (unsigned)(pl * o_cout8)));
+                x.t11[pl] = *reinterpret_cast<const half8*>(tb + (tb0 + (unsigned)(ly.i1 * a.up_w + lx.i1) * (unsigned)us + (unsigned)(pl * o_cout8)));
             }
             x.ly0 = ly.l0; x.ly1 = ly.l1; x.lx0 = lx.l0; x.lx1 = lx.l1;
         }
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
-            if (FULL && a.add1) x.a1[pl] = *reinterpret_cast<const half8*>(a.add1 + dense + pl * a.Cout8);
-            if (FULL && a.add2) x.a2[pl] = *reinterpret_cast<const half8*>(a.add2 + dense + pl * a.Cout8);
+            if (FULL && o_add1) x.a1[pl] = *reinterpret_cast<const half8*>(o_add1 + dense + pl * o_cout8);
+            if (FULL && o_add2) x.a2[pl] = *reinterpret_cast<const half8*>(o_add2 + dense + pl * o_cout8);
         }
         return x;
     };
@@ -365,44 +381,44 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
             v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
         }
-        if (a.res) {
+        if (o_res) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += val(rres[p], e);
         }
-        if (FULL && a.up) {        // Upsample_unit: out = relu(u_skip(x) + up_conv(bilinear_up(prev))) (smap.py:213-217); the
+        if (FULL && o_up) {        // Upsample_unit: out = relu(u_skip(x) + up_conv(bilinear_up(prev))) (smap.py:213-217); the
                            // 1x1 up_conv was applied at low resolution, this is its bilinear resampling
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 v[e] += x.ly0 * (x.lx0 * val(x.t00, e) + x.lx1 * val(x.t01, e)) +
                         x.ly1 * (x.lx0 * val(x.t10, e) + x.lx1 * val(x.t11, e));
         }
-        if (a.relu) {
+        if (o_relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];       // NaN stays NaN, as torch's ReLU: an overflow must reach the head-sum guard
         }
-        if (FULL && a.add1) {
+        if (FULL && o_add1) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += val(x.a1, e);
         }
-        if (FULL && a.add2) {
+        if (FULL && o_add2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += val(x.a2, e);
         }
         if (!x.ok) return;
         if (a.out_fp32) {
-            float* op = reinterpret_cast<float*>(a.out) + x.o;
+            float* op = reinterpret_cast<float*>(o_out) + x.o;
             *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
             half8 h;
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
-            *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + x.o) = h;
+            *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(o_out) + x.o) = h;
             if (X3) {           // lo plane: the part of v that fp16 dropped (v - hi is exact in fp32)
                 half8 l;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) l[e] = (_Float16)(v[e] - (float)h[e]);
-                *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(a.out) + x.o + a.out_lo) = l;
+                *reinterpret_cast<half8*>(reinterpret_cast<_Float16*>(o_out) + x.o + o_lo) = l;
             }
         }
     };

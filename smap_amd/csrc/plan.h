@@ -39,6 +39,11 @@ struct ConvArgs {
     float acc_scale0;
     const _Float16* wd;      // tile ids 92, 93: packed [n chunk][k chunk][64 rows][128 B] weights of the 1x1 SHORTCUT conv of a layer's first
     float acc_scale_d;       // block (head_cin -> tail_cout, no ReLU; its bias is folded into bias2), or null
+    // N segments (smap_op.seg_*): rows >= seg_n1 / seg_n2 of the weight matrix belong to outputs 1 / 2 (INT_MAX = no such segment)
+    int seg_n1, seg_n2;
+    void* seg_out1; void* seg_out2;
+    int seg_cout8_1, seg_cout8_2, seg_stride1, seg_stride2, seg_relu1, seg_relu2;
+    float seg_scale1, seg_scale2;
 #ifdef SMAP_TRACE
     long long* dbg;          // diagnostics build only (tools/build_ablate.py --trace): per-workgroup phase stamps
 #endif

@@ -12,6 +12,7 @@
 #include <new>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
 #include <vector>
 #include <type_traits>
 #include "smap_hip.h"
@@ -632,6 +633,24 @@ static int validate(const smap_op& o)
                     return SMAP_E_ARG;
             }
             if ((int64_t)o.cout_pad * o.ksize * o.ksize * o.Cin * 2 * (1 + o.precision) > ((int64_t)1 << 32)) return SMAP_E_ARG;
+            if (o.seg_n[0] == 0 && o.seg_n[1] != 0) return SMAP_E_ARG;
+            if (o.seg_n[0] != 0) {                       // N segments: conv.hip's tiles, 1x1, fp16 outputs; every segment starts on an N tile
+                const bool igemm = (o.tile >= 0 && o.tile < 30) || (o.tile >= 50 && o.tile < 60);
+                if (!igemm || o.ksize != 1 || o.out_fp32 || o.out_c_off != 0) return SMAP_E_ARG;
+                int prev = 0;
+                for (int j = 0; j < 2 && o.seg_n[j] != 0; ++j) {
+                    if (o.seg_n[j] <= prev || o.seg_n[j] % bn || o.seg_n[j] >= o.cout_pad) return SMAP_E_ARG;
+                    const int end = (j == 0 && o.seg_n[1] != 0) ? o.seg_n[1] : o.cout_pad;
+                    if (o.seg_cout[j] <= 0 || o.seg_cout[j] % 8 || o.seg_n[j] + o.seg_cout[j] > end) return SMAP_E_ARG;
+                    if (o.seg_out_stride_c[j] % 8 || (o.precision == 1 && o.seg_out_stride_c[j] % 16)) return SMAP_E_ARG;
+                    if (o.seg_out_stride_c[j] < o.seg_cout[j] * (1 + o.precision)) return SMAP_E_ARG;
+                    if (o.precision == 1 && !(o.seg_acc_scale[j] > 0.f)) return SMAP_E_ARG;
+                    const int64_t sb = (int64_t)o.B * o.Ho * o.Wo * o.seg_out_stride_c[j];
+                    if (sb >= ((int64_t)1 << 31) || o.seg_out_off[j] < SMAP_ZERO_PAGE || hits_zero_page(o.seg_out_off[j], sb * 2)) return SMAP_E_ARG;
+                    prev = o.seg_n[j];
+                }
+                if (((o.Cout + 7) & ~7) > o.seg_n[0]) return SMAP_E_ARG;
+            }
             // epilogues address outputs / residuals / addends / the low-res tensor with 32-bit ELEMENT offsets from their bases
             if ((int64_t)o.B * o.Ho * o.Wo * o.out_stride_c >= ((int64_t)1 << 31)) return SMAP_E_ARG;
             if ((int64_t)o.B * o.Ho * o.Wo * ((o.Cout + 7) & ~7) * (1 + o.precision) >= ((int64_t)1 << 31)) return SMAP_E_ARG;
@@ -780,6 +799,14 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
                 a.acc_scale0 = o.head_acc_scale;
                 a.wd = o.head_cin > 0 && o.short_acc_scale > 0.f ? reinterpret_cast<const _Float16*>(wb + o.short_w_off) : nullptr;
                 a.acc_scale_d = o.short_acc_scale;
+                a.seg_n1 = o.seg_n[0] > 0 ? o.seg_n[0] : INT32_MAX;
+                a.seg_n2 = o.seg_n[1] > 0 ? o.seg_n[1] : INT32_MAX;
+                a.seg_out1 = o.seg_n[0] > 0 ? ar + o.seg_out_off[0] : nullptr;
+                a.seg_out2 = o.seg_n[1] > 0 ? ar + o.seg_out_off[1] : nullptr;
+                a.seg_cout8_1 = o.seg_cout[0]; a.seg_cout8_2 = o.seg_cout[1];
+                a.seg_stride1 = o.seg_out_stride_c[0]; a.seg_stride2 = o.seg_out_stride_c[1];
+                a.seg_relu1 = o.seg_relu[0]; a.seg_relu2 = o.seg_relu[1];
+                a.seg_scale1 = o.seg_acc_scale[0]; a.seg_scale2 = o.seg_acc_scale[1];
                 int bm, bn;
                 smap_conv_tile_dims(o.tile, &bm, &bn);
                 a.m_tiles = (a.M + bm - 1) / bm;
@@ -889,6 +916,8 @@ int smap_workspace_bytes(const smap_plan* plan, int64_t* arena_bytes, int64_t* o
                 up(ar, o.out_off, M * o.out_stride_c * (o.out_fp32 ? 4 : 2));
                 up(ar, o.res_off, M * c8 * 2 * pl); up(ar, o.add1_off, M * c8 * 2 * pl); up(ar, o.add2_off, M * c8 * 2 * pl);
                 up(ar, o.aux_off[0], (int64_t)o.B * o.aux_h[0] * o.aux_w[0] * c8 * 2 * pl);
+                for (int j = 0; j < 2; ++j)
+                    if (o.seg_n[j] > 0) up(ar, o.seg_out_off[j], M * o.seg_out_stride_c[j] * 2);
                 break;
             }
             case SMAP_OP_STEM: case SMAP_OP_STEMPOOL: up(ar, o.out_off, M * 64 * 2 * pl); break;

@@ -319,6 +319,7 @@ class Op:
     add2: Tensor = None
     aux: list = field(default_factory=list)
     p: dict = field(default_factory=dict)
+    outs: list = field(default_factory=list)      # further output tensors (N segments 1, 2 of a merged 1x1 launch)
 
 
 def pick_tile_heuristic(M, cout):
@@ -487,6 +488,74 @@ class Graph:
             acc_scale=acc_scale, frames=nfr, w_pairs=w_pairs,
             w_ref=w if self.keep_ref else None, b_ref=b if self.keep_ref else None)))
         return out
+
+    def conv_seg(self, segs, x, up=None, tile=None):
+        """Several 1x1 stride-1 convs that read the SAME input as ONE launch with one output tensor per conv (include/smap_hip.h
+        smap_op.seg_*; Upsample_unit, smap.py:210-241: u_skip | skip1 on x; skip2 | cross_conv | the next unit's up_conv on
+        `out`).  segs: [(tensor name, prefix, relu)], up to three; `up` (the fused bilinear add) belongs to the first.  The weight
+        matrix is the concatenation of the convs' rows, each segment starting on a multiple of the tile's N extent and carrying
+        its own power-of-two scale in split precision, so every conv computes exactly what its own launch would.  Returns the
+        output tensors in order."""
+        assert 2 <= len(segs) <= 3
+        folded = [fold_conv_bn(self.sd, pre) for _, pre, _ in segs]
+        cin = x.C
+        couts = [w.shape[0] for w, _ in folded]
+        assert all(w.shape[1] == cin and w.shape[2] == 1 for w, _ in folded) and all(c % 8 == 0 for c in couts)
+        M = self.B * x.H * x.W
+        # table keys: the merged shape "B,H,W,Cin,c0+c1[+c2],1,1" (tools/autotune_seg.py), then -- a launch nobody tuned -- the entry of its
+        # widest conv alone (same input, same K: the nearest measured relative)
+        key = f"{self.B},{x.H},{x.W},{cin},{'+'.join(map(str, couts))},1,1"
+        wide = f"{self.B},{x.H},{x.W},{cin},{max(couts)},1,1"
+        legal = lambda t: tile_family(t) == "igemm" and (t in X3_TILES or not self.x3) and t not in (3, 8)
+        if tile is not None:
+            assert legal(tile), tile
+        elif self.x3:
+            keys = ([key + ",up"] if up is not None else []) + [key] + ([wide + ",up"] if up is not None else []) + [wide]
+            cands = pick_tile_x3(M, sum(couts), keys)
+            x3t = os.environ.get("SMAP_X3_TILE", "")         # A/B hook, as in Graph.conv
+            if x3t:
+                cands = [int(x3t)] + cands
+            tile = next(t for t in cands if legal(t))
+        else:
+            tile = pick_tile(M, sum(couts), key)
+            if not legal(tile):
+                tile = pick_tile_heuristic(M, sum(couts))
+        bn = TILES[tile][1]
+        starts, n = [], 0
+        for c in couts:
+            starts.append(n)
+            n = _rup(n + c, bn)
+        cout_pad = n
+        planes = 2 if self.x3 else 1
+        wk = torch.zeros((planes, cout_pad, cin), dtype=torch.float16)
+        bk = torch.zeros((cout_pad,), dtype=torch.float32)
+        scales = []
+        for (w, b), st, c in zip(folded, starts, couts):
+            if self.x3:
+                hi, lo, sc = split_f16(w.reshape(c, cin))
+                wk[0, st:st + c], wk[1, st:st + c] = hi, lo
+            else:
+                sc = 1.0
+                wk[0, st:st + c] = w.reshape(c, cin).to(torch.float16)
+            scales.append(sc)
+            bk[st:st + c] = b.to(torch.float32)
+        if not torch.isfinite(wk).all():
+            raise ValueError(f"{segs[0][0]}: folded weights exceed the fp16 range")
+        wk = pack_conv_weights(wk, tile, self.x3, 1, cin, pairs=self.w_pairs)
+        outs = [self.tensor(nm, x.H, x.W, c) for (nm, _, _), c in zip(segs, couts)]
+        fl = 2 * M * sum(couts) * cin
+        by = x.nbytes + sum(t.nbytes for t in outs) + wk.numel() * 2 + (up.nbytes if up is not None else 0)
+        self.flops += fl
+        self.alg_bytes += by
+        keep = self.keep_ref
+        self.ops.append(Op(OP_CONV, out=outs[0], inp=x, aux=[up] if up is not None else [], outs=outs[1:], p=dict(
+            flops=fl, alg_bytes=by, kinds="1x1",
+            Cin=cin, in_c_off=0, Cout=couts[0], ksize=1, stride=1, pad=0, relu=int(segs[0][2]), cout_pad=cout_pad, tile=tile, out_fp32=0,
+            w_off=self._add_w(wk), bias_off=self._add_w(bk), acc_scale=scales[0], frames=self.B, w_pairs=self.w_pairs,
+            segs=[dict(n0=st, cout=c, relu=int(r), acc_scale=sc, w_ref=w if keep else None, b_ref=b if keep else None)
+                  for st, c, (_, _, r), sc, (w, b) in list(zip(starts, couts, segs, scales, folded))[1:]],
+            w_ref=folded[0][0] if keep else None, b_ref=folded[0][1] if keep else None)))
+        return outs
 
     def conv_tail(self, name, pre3, pre1, x, tile, res=None, add1=None, add2=None):
         """A Bottleneck's 3x3 stride-1 conv (prefix pre3, bias + ReLU) and the 1x1 behind it (prefix pre1, + res, ReLU, + add1,
@@ -697,8 +766,50 @@ class Graph:
         # Upsample_module (smap.py:244-286): up1 on x4 ... up4 on x1
         out, s1, s2, cross = None, [None] * 4, [None] * 4, None
         head_t = {}
+        merge = os.environ.get("SMAP_MERGE_1X1", "1") != "0"     # shared-input 1x1s of an Upsample_unit as one launch (A/B hook: "0" = one launch each)
+        tl = None                                                 # up_conv@low of the unit at hand (a segment of the previous unit's launch on `out`)
         for ind, xin in enumerate((x4, x3, x2, x1)):
             u = f"{pre}upsample.up{ind + 1}"
+            un = f"{pre}upsample.up{ind + 2}"                     # the next unit: its up_conv reads this unit's `out` (commuted with the upsample)
+            if merge:
+                # launch 1, on x:   out = relu(u_skip(x) [+ bilinear(up_conv@low)])  |  skip1 = relu(skip1(x))
+                if gen_skip:
+                    lvl = 3 - ind
+                    out, s1[lvl] = self.conv_seg([(u + ".out", u + ".u_skip", True), (u + ".skip1", u + ".skip1", True)], xin, up=tl)
+                else:
+                    out = self.conv(u + ".out", [u + ".u_skip"], xin, relu=True, up=tl)
+                # launch 2, on out: skip2 | cross_conv (stages with skips), res_conv1 (last stage), the next unit's up_conv@low
+                sg = []
+                if gen_skip:
+                    sg.append((u + ".skip2", u + ".skip2", True))
+                    if ind == 3:
+                        sg.append((u + ".cross_conv", u + ".cross_conv", True))
+                if heads and 1 <= ind < 3:
+                    sg.append((u + ".res1", u + ".res_conv1", True))
+                if ind < 3:
+                    sg.append((un + ".up_conv@low", un + ".up_conv", False))
+                got = {}
+                if len(sg) >= 2:
+                    got = dict(zip([n_ for n_, _, _ in sg], self.conv_seg(sg, out)))
+                elif len(sg) == 1:
+                    got = {sg[0][0]: self.conv(sg[0][0], [sg[0][1]], out, relu=sg[0][2])}
+                tl = got.get(un + ".up_conv@low")
+                if gen_skip:
+                    s2[3 - ind] = got[u + ".skip2"]
+                    if ind == 3:
+                        cross = got[u + ".cross_conv"]
+                if heads:
+                    if ind == 3:
+                        m = self.conv(u + ".heads1x1", [u + ".res_conv1", u + ".res_d_conv1", u + ".res_rd_conv1"], out, relu=True)
+                        c = self.chl
+                        head_t["res4"] = self.conv(u + ".res", [u + ".res_conv2"], m, 3, relu=False, in_c_off=0, cin=c, out_fp32=True)
+                        head_t["res_d"] = self.conv(u + ".res_d", [u + ".res_d_conv2"], m, 3, relu=False, in_c_off=c, cin=c, out_fp32=True,
+                                                    frames=self.frames)
+                        head_t["res_rd"] = self.conv(u + ".res_rd", [u + ".res_rd_conv2"], m, 3, relu=False, in_c_off=2 * c, cin=c,
+                                                     out_fp32=True, frames=self.frames)
+                    elif ind >= 1:
+                        head_t[f"res{ind + 1}"] = self.conv(u + ".res", [u + ".res_conv2"], got[u + ".res1"], 3, relu=False, out_fp32=True)
+                continue
             if ind == 0:
                 out = self.conv(u + ".out", [u + ".u_skip"], xin, relu=True)
             else:
@@ -755,9 +866,9 @@ class Graph:
             for t in [op.inp, op.res, op.add1, op.add2] + list(op.aux):
                 if t is not None:
                     t.last = i
-            if op.out is not None:
-                op.out.first = i
-                op.out.last = max(op.out.last, i)
+            for t in ([op.out] if op.out is not None else []) + list(op.outs):
+                t.first = i
+                t.last = max(t.last, i)
         # arena[k * WINDOW : k * WINDOW + ZERO_PAGE] are the conv kernels' zero pages (csrc/plan.hip): never allocated, so no
         # tensor crosses a window boundary and every conv input is within 32 bits of its window's base
         free, top = [], ZERO_PAGE    # free: list of (off, size)
@@ -851,6 +962,10 @@ class Graph:
                     t = op.aux[0]
                     assert t.C == y.C and t.esize == 2
                     o.aux_off[0], o.aux_h[0], o.aux_w[0] = t.off, t.H, t.W
+                for j, (sg, t) in enumerate(zip(p.get("segs", []), op.outs)):
+                    assert (t.H, t.W, t.C) == (y.H, y.W, sg["cout"]) and t.esize == 2
+                    o.seg_n[j], o.seg_cout[j], o.seg_relu[j], o.seg_acc_scale[j] = sg["n0"], sg["cout"], sg["relu"], sg["acc_scale"]
+                    o.seg_out_stride_c[j], o.seg_out_off[j] = t.C * t.planes, t.off
             elif op.kind in (OP_STEM, OP_STEMPOOL):
                 y = op.out
                 o.H, o.W, o.Cin, o.Ho, o.Wo, o.Cout = self.H, self.W, 3, y.H, y.W, 64

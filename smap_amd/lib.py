@@ -44,6 +44,8 @@ class SmapOp(C.Structure):
         ("tail_w_off", C.c_int64), ("tail_bias_off", C.c_int64),
         ("head_cin", C.c_int32), ("head_acc_scale", C.c_float), ("head_w_off", C.c_int64), ("head_bias_off", C.c_int64),
         ("short_w_off", C.c_int64), ("short_acc_scale", C.c_float), ("reserved0", C.c_int32),
+        ("seg_n", C.c_int32 * 2), ("seg_cout", C.c_int32 * 2), ("seg_relu", C.c_int32 * 2), ("seg_out_stride_c", C.c_int32 * 2),
+        ("seg_acc_scale", C.c_float * 2), ("seg_out_off", C.c_int64 * 2),
     ]
 
 

@@ -741,6 +741,118 @@ def test_small_schedule_split_precision_every_tensor(golden_dir, small, monkeypa
         assert np.abs(a.numpy() - z[k]).max() < 2e-5 * np.abs(z[k]).max(), k
 
 
+@pytest.mark.parametrize("precision,tol", [("x3", 2e-5), ("f16", 2e-2)])
+@pytest.mark.parametrize("merge", ["1", "0"], ids=["merged_1x1", "one_launch_each"])
+def test_small_schedule_merged_shared_input_launches(golden_dir, small, monkeypatch, merge, precision, tol):
+    """The shared-input 1x1 convs of every Upsample_unit (smap.py:210-241: u_skip | skip1 on x; skip2 | cross_conv | res_conv1 | the
+    next unit's up_conv on `out`) as ONE launch with one output tensor per conv (smap_op.seg_*) -- and, SMAP_MERGE_1X1=0, as one
+    launch each: every tensor of both schedules against the torch interpretation, the outputs against the imported reference."""
+    from smap_amd.engine import BackboneEngine, Graph
+    from oracle.graph_interp import run_graph
+    _, sd = small
+    monkeypatch.setenv("SMAP_MERGE_1X1", merge)
+    z = np.load(f"{golden_dir}/backbone_small.npz")
+    x = torch.from_numpy(z["x"])
+    eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision=precision)
+    assert sum(len(op.outs) for op in eng.graph.ops) == (18 if merge == "1" else 0)
+    outs = [o.cpu() for o in eng.run(x.to(DEV))]
+    torch.cuda.synchronize()
+    g = Graph(sd, 2, 64, 96, keep_ref=True, precision=precision)
+    with torch.no_grad():
+        *ref, T = run_graph(g, x.double() if precision == "x3" else x, quantize=precision == "f16", keep=True)
+    worst = []
+    for t in eng.graph.tensors:
+        got = eng.read_tensor(t.name).cpu().double().permute(0, 3, 1, 2)
+        want = T[t.name].double()
+        e = (got[:, :want.shape[1]] - want).abs().max().item()
+        worst.append((e / (want.abs().max().item() + 1e-6), t.name))
+    worst.sort(reverse=True)
+    assert worst[0][0] < tol, worst[:5]
+    for a, k in zip(outs, ("hms", "det_d", "root_d")):
+        assert np.abs(a.numpy() - z[k]).max() < (2e-5 if precision == "x3" else 1e-2) * np.abs(z[k]).max(), k
+
+
+SEG_CASES = [   # B, H, W, Cin, couts, relus, up (low-res size or None), tile
+    (2, 13, 21, 256, (256, 64), (1, 1), None, 20),
+    (2, 13, 21, 256, (256, 64, 256), (1, 1, 0), None, 21),
+    (1, 16, 26, 512, (256, 512), (1, 1), (8, 13), 54),
+    (2, 9, 11, 128, (128, 256, 8), (0, 1, 1), (5, 6), 2),
+    (3, 16, 24, 256, (512, 256), (1, 0), None, 53),
+    (1, 32, 52, 64, (256, 64), (1, 1), (16, 26), 50),
+]
+
+
+@pytest.mark.parametrize("x3", [True, False], ids=["x3", "f16"])
+@pytest.mark.parametrize("case", SEG_CASES, ids=lambda c: "x".join(map(str, c[:4])) + "-" + "+".join(map(str, c[4])) + f"-t{c[7]}")
+def test_merged_1x1_launch_matches_torch(case, x3):
+    """One launch, several 1x1 convs on one input, one dense output tensor each (include/smap_hip.h smap_op.seg_*): every output
+    against an f64 torch conv of the same (rounded) operands; ragged M, a segment narrower than the N tile, the fused bilinear
+    add on segment 0 only, per-segment ReLU and accumulator scale."""
+    import torch.nn.functional as F
+    from smap_amd import engine as E
+    from smap_amd import lib as L
+    B, H, W, cin, couts, relus, up, tile = case
+    gen = torch.Generator().manual_seed(sum(case[:4]) + tile)
+    sd, segs = {}, []
+    for j, (c, r) in enumerate(zip(couts, relus)):
+        pre = f"s{j}"
+        sd[pre + ".conv.weight"] = torch.randn(c, cin, 1, 1, generator=gen) * (0.05 * 4 ** j)      # different scales per segment
+        sd[pre + ".conv.bias"] = torch.randn(c, generator=gen) * 0.1
+        sd[pre + ".bn.weight"] = torch.rand(c, generator=gen) + 0.5
+        sd[pre + ".bn.bias"] = torch.randn(c, generator=gen) * 0.1
+        sd[pre + ".bn.running_mean"] = torch.randn(c, generator=gen) * 0.1
+        sd[pre + ".bn.running_var"] = torch.rand(c, generator=gen) + 0.5
+        segs.append((f"y{j}", pre, bool(r)))
+    g = E.Graph.__new__(E.Graph)
+    g.precision, g.x3, g.keep_ref, g.flip_pair, g.frames = ("x3" if x3 else "f16"), x3, True, None, B
+    g.sd, g.B, g.H, g.W, g.w_pairs = sd, B, H * 4, W * 4, 1
+    g.ops, g.tensors, g.wchunks, g.woff, g.flops, g.alg_bytes = [], [], [], 0, 0, 0
+    xt = g.tensor("x", H, W, cin)
+    ut = g.tensor("up", up[0], up[1], couts[0]) if up else None
+    outs = g.conv_seg(segs, xt, up=ut, tile=tile)
+    xt.first = 0
+    if ut is not None:
+        ut.first = 0
+    g.allocate(reuse=False)
+    ops = g.emit()
+    lib = L.load()
+    h = C.c_void_p()
+    L.check(lib.smap_plan_create(ops, 1, C.byref(h)), "smap_plan_create")
+    arena = torch.zeros(g.arena_bytes, dtype=torch.uint8, device=DEV)
+
+    def put(t, v):                    # NCHW fp32 -> the tensor's storage (fp16, or hi | lo planes)
+        v = v.permute(0, 2, 3, 1).contiguous()
+        hi = v.to(torch.float16)
+        if t.planes == 2:
+            lo = (v - hi.float()).to(torch.float16)
+            raw = torch.stack([hi, lo], 3).reshape(-1)
+            val = (hi.double() + lo.double())
+        else:
+            raw, val = hi.reshape(-1), hi.double()
+        arena[t.off:t.off + t.nbytes].view(torch.float16).copy_(raw.to(DEV))
+        return val.permute(0, 3, 1, 2)
+    xv = put(xt, torch.randn(B, cin, H, W, generator=gen))
+    uv = put(ut, torch.randn(B, couts[0], up[0], up[1], generator=gen)) if up else None
+    blob = g.weight_blob().to(DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()), None, st), "run")
+    torch.cuda.synchronize()
+    lib.smap_plan_destroy(h)
+    p = g.ops[0].p
+    refs = [(p["w_ref"], p["b_ref"], p["relu"])] + [(sg["w_ref"], sg["b_ref"], sg["relu"]) for sg in p["segs"]]
+    for j, (t, (w, b, r)) in enumerate(zip(outs, refs)):
+        raw = arena[t.off:t.off + t.nbytes].view(torch.float16).cpu()
+        got = (raw.view(B, H, W, 2, t.C).double().sum(3) if t.planes == 2 else raw.view(B, H, W, t.C).double()).permute(0, 3, 1, 2)
+        wq = w.double() if x3 else w.to(torch.float16).double()
+        want = F.conv2d(xv, wq, b.double())
+        if j == 0 and up:
+            want = want + F.interpolate(uv, size=(H, W), mode="bilinear", align_corners=True)
+        if r:
+            want = F.relu(want)
+        err, mx = (got - want).abs().max().item(), want.abs().max().item()
+        assert torch.isfinite(got).all() and err < ((3e-6 * mx + 1e-6) if x3 else 2e-3 * mx), (j, err, mx)
+
+
 @pytest.mark.parametrize("env", [{"SMAP_HALO3": "16"}, {"SMAP_HALO3": "32", "SMAP_HALO3_DEEP": "1"}], ids=["halo16", "halo32deep"])
 def test_small_schedule_split_precision_with_halo_kernel(golden_dir, small, monkeypatch, env):
     """precision "x3" with every plain 3x3 conv on the halo-tiled kernel's split-precision instances."""

@@ -191,16 +191,21 @@ def test_backbone_ref_matches_reference_at_full_size(golden_dir):
     print("full-size oracle vs imported reference (sampled, channel sums):", worst)
 
 
-def test_schedule_wiring_matches_reference_golden(golden_dir, small_model):
+@pytest.mark.parametrize("merge", ["1", "0"])
+def test_schedule_wiring_matches_reference_golden(golden_dir, small_model, monkeypatch, merge):
     """The engine's op list, interpreted in fp32 on CPU, reproduces the reference outputs:
-    folding, dead-head removal, commuted up_conv, merged heads, epilogue skip adds."""
+    folding, dead-head removal, commuted up_conv, merged heads, epilogue skip adds -- with the shared-input 1x1s of every
+    Upsample_unit (smap.py:210-241) as one launch with several outputs (default) and as one launch each."""
     from smap_amd.engine import Graph
     from oracle.graph_interp import run_graph
     z = np.load(f"{golden_dir}/backbone_small.npz")
     _, sd = small_model
+    monkeypatch.setenv("SMAP_MERGE_1X1", merge)
     g = Graph(sd, 2, 64, 96, keep_ref=True)
     g.allocate()
-    assert len(g.ops) == 208          # 203 convs + stem + maxpool + 3 head sums
+    # 203 convs + stem + maxpool + 3 head sums; merged: 2 launches fewer per Upsample_unit of stages 0 / 1, 1 fewer for up2 / up3 of stage 2
+    assert len(g.ops) == (208 - 18 if merge == "1" else 208)
+    assert sum(len(op.outs) for op in g.ops) == (18 if merge == "1" else 0)
     with torch.no_grad():
         outs = run_graph(g, torch.from_numpy(z["x"]), quantize=False)
         outs_q = run_graph(g, torch.from_numpy(z["x"]), quantize=True)
