@@ -365,11 +365,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     cdev = dev if backend == "nccl" else torch.device("cpu")      # where collective payloads live
+    # SMAP_FORCE_GATHER=1 (tests/test_entry_gpu.py): a ONE-rank run that still initialises the process group and sends its records through
+    # the end-of-run all_gather -- the RCCL path of configs[3] on a one-GPU box
+    force_gather = world == 1 and os.environ.get("SMAP_FORCE_GATHER", "") == "1"
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm; one process per GPU
         else:
             dist.init_process_group(backend)
+    elif force_gather:
+        from smap_amd.dist import init_single_rank_group
+        init_single_rank_group(backend, dev)
 
     from benchkit.workload import PEOPLE_CAM, make_cfg, people_state_dict, synth_scene
     from model.smap import SMAP
@@ -464,7 +470,7 @@ def main():
         collected.extend(tail)
     t_flush = time.perf_counter() - t0
     gathered = None
-    if world > 1:                             # ONE gather per run: every rank's records to every rank (RCCL, comm stream)
+    if world > 1 or force_gather:             # ONE gather per run: every rank's records to every rank (RCCL, comm stream)
         payload = pickle.dumps(collected, protocol=pickle.HIGHEST_PROTOCOL)
         with torch.cuda.stream(pipe.s_comm):
             gathered = gather_bytes(payload, cdev)
@@ -586,6 +592,9 @@ def main():
                        "value_launch_frames_0": fps_lf0 if fps_lf0 is not None else (fps if pipe.frames_per_launch == B * (2 if args.flip else 1) else None),
                        "added_latency_steps_by_coalescing": (pipe.frames_per_launch // (B * (2 if args.flip else 1)) - 1),
                        "ranks_in_gather": len(gathered) if gathered is not None else 1,
+                       # did the records go through torch.distributed (backend "nccl" = RCCL) and come back byte for byte?
+                       "gather": ({"backend": dist.get_backend(), "payload_bytes": len(payload), "payload_device": str(cdev),
+                                   "own_payload_returned_identical": gathered[rank] == payload} if gathered is not None else None),
                        "association_lift_us_per_launch": {k: float(np.median(v)) for k, v in sorted(post_us.items())},
                        # submit_wall = enqueue (the host's own work: launches, H2D of the cameras, record building) + backpressure_wait
                        # (asleep until the GPU has finished the batch submitted `depth` steps earlier: a closed loop must wait somewhere)
@@ -665,6 +674,7 @@ def main():
         rcs = torch.tensor([rc], dtype=torch.int32, device=cdev)
         dist.all_reduce(rcs, op=dist.ReduceOp.MAX)
         rc = int(rcs.item())
+    if dist.is_initialized():
         dist.destroy_process_group()
     if rc:
         sys.exit(rc)

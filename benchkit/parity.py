@@ -29,10 +29,16 @@ What is compared, per frame (north_star: "peak indices / limb assignments bit-ex
            in one path -- the lifter's counterpart of a peak tie, a DISCRETE event and not accumulated rounding.  Every joint
            beyond 0.01 cm is therefore traced back: the sampled pixel indices of both paths are recomputed for the limbs
            on its chain to the root (chain_bones, test_util.py:45-57); the joint is a LIFTER TIE when some index differs there
-           while the two paths' sample coordinates are within LIFT_TIE_PX (5e-4 network px) of each other (so it is the step, not the coordinate,
-           that moved the sample).  joints_over_0.1cm_unexplained -- a joint off by more than 1e-3 m WITHOUT such a straddled
-           step -- is the number that must be ZERO; lifter_ties / lifter_tie_max_coord_diff_px are reported beside it.
-           (The percentile clamp and the mean of test_util.py:80-85 are continuous in the samples: no events there.)
+           while (1) the two paths' sample coordinates are within the centroid noise the MEASURED map difference allows
+           (`centroid_bound`: |d centroid| <= 2 eps sum|x - c| / sum(w) over the peak's 7x7 window, eps = max |d map| of the
+           frame, + the fp32 accumulation term; x 4 = network px; a sample between two peaks moves by at most the larger of
+           their two bounds) -- so it is the step, not the coordinate, that moved the sample -- and (2) its error is no larger
+           than what the moved samples can cause: the depth maps' own difference between the two pixels each moved sample
+           read, summed over the chain (mean and percentile clamp of test_util.py:80-85 are 1-Lipschitz in the samples), plus
+           the measured root-depth difference (`lifter_tie_cap`).  The derivation is checked on EVERY matched peak of the
+           comparison: the measured coordinate difference must stay under the peak's bound (centroid_noise_max_over_bound <=
+           1).  joints_over_0.1cm_unexplained -- a joint off by more than 1e-3 m WITHOUT such a straddled step, or beyond
+           its cap -- is the number that must be ZERO; lifter_ties / lifter_tie_max_coord_diff_px are reported beside it.
 """
 import numpy as np
 import torch
@@ -42,11 +48,8 @@ TOL_PX = 0.5
 NEAR_TIE = 1e-6          # decision margin (relative to the key-point map scale) below which a peak is a floating-point tie
 THRESHOLD = 0.2          # association.cpp:55 nms threshold on the /255-scaled maps
 MAXP = 127
-LIFT_TIE_PX = 5e-4       # two paths' sample coordinates (network pixels) closer than this straddling an index step = a lifter tie.
-                         # The coordinates are 7x7 centroids of maps that agree to ~3e-6 of their scale; a centroid moves by up to
-                         # eps * (scale / mean window value) * ~1.7 px, i.e. a few 1e-5 heat-map px = ~1e-4 network px (observed at
-                         # the straddled steps of the gain-1.0 flip cases on MI355X: 2.2e-5 and 1.4e-4).  5e-4 network px is
-                         # 1/4000 of the 0.5 heat-map px within which two candidates count as the same peak.
+# (rounds 3-4 used a constant LIFT_TIE_PX here, 1e-4 and then 5e-4 network px, chosen after looking at the cases; round 5 derives
+#  the bound per peak from the measured map difference: centroid_bounds below.)
 STRIDE = 4
 # association.cpp:23-25 jointPairs = cfg.DATASET.PAF.VECTOR (limb k: src -> dst); chain_bones (test_util.py:45-57) walks
 # them from the root (joint 2): joint 0 from limb 1 (reversed), joint 1 from limb 0, then dst from src for k >= 2
@@ -86,6 +89,41 @@ def lift_sample_pixels(body):
         idx = np.stack([np.round(ys).astype(np.int64) // STRIDE, np.round(xs).astype(np.int64) // STRIDE], 1)
         out[k] = (idx, np.stack([ys, xs], 1))
     return root, b[2, ::-1].astype(np.float64), out
+
+
+def centroid_bounds(kp_ref, peaks_ref, eps):
+    """How far can writeResultKernel's 7x7 centroid (nmsBase.cu:95-128: sum of x * s over the window pixels with s > 0, divided by
+    their sum) move when every map value moves by at most `eps`?  First order: |dc| <= eps * sum|x_j - c| / S with S the window's
+    positive mass (a value crossing zero enters or leaves with |s| <= eps: the same form); doubled for the second-order terms, plus
+    the rounding of the fp32 accumulation itself when its inputs change (24 * 2^-24 * coordinate, see below).  kp_ref [15,H,W]: reference key-point maps (scaled); peaks_ref
+    [15,128,3]: the reference peak list.  Returns {(channel, x as float32 bits, y bits): bound in HEAT-MAP pixels}."""
+    out = {}
+    C, H, W = kp_ref.shape
+    cand = {}
+    for (c, y, x) in peak_pixels(kp_ref, cap=True):
+        cand.setdefault(c, []).append((y, x))
+    for c, pts in cand.items():
+        pts.sort()                                               # raster order = the order of the peak list
+        n = int(peaks_ref[c, 0, 0])
+        for i, (y, x) in enumerate(pts[:n]):
+            y0, y1, x0, x1 = max(0, y - 3), min(H, y + 4), max(0, x - 3), min(W, x + 4)
+            win = kp_ref[c, y0:y1, x0:x1].astype(np.float64)
+            pos = win > -eps
+            S = float(np.where(win > 0, win, 0.0).sum())
+            if S <= 49 * eps:
+                b = 7.0
+            else:
+                xs = np.arange(x0, x1, dtype=np.float64)[None, :] + np.zeros_like(win)
+                ys = np.arange(y0, y1, dtype=np.float64)[:, None] + np.zeros_like(win)
+                cx, cy = float(peaks_ref[c, 1 + i, 0]) - 0.5, float(peaks_ref[c, 1 + i, 1]) - 0.5
+                t = max(float(np.abs(xs - cx)[pos].sum()), float(np.abs(ys - cy)[pos].sum()))
+                # fp32 accumulation: xAcc and sAcc each collect <= 49 roundings of relative size 2^-24; their differences between two
+                # runs on nearly equal inputs add like a random walk (sqrt(49) = 7), twice (numerator and denominator), relative to
+                # the coordinate itself, with a factor 1.7 in hand: 24 (SURVEY 8c measured 4.6e-5 px between an FMA and a non-FMA
+                # build of the same kernel = 0.16 of this term at x = 200; tests/test_parity_cpu.py: 0.35 under 3e-6 map noise)
+                b = 2.0 * eps * t / S + 24 * 2.0 ** -24 * max(cx, cy, 1.0)
+            out[(c, np.float32(peaks_ref[c, 1 + i, 0]).tobytes(), np.float32(peaks_ref[c, 1 + i, 1]).tobytes())] = b
+    return out
 
 
 def peak_pixels(kp, cap=True):
@@ -203,6 +241,8 @@ def compare(hip, ref, root_idx=2):
     n_j = m_j = 0
     errs, rz_errs = [], []
     big_unexplained, lifter_ties, tie_diffs, after_peak_tie, tie_events = [], 0, [], 0, set()
+    noise_px, noise_ratio, tie_bounds, tie_over_cap, tie_errs, root_steps = [0.0], [0.0], [], 0, [], 0
+    rz_same_pixel = []
     worst_frame = None
     margins = []
     cap_shifted = n_cand = 0
@@ -219,10 +259,23 @@ def compare(hip, ref, root_idx=2):
             n_cand += len(ub)
             pa, pb = peak_pixels(a["hms"][:NJ]), peak_pixels(b["hms"][:NJ])
             cap_shifted += sum(1 for p in pa ^ pb if p in ua and p in ub)
+        # centroid noise the measured map difference allows, per reference peak (see `centroid_bounds`), and the measured one
+        eps_f = float(np.abs(a["hms"][:NJ].astype(np.float64) - b["hms"][:NJ]).max()) if ("hms" in a and "hms" in b) else 0.0
+        cb_f = centroid_bounds(b["hms"][:NJ], b["peaks"], eps_f) if "hms" in b else {}
+        cb_default = max(cb_f.values()) if cb_f else 0.0
+
+        def bound_of(c, xy):
+            return cb_f.get((c, np.float32(xy[0]).tobytes(), np.float32(xy[1]).tobytes()), cb_default)
         for c in range(NJ):
             na, nb = int(a["peaks"][c, 0, 0]), int(b["peaks"][c, 0, 0])
             n_pk += max(na, nb)
-            m_pk += len(_pair(a["peaks"][c, 1:1 + na, :2], b["peaks"][c, 1:1 + nb, :2]))
+            prs = _pair(a["peaks"][c, 1:1 + na, :2], b["peaks"][c, 1:1 + nb, :2])
+            m_pk += len(prs)
+            for i, j in prs:
+                d = float(np.abs(a["peaks"][c, 1 + i, :2].astype(np.float64) - b["peaks"][c, 1 + j, :2]).max())
+                if d < 0.05:                                      # the same integer peak (a neighbouring candidate is >= 1 px away)
+                    noise_px.append(d)
+                    noise_ratio.append(d / max(bound_of(c, b["peaks"][c, 1 + j, :2]), 1e-30))
         A, Bo = a["bodys"], b["bodys"]
         n_pe += max(len(A), len(Bo))
         ia = [i for i in range(len(A)) if A[i, root_idx, 3] > 0]
@@ -246,6 +299,8 @@ def compare(hip, ref, root_idx=2):
                     ra, ca, sa = lift_sample_pixels(A[pa])
                     rb, cb, sb = lift_sample_pixels(Bo[pb])
                     root_step = float(np.abs(ca - cb).max()) if ra != rb else None
+                    root_bound = STRIDE * bound_of(root_idx, Bo[pb, root_idx, :2])
+                    drz = abs(float(a["rz"][pa]) - float(b["rz"][pb]))
                     for j, ej in zip(np.nonzero(both)[0], e):
                         if ej <= 1e-2:
                             continue
@@ -255,19 +310,48 @@ def compare(hip, ref, root_idx=2):
                         if any(not (agree[LIMBS[k][0]] and agree[LIMBS[k][1]]) for k in chain):
                             after_peak_tie += 1
                             continue
-                        diffs = [] if root_step is None else [root_step]         # coordinate gaps at the straddled steps of the chain
+                        # coordinate gaps at the straddled steps of the chain, each relative to ITS bound (network px): a sample
+                        # between two peaks moves by at most the larger of the two centroids' bounds; cap = what the moved samples
+                        # can cause (the reference depth map's difference between the two pixels each of them read, 1-Lipschitz mean)
+                        diffs, ratios = [], []
+                        cap = drz
+                        if root_step is not None:
+                            diffs.append(root_step)
+                            ratios.append(root_step / max(root_bound, 1e-30))
                         for k in chain:
                             if k in sa and k in sb:
                                 moved = (sa[k][0] != sb[k][0]).any(1)
                                 if moved.any():
-                                    diffs.append(float(np.abs(sa[k][1][moved] - sb[k][1][moved]).max()))
-                        if diffs and max(diffs) <= LIFT_TIE_PX:
+                                    s_, d_ = LIMBS[k]
+                                    bk = STRIDE * max(bound_of(s_, Bo[pb, s_, :2]), bound_of(d_, Bo[pb, d_, :2]))
+                                    gap = float(np.abs(sa[k][1][moved] - sb[k][1][moved]).max())
+                                    diffs.append(gap)
+                                    ratios.append(gap / max(bk, 1e-30))
+                                    tie_bounds.append(bk)
+                                    if "det_d" in b:
+                                        dm = b["det_d"][k].astype(np.float64)
+                                        ia_, ib_ = sa[k][0][moved], sb[k][0][moved]
+                                        cap += float(np.abs(dm[ia_[:, 0], ia_[:, 1]] - dm[ib_[:, 0], ib_[:, 1]]).max())
+                        # X, Y follow Z through the back-projection ((x - cx) z / f: |x - cx| / f < 1 for any lens this wide), + slack
+                        # for the continuous part (the maps' own 3e-6)
+                        cap = 1.8 * cap + 0.01
+                        if diffs and max(ratios) <= 1.0 and ej <= cap:
                             lifter_ties += 1
                             tie_events.add((f, int(pb)))             # one straddled step moves every joint further down the chain
                             tie_diffs.append(max(diffs))
+                            tie_errs.append(float(ej))
                         elif ej > 0.1:
-                            big_unexplained.append((f, int(pb), int(j), float(ej), diffs))
+                            tie_over_cap += int(bool(diffs) and max(ratios) <= 1.0)
+                            big_unexplained.append((f, int(pb), int(j), float(ej), diffs, ratios, cap))
             rz_errs.append(abs(float(a["rz"][pa]) - float(b["rz"][pb])))
+            # the root depth is read at int(x), int(y) of the root joint // 4 (test_util.py:62-66): the SAME pixel in both paths unless
+            # the root coordinate straddles an integer (a "root step": one more lifter tie, bounded like the others)
+            ra_, ca_, _ = lift_sample_pixels(A[pa])
+            rb_, cb_, _ = lift_sample_pixels(Bo[pb])
+            if ra_ == rb_:
+                rz_same_pixel.append(rz_errs[-1])
+            else:
+                root_steps += 1
     errs = np.asarray(errs) if errs else np.zeros((0,))
     return {
         "frames": len(hip), "peaks_ref": int(sum(int(b["peaks"][c, 0, 0]) for b in ref for c in range(NJ))),
@@ -289,7 +373,15 @@ def compare(hip, ref, root_idx=2):
         "joints_moved_after_peak_tie": int(after_peak_tie),
         "lifter_ties": int(lifter_ties), "lifter_tie_events": len(tie_events),      # joints moved / skeletons with a straddled step
         "lifter_tie_max_coord_diff_px": float(max(tie_diffs)) if tie_diffs else 0.0,
+        # the DERIVED bound those gaps were held to (network px; per limb: 4 x the larger of its two peaks' centroid bounds) and the
+        # check of the derivation on every matched peak of the comparison: measured centroid difference / its bound (must be <= 1)
+        "lifter_tie_bound_px_min_max": [float(min(tie_bounds)), float(max(tie_bounds))] if tie_bounds else None,
+        "lifter_tie_max_joint_err_cm": float(max(tie_errs)) if tie_errs else 0.0,
+        "lifter_ties_over_cap": int(tie_over_cap),
+        "centroid_noise_max_px": float(max(noise_px)), "centroid_noise_max_over_bound": float(max(noise_ratio)),
+        "centroid_peaks_checked": len(noise_px) - 1,
         "root_z_max_err_cm": float(max(rz_errs)) if rz_errs else 0.0,
+        "root_z_max_err_cm_same_pixel": float(max(rz_same_pixel)) if rz_same_pixel else 0.0, "root_steps": int(root_steps),
         "root_z_mean_cm": float(np.mean([r for b in ref for r in b["rz"]])) if any(len(b["rz"]) for b in ref) else 0.0,
         "map_rel_err_max": maps,
     }

@@ -144,7 +144,7 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
             drain(pipe.submit(imgs, cams, list(img_path), annotations=annotations))
     if pipe is not None:
         drain(pipe.flush())
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SMAP_FORCE_GATHER", "") == "1"):
         parts = gather_records(result["3d_pairs"], device)
         result["3d_pairs"] = [r for part in parts for r in part]                # rank order == frame order
     if rank == 0:
@@ -191,6 +191,9 @@ def main():
     dry = bool(args.dry_run)
     if world > 1 and not dist.is_initialized():
         dist.init_process_group("gloo" if dry else "nccl")
+    elif world == 1 and os.environ.get("SMAP_FORCE_GATHER", "") == "1" and not dist.is_initialized():
+        from smap_amd.dist import init_single_rank_group       # one rank, real collectives: the RCCL path on a one-GPU box (tests)
+        init_single_rank_group("gloo" if dry else "nccl")
     if not dry:
         torch.cuda.set_device(local)
     os.makedirs(cfg.TEST_DIR, exist_ok=True)

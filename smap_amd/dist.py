@@ -7,6 +7,7 @@ per-frame result records, following the reference's own helper
 maximum) and its contiguous per-rank split (lib/utils/dataloader.py:80-85).
 """
 import math
+import os
 import pickle
 
 import torch
@@ -20,12 +21,35 @@ def shard_range(num_items, world_size, rank):
     return st, min(num_items, st + per)
 
 
+def _single_rank_shortcut():
+    """A world of one rank has nothing to gather -- unless SMAP_FORCE_GATHER=1 asks for the collectives anyway (the `-m gpu`
+    test that takes the RCCL path on a one-GPU box: tests/test_entry_gpu.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("SMAP_FORCE_GATHER", "") != "1"
+
+
+def init_single_rank_group(backend="nccl", device=None):
+    """SMAP_FORCE_GATHER=1 without a launcher: a process group of ONE rank on 127.0.0.1, so that the end-of-run gather really
+    goes through torch.distributed (backend "nccl" = RCCL) on a one-GPU box."""
+    import socket
+    if dist.is_initialized():
+        return
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(port))
+    kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+    dist.init_process_group(backend, rank=0, world_size=1, **kw)
+
+
 def gather_bytes(payload, device=None):
     """payload: bytes of this rank.  Returns every rank's bytes, in rank order, on every rank: all_gather of the
     lengths, then of the uint8 buffers padded to the maximum (lib/utils/comm.py:47-87); two host syncs per call (the
     lengths, the payloads), both on the CURRENT stream only.  Works for backend nccl (= RCCL; tensors on `device`)
     and gloo (CPU tensors)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single_rank_shortcut():
         return [bytes(payload)]
     world = dist.get_world_size()
     backend = dist.get_backend()
@@ -49,7 +73,7 @@ def gather_records(records, device=None):
     pickle, as the reference's helper does (lib/utils/comm.py:57-59): JSON-encoding a batch of poses costs more host time
     than the batch takes on the GPU (8 ms vs 5.5 ms for 8 frames x 8 persons) and JSON is only the FILE format, written
     once by rank 0 after the run (test.py:147-151)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single_rank_shortcut():
         return [records]
     return [pickle.loads(b) for b in gather_bytes(pickle.dumps(records, protocol=pickle.HIGHEST_PROTOCOL), device)]
 

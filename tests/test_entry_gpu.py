@@ -119,6 +119,40 @@ def test_bench_main_two_ranks_on_one_gpu():
     assert "cpu_baseline" not in d                       # reported at N = 1 only
 
 
+def test_rccl_gather_runs_on_hardware_with_one_rank():
+    """RCCL itself, on a one-GPU box: bench.py's REAL `nccl` branch (process group on the device, payload on the device, the end-of-run
+    gather on the comm stream inside the timed region, barrier) with ONE rank -- SMAP_FORCE_GATHER=1 skips the world == 1 shortcut
+    of smap_amd/dist.py::gather_bytes, so the records really go through dist.all_gather on device tensors
+    (lib/utils/comm.py:47-87) and must come back byte for byte.  Then the helper alone on payloads of ragged sizes."""
+    env = dict(os.environ, SMAP_FORCE_GATHER="1", SMAP_BENCH_NO_LF0="1")
+    env.pop("SMAP_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["config"]
+    assert c["ranks_in_gather"] == 1 and c["gather"]["backend"] == "nccl" and c["gather"]["payload_device"].startswith("cuda")
+    assert c["gather"]["own_payload_returned_identical"] is True and c["gather"]["payload_bytes"] > 10000
+    assert c["records_in_run"] >= 4 * 8 and c["timed_steps_reproduce"]["identical_records_per_frame_across_steps"]
+    code = (
+        "import os, pickle, torch, torch.distributed as dist\n"
+        "os.environ['SMAP_FORCE_GATHER'] = '1'\n"
+        "from smap_amd.dist import init_single_rank_group, gather_bytes, gather_records\n"
+        "torch.cuda.set_device(0)\n"
+        "init_single_rank_group('nccl', torch.device('cuda:0'))\n"
+        "assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1\n"
+        "for n in (0, 1, 7, 4096, 1 << 20):\n"
+        "    p = bytes(bytearray((i * 131 + n) % 251 for i in range(n)))\n"
+        "    got = gather_bytes(p, 'cuda:0')\n"
+        "    assert got == [p], n\n"
+        "recs = [{'pred_3d': [[1.5, 2.5]], 'image_path': 'a/b'}]\n"
+        "assert gather_records(recs, 'cuda:0') == [recs]\n"
+        "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-3000:]
+
+
 def test_two_stream_pipeline_equals_serial_path():
     """smap_amd/pipeline.py (post-processing of batch k overlapped with the backbone of batch k+1,
     double-buffered outputs, pinned D2H) returns exactly what the serial calls return."""

@@ -1,0 +1,65 @@
+"""The end-to-end parity CHECKER (benchkit/parity.py) on CPU: both "paths" are the oracle, one of them on maps perturbed by the
+amount the split-precision backbone differs from the fp32 reference (3e-6 of the map scale).  What is pinned here is the checker's
+own arithmetic: the DERIVED centroid-noise bound holds on every peak, joints moved by a straddled rounding step are classified as
+lifter ties within their cap, and a genuinely wrong coordinate is not."""
+import numpy as np
+import pytest
+
+from benchkit import parity
+from benchkit.workload import PEOPLE_CAM, synth_scene
+from oracle import oracle_lib as O
+
+
+def _frames(n, eps, seed0=100, shift=None):
+    rng = np.random.default_rng(7)
+    ref, hip = [], []
+    cam = np.asarray(PEOPLE_CAM, np.float64)
+    for f in range(n):
+        hms, rdepth, _, _ = synth_scene(6 + f, seed=seed0 + f)
+        yy, xx = np.mgrid[0:128, 0:208].astype(np.float32)
+        det_d = np.stack([10.0 * np.sin(xx / (5.0 + k) + k) * np.cos(yy / (7.0 + k)) for k in range(14)]).astype(np.float32)
+        root_d = (rdepth * 2.0).astype(np.float32)
+
+        def path(h, wrong=None):
+            bodys, peaks, _ = O.connect(h, root_d, 2, True)
+            if wrong is not None and len(bodys):
+                bodys = bodys.copy()
+                bodys[0, 5, 0] += wrong                       # a wrong coordinate: NOT a tie
+            p2, p3, rz = O.lift(bodys, det_d, root_d, cam)
+            return dict(peaks=peaks, bodys=bodys, p2=p2, p3=p3, rz=rz, hms=h, det_d=det_d, root_d=root_d)
+        ref.append(path(hms))
+        noisy = (hms + rng.uniform(-eps, eps, hms.shape).astype(np.float32) * (np.abs(hms) > 0)).astype(np.float32)
+        hip.append(path(noisy, wrong=shift if f == 0 else None))
+    return hip, ref
+
+
+def test_centroid_bound_holds_on_every_peak_and_ties_are_classified():
+    hip, ref = _frames(6, 3e-6)
+    m = parity.compare(hip, ref)
+    assert m["persons_ref"] >= 30 and m["centroid_peaks_checked"] >= 300
+    assert 0.0 < m["centroid_noise_max_over_bound"] <= 1.0, m
+    assert m["centroid_noise_max_px"] < 1e-3
+    assert m["joints_over_0.1cm_unexplained"] == 0 and m["lifter_ties_over_cap"] == 0, m
+    assert m["root_z_max_err_cm_same_pixel"] <= 1e-3 * max(m["root_z_mean_cm"], 1.0)
+    # identical inputs: nothing to classify
+    z = parity.compare(ref, ref)
+    assert z["max_joint_err_cm"] == 0 and z["lifter_ties"] == 0 and z["centroid_noise_max_px"] == 0
+
+
+def test_larger_map_noise_moves_samples_and_stays_explained():
+    """1e-3 of the map scale (the fp16 mode's error level): centroids move by ~1e-3 px, depth samples straddle rounding steps --
+    every joint beyond 1e-3 m must be traced to a step within the bound that noise level allows, and stay under its cap."""
+    hip, ref = _frames(8, 1e-3, seed0=300)
+    m = parity.compare(hip, ref)
+    assert m["centroid_noise_max_over_bound"] <= 1.0, m
+    assert m["lifter_ties"] >= 1 and m["lifter_ties_over_cap"] == 0, m
+    assert m["lifter_tie_max_coord_diff_px"] <= m["lifter_tie_bound_px_min_max"][1]
+    assert m["lifter_tie_max_joint_err_cm"] < 1.0
+
+
+def test_a_wrong_coordinate_is_not_a_tie():
+    hip, ref = _frames(2, 3e-6, seed0=500, shift=0.3)       # 0.3 heat-map px = 1.2 network px off on one joint of one path
+    m = parity.compare(hip, ref)
+    assert m["joints_over_0.1cm_unexplained"] >= 1 or m["max_joint_err_cm"] <= 0.1, m
+    if m["max_joint_err_cm"] > 0.1:
+        assert m["joints_over_0.1cm_unexplained"] >= 1
