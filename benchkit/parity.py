@@ -265,7 +265,9 @@ def compare(hip, ref, root_idx=2):
         cb_default = max(cb_f.values()) if cb_f else 0.0
 
         def bound_of(c, xy):
-            return cb_f.get((c, np.float32(xy[0]).tobytes(), np.float32(xy[1]).tobytes()), cb_default)
+            # a coordinate that is not in the reference peak list (hand-made frames of the unit tests): the fp32 accumulation term alone
+            return cb_f.get((c, np.float32(xy[0]).tobytes(), np.float32(xy[1]).tobytes()),
+                            max(cb_default, 24 * 2.0 ** -24 * max(float(xy[0]), float(xy[1]), 1.0)))
         for c in range(NJ):
             na, nb = int(a["peaks"][c, 0, 0]), int(b["peaks"][c, 0, 0])
             n_pk += max(na, nb)
@@ -328,10 +330,13 @@ def compare(hip, ref, root_idx=2):
                                     diffs.append(gap)
                                     ratios.append(gap / max(bk, 1e-30))
                                     tie_bounds.append(bk)
-                                    if "det_d" in b:
-                                        dm = b["det_d"][k].astype(np.float64)
-                                        ia_, ib_ = sa[k][0][moved], sb[k][0][moved]
+                                    ia_, ib_ = sa[k][0][moved], sb[k][0][moved]
+                                    dm = b["det_d"][k].astype(np.float64) if ("det_d" in b and b["det_d"].shape[0] > k) else None
+                                    if dm is not None and max(ia_[:, 0].max(), ib_[:, 0].max()) < dm.shape[0] and max(ia_[:, 1].max(), ib_[:, 1].max()) < dm.shape[1] \
+                                            and min(ia_.min(), ib_.min()) >= 0:
                                         cap += float(np.abs(dm[ia_[:, 0], ia_[:, 1]] - dm[ib_[:, 0], ib_[:, 1]]).max())
+                                    else:
+                                        cap = float("inf")              # no depth map to look the step up in: no cap
                         # X, Y follow Z through the back-projection ((x - cx) z / f: |x - cx| / f < 1 for any lens this wide), + slack
                         # for the continuous part (the maps' own 3e-6)
                         cap = 1.8 * cap + 0.01

@@ -21,6 +21,7 @@ import argparse
 import json
 import logging
 import os
+import sys
 
 import numpy as np
 import torch
@@ -111,10 +112,15 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
         except ImportError:
             pass
     pipe = None
+    dropped = []                     # frames without a result: their maps came out non-finite
 
     def drain(recs):
         if recs:
             result["3d_pairs"].extend(recs)
+
+    def retire(p):                   # a pipeline that is replaced or finished: everything in flight + the frames it dropped
+        drain(p.flush())
+        dropped.extend(getattr(p, "dropped_frames", []))
 
     for batch in it:
         annotations = None
@@ -136,17 +142,23 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
                 annotations = list(annotations) + [annotations[-1]] * pad
         if pipe is None or pipe.B != len(imgs):
             if pipe is not None:
-                drain(pipe.flush())
+                retire(pipe)
             pipe = pipeline_cls(model, cfg, len(imgs), imgs.shape[-2], imgs.shape[-1], device, refine_w,
                                 do_flip=bool(cfg.DO_FLIP), record_mode=cfg.TEST_MODE, numpy_records=True,
                                 depth=int(os.environ.get("SMAP_PIPELINE_DEPTH", 2)))   # two backbones in flight (+19 %)
         with torch.no_grad():
             drain(pipe.submit(imgs, cams, list(img_path), annotations=annotations))
     if pipe is not None:
-        drain(pipe.flush())
+        retire(pipe)
     if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SMAP_FORCE_GATHER", "") == "1"):
         parts = gather_records(result["3d_pairs"], device)
         result["3d_pairs"] = [r for part in parts for r in part]                # rank order == frame order
+        dropped = [n for part in gather_records(dropped, device) for n in part]
+    if dropped:
+        # the reference's fp32 forward has no such failure: say so where the caller will look (the result file and the exit status)
+        result["dropped_frames"] = list(dropped)
+        logger.warning("{} frame(s) have no result (non-finite maps: an activation exceeded the fp16 range, INTEGRATION.md section 5): {}".format(
+            len(dropped), dropped[:20]))
     if rank == 0:
         dir_name = os.path.split(os.path.split(os.path.realpath(__file__))[0])[1]
         name = os.path.join(output_dir, "{}_{}_{}_{}.json".format(dir_name, cfg.TEST_MODE, cfg.DATA_MODE,
@@ -242,11 +254,16 @@ def main():
             else:
                 logger.info("No such RefineNet checkpoint of {}".format(args.RefineNet_path))
                 return
-        generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, device,
-                                output_dir=os.path.join(cfg.OUTPUT_DIR, "result"))
+        result = generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, device,
+                                         output_dir=os.path.join(cfg.OUTPUT_DIR, "result"))
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        if result.get("dropped_frames"):
+            return 2                 # the result file is written, but it lacks frames the reference would have produced
     else:
         logger.info("No such checkpoint of SMAP {}".format(args.SMAP_path))
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -22,6 +22,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the declarations between this push and the pop at the end of the file are its
+ * whole dynamic symbol table (tests/test_abi_cpu.py compares `nm -D` with this header in both directions). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define SMAP_E_ARG (-1)
 
@@ -180,10 +185,11 @@ typedef struct smap_op {
                                        channels >= in_c_off are halved; pair = int32[Cout] at w_off in the weight blob. */
     int32_t w_pairs;                /* CONV, 32-half K tiles only: 1 = the weight blob stores them in pairs (see w_off), 0 = one
                                        contiguous block per K tile */
-    int32_t status_off;             /* HEADSUM: byte offset (> 0) in the fp32 output buffer of an int32 STATUS word, or 0 = none.
-                                       smap_plan_run clears it, the head sum ORs in bit 0 when a value it writes is not finite
-                                       and bit 1 + (b mod 31) for the output frame b the value belongs to (so a host can drop
-                                       the affected frames of a multi-frame launch and keep the others): split precision keeps
+    int32_t status_off;             /* HEADSUM: byte offset (> 0) in the fp32 output buffer of SMAP_STATUS_WORDS(B) int32 STATUS words, or
+                                       0 = none.  smap_plan_run clears them; when a value the head sum writes for output frame b is not
+                                       finite it ORs bit 0 and bit 1 + b % 31 into word b / 31, and bit 0 into word 0 (so word 0's bit 0
+                                       says "some frame of the launch", and a host can drop exactly the affected frames of a launch of
+                                       any size and keep the others): split precision keeps
                                        fp16's RANGE, an activation beyond 65504 turns into inf / NaN downstream; the host
                                        checks the word when it collects the maps. */
     int32_t tail_cout;              /* CONV, tile ids 80..89 only (else 0): the op is a Bottleneck TAIL in one launch
@@ -225,6 +231,8 @@ typedef struct smap_op {
     int64_t seg_out_off[2];
 } smap_op;
 
+#define SMAP_STATUS_WORDS(frames) (((frames) + 30) / 31)      /* int32 status words of a schedule with `frames` output frames */
+
 /* sizeof(smap_op) as compiled: lets a foreign-language binding verify its struct mirror. */
 int smap_sizeof_op(void);
 /* Geometry of a CONV tile id, for whoever packs the weight blob: M x N extent of the output tile (0 on success, -1 for an
@@ -247,7 +255,7 @@ void smap_plan_destroy(smap_plan* plan);
 /* Runs the whole schedule on `stream`.
  * input : [B,3,H,W] fp32 NCHW images; arena: activation arena; weights: weight blob;
  * out   : fp32 output buffer (hms [B,43,h,w] | det_d [B,14,h,w] | root_d [B,1,h,w] at the
- *         offsets recorded in the HEADSUM ops, plus the int32 status word at status_off when the ops name one). */
+ *         offsets recorded in the HEADSUM ops, plus the SMAP_STATUS_WORDS(B) int32 status words at status_off when the ops name them). */
 int smap_plan_run(const smap_plan* plan, const float* input, void* arena, const void* weights,
                   float* out, void* stream);
 /* The same with the images in n_inputs (1..SMAP_MAX_INPUTS, a divisor of B) separate buffers of B / n_inputs frames each,
@@ -291,6 +299,9 @@ int smap_plan_create_from_blob(const void* blob, size_t blob_bytes, smap_plan** 
 int smap_plan_run_range(const smap_plan* plan, int first, int count, const float* input,
                         void* arena, const void* weights, float* out, void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

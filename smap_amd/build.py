@@ -26,7 +26,8 @@ SOURCES = [
     ("convc.hip", []),
     ("plan.hip", []),
 ]
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+# -fvisibility=hidden: the .so exports exactly what include/smap_hip.h declares (its visibility push / pop), nothing of the internals
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"),
           "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 
 
@@ -60,7 +61,12 @@ def build_lib(force=False, verbose=False):
             relink = True
         objs.append(op)
     if relink or not os.path.exists(OUT):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        # the dynamic symbol table = the functions include/smap_hip.h declares (-fvisibility=hidden + the header's visibility push) and
+        # nothing else: a linker version script also keeps hipcc's per-unit __hip_cuid_* markers and weak template instantiations local
+        vmap = os.path.join(OBJ, "exports.map")
+        with open(vmap, "w") as f:
+            f.write("{ global: smap_*; local: *; };\n")
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vmap, "-o", OUT] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -981,7 +981,10 @@ int smap_convb_tile_dims(int tile, int* bm, int* bn, int* bn2)
     }
 }
 
-// tools only (not part of include/smap_hip.h): resident workgroups per CU the runtime reports for a tile id's kernel
+// tools only (not part of include/smap_hip.h; exported from diagnostics builds with -DSMAP_DEBUG_EXPORTS, tools/build_ablate.py): resident
+// workgroups per CU the runtime reports for a tile id's kernel
+extern "C" __attribute__((visibility("default"))) int smap_debug_convb_occupancy(int tile);
+#ifdef SMAP_DEBUG_EXPORTS
 extern "C" int smap_debug_convb_occupancy(int tile)
 {
     int n = -1;
@@ -995,6 +998,7 @@ extern "C" int smap_debug_convb_occupancy(int tile)
     }
     return e == hipSuccess ? n : -1000 - (int)e;
 }
+#endif
 
 hipError_t smap_launch_convb(const ConvArgs& a, int tile, hipStream_t st)
 {

@@ -483,10 +483,12 @@ hipError_t smap_launch_convc(const ConvArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-// tools only: resident workgroups per CU the runtime reports
-extern "C" int smap_debug_convc_occupancy(void)
+// tools only (diagnostics builds with -DSMAP_DEBUG_EXPORTS): resident workgroups per CU the runtime reports
+#ifdef SMAP_DEBUG_EXPORTS
+extern "C" __attribute__((visibility("default"))) int smap_debug_convc_occupancy(void)
 {
     int n = -1;
     const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bottleneck128_kernel, 512, 0);
     return e == hipSuccess ? n : -1000 - (int)e;
 }
+#endif

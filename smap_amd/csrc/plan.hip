@@ -527,8 +527,12 @@ __global__ __launch_bounds__(256) void headsum_kernel(HeadSrc s, float* __restri
             if (c >= n_kpt) v = v * 0.5f;
         }
         out[(((size_t)b * C + c) * Ho + y) * Wo + x] = v;
-        // inf / NaN: an activation left the fp16 range upstream.  bit 0 = some frame, bit 1 + (b mod 31) = output frame b
-        if (status && !(fabsf(v) <= 3.4028234e38f)) atomicOr(status, 1 | (2 << (b % 31)));
+        // inf / NaN: an activation left the fp16 range upstream.  Status word b / 31: bit 0 = some frame of the word, bit 1 + b % 31 =
+        // output frame b; word 0's bit 0 = some frame of the launch (include/smap_hip.h)
+        if (status && !(fabsf(v) <= 3.4028234e38f)) {
+            atomicOr(reinterpret_cast<unsigned*>(status) + b / 31, 1u | (2u << (b % 31)));
+            if (b >= 31) atomicOr(reinterpret_cast<unsigned*>(status), 1u);
+        }
     }
 }
 
@@ -694,8 +698,8 @@ constexpr long long TL_SLICE = 4LL * (1 + 16384);               // int64 per lau
 static int tl_next = 0;
 static long long* tl_base() { const char* e = getenv("SMAP_TIMELINE_PTR"); return e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 0)) : nullptr; }
 static int tl_cap() { const char* e = getenv("SMAP_TIMELINE_CAP"); return e ? atoi(e) : 0; }
-extern "C" void smap_timeline_reset(void) { tl_next = 0; }
-extern "C" int smap_timeline_count(void) { return tl_next; }
+extern "C" __attribute__((visibility("default"))) void smap_timeline_reset(void) { tl_next = 0; }
+extern "C" __attribute__((visibility("default"))) int smap_timeline_count(void) { return tl_next; }
 #endif
 
 extern "C" {
@@ -746,7 +750,7 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
         if (hipError_t e = hipMemsetAsync(ar + w, 0, SMAP_ZERO_PAGE, st); e != hipSuccess) return hip_rc(e);
     for (int i = first; i < first + count; ++i)          // the status word (one per schedule) starts every run at 0
         if (plan->ops[i].kind == SMAP_OP_HEADSUM && plan->ops[i].status_off > 0 && out) {
-            if (hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(out) + plan->ops[i].status_off, 0, 4, st); e != hipSuccess) return hip_rc(e);
+            if (hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(out) + plan->ops[i].status_off, 0, 4 * (size_t)SMAP_STATUS_WORDS(plan->ops[i].B), st); e != hipSuccess) return hip_rc(e);
             break;
         }
     for (int i = first; i < first + count; ++i) {
@@ -930,7 +934,7 @@ int smap_workspace_bytes(const smap_plan* plan, int64_t* arena_bytes, int64_t* o
                 const int64_t frames = o.flip_from > 0 ? 2 * (int64_t)o.B : o.B;        // the sources hold the mirrored half too
                 for (int k = 0; k < o.n_aux; ++k) up(ar, o.aux_off[k], frames * o.aux_h[k] * o.aux_w[k] * o.Cin * 4);
                 up(ob, o.ext_off, M * o.Cout * 4);
-                if (o.status_off > 0) up(ob, o.status_off, 4);
+                if (o.status_off > 0) up(ob, o.status_off, 4 * (int64_t)SMAP_STATUS_WORDS(o.B));
                 break;
             }
             default: break;
@@ -949,21 +953,40 @@ int smap_plan_create_from_blob(const void* blob, size_t blob_bytes, smap_plan** 
     memcpy(&h, blob, sizeof(h));
     if (memcmp(h.magic, "SMAPPLN1", 8) || h.version != 1 || h.sizeof_op != sizeof(smap_op) || h.header_bytes != sizeof(smap_blob_header))
         return SMAP_E_ARG;
-    if (h.n_ops <= 0 || h.n_ops > 4096 || h.ops_offset < (int64_t)sizeof(h) || h.weights_offset < 0 || h.weights_bytes < 0) return SMAP_E_ARG;
-    if (h.ops_offset + (int64_t)h.n_ops * (int64_t)sizeof(smap_op) > (int64_t)blob_bytes || h.weights_offset + h.weights_bytes > (int64_t)blob_bytes)
-        return SMAP_E_ARG;
+    // every (offset, size) pair is checked as `off <= total - size` with total - size >= 0: no sum that could wrap
+    const int64_t total = (int64_t)blob_bytes;
+    auto inside = [](int64_t off, int64_t size, int64_t total_) { return off >= 0 && size >= 0 && size <= total_ && off <= total_ - size; };
+    if (h.n_ops <= 0 || h.n_ops > 4096 || h.ops_offset < (int64_t)sizeof(h)) return SMAP_E_ARG;
+    if (!inside(h.ops_offset, (int64_t)h.n_ops * (int64_t)sizeof(smap_op), total) || !inside(h.weights_offset, h.weights_bytes, total)) return SMAP_E_ARG;
     std::vector<smap_op> ops(h.n_ops);
     memcpy(ops.data(), static_cast<const char*>(blob) + h.ops_offset, (size_t)h.n_ops * sizeof(smap_op));
-    for (const smap_op& o : ops) {      // the blob's weight section must hold what the ops point at
-        if ((o.kind == SMAP_OP_CONV || o.kind == SMAP_OP_STEM || o.kind == SMAP_OP_STEMPOOL) &&
-            (o.w_off < 0 || o.w_off >= h.weights_bytes || o.bias_off < 0 || o.bias_off >= h.weights_bytes))
-            return SMAP_E_ARG;
+    for (const smap_op& o : ops) {      // the blob's weight section must hold EVERY byte the ops point at (packed sizes: include/smap_hip.h)
+        const int64_t wb = h.weights_bytes, pl = o.precision == 1 ? 2 : 1;
+        bool ok = true;
+        if (o.kind == SMAP_OP_CONV) {
+            if (o.cout_pad <= 0 || o.Cin <= 0 || o.ksize <= 0 || o.ksize > 7) return SMAP_E_ARG;
+            ok = inside(o.w_off, (int64_t)o.cout_pad * o.ksize * o.ksize * o.Cin * 2 * pl, wb) && inside(o.bias_off, (int64_t)o.cout_pad * 4, wb);
+            if (o.tail_cout > 0)
+                ok = ok && o.tail_cout_pad > 0 && o.Cout > 0 && inside(o.tail_w_off, (int64_t)o.tail_cout_pad * o.Cout * 2 * pl, wb) &&
+                     inside(o.tail_bias_off, (int64_t)o.tail_cout_pad * 4, wb);
+            if (o.head_cin > 0) {
+                ok = ok && inside(o.head_w_off, (int64_t)o.head_cin * o.Cin * 2 * pl, wb) && inside(o.head_bias_off, (int64_t)o.Cin * 4, wb);
+                if (o.short_acc_scale > 0.f) ok = ok && o.tail_cout > 0 && inside(o.short_w_off, (int64_t)o.tail_cout * o.head_cin * 2 * pl, wb);
+            }
+        } else if (o.kind == SMAP_OP_STEM || o.kind == SMAP_OP_STEMPOOL) {
+            ok = inside(o.w_off, (int64_t)64 * ST_K * 2 * pl, wb) && inside(o.bias_off, 64 * 4, wb);
+        } else if (o.kind == SMAP_OP_HEADSUM && o.flip_from > 0) {
+            ok = o.Cout > 0 && inside(o.w_off, (int64_t)o.Cout * 4, wb);
+        }
+        if (!ok) return SMAP_E_ARG;
     }
     smap_plan* p = nullptr;
     if (int rc = smap_plan_create(ops.data(), h.n_ops, &p)) return rc;
     int64_t ar = 0, ob = 0;
     smap_workspace_bytes(p, &ar, &ob);
-    if (ar > h.arena_bytes || ob > h.out_bytes) { smap_plan_destroy(p); return SMAP_E_ARG; }     // header and ops disagree
+    // the sizes a host allocates from (header AND info) must cover what the ops touch
+    if (ar > h.arena_bytes || ob > h.out_bytes || ar > h.info.arena_bytes || ob > h.info.out_bytes ||
+        h.info.weights_offset != h.weights_offset || h.info.weights_bytes != h.weights_bytes) { smap_plan_destroy(p); return SMAP_E_ARG; }
     if (info) *info = h.info;
     *plan = p;
     return 0;

@@ -67,8 +67,8 @@ TAIL_BN = {80: 64, 81: 128, 82: 64, 90: 64, 91: 64, 92: 64, 93: 64, 94: 128}    
 # frames/s (+ first blocks); 4 x 16 tiles: 816.
 BLOCK_DEFAULT = {64: 91, 128: 94}       # layer1 (csrc/convb.hip) and layer2 (csrc/convc.hip) identity blocks
 BLOCK_FIRST_DEFAULT = {64: 93}
-# (ids 10..18 and 40..41 belonged to two kernels that no measured table entry selects -- a register-epilogue GEMM and a
-#  weight-stationary persistent 1x1; they live on as experiments under tools/experiments/, outside the product build)
+# (ids 10..18 belonged to a register-epilogue GEMM that no measured table entry selected; it lives on as an experiment under
+#  tools/experiments/, outside the product build.  ids 40..45 are live: the eight-wave halo tiles of csrc/conv3.hip.)
 
 
 def _tile_remap():
@@ -377,9 +377,20 @@ DEFAULT_REMAP = {}
 
 
 class ArenaTooLarge(ValueError):
-    """One activation tensor of the schedule exceeds a 4 GiB window (the conv kernels address their input with 32-bit byte
-    offsets from a 4 GiB-aligned base, csrc/plan.hip): run the frames in smaller batches.  (Until round 3 the whole ARENA had
-    to stay below 4 GiB; now only a single tensor has a limit -- 4 GiB is 52 frames of the widest split-precision tensor.)"""
+    """The schedule does not fit: ONE activation tensor exceeds a 4 GiB window (the conv kernels address their input with 32-bit
+    byte offsets from a 4 GiB-aligned base, csrc/plan.hip: 52 frames of the widest split-precision tensor), or the whole arena
+    exceeds the memory budget (BackboneEngine: SMAP_MAX_ARENA_BYTES, default 45 % of the device memory that is free when the engine
+    is built -- a pipeline keeps one arena per backbone in flight).  Either way: run the frames in smaller launches
+    (PosePipeline splits by itself)."""
+
+
+def arena_budget(device):
+    """Bytes one activation arena may take on `device`: SMAP_MAX_ARENA_BYTES, else 45 % of what is free right now."""
+    env = os.environ.get("SMAP_MAX_ARENA_BYTES", "")
+    if env:
+        return int(float(env))
+    free, _ = torch.cuda.mem_get_info(device)
+    return int(0.45 * free)
 
 
 class Graph:
@@ -852,7 +863,8 @@ class Graph:
             self.out_layout = dict(hms=(0, n_hms), det_d=(B * n_hms * h * w * 4, n_d),
                                    root_d=(B * (n_hms + n_d) * h * w * 4, 1))
             self.out_bytes = B * (n_hms + n_d + 1) * h * w * 4
-            self.status_off = self.out_bytes                 # int32 status word behind the maps (include/smap_hip.h)
+            self.status_off = self.out_bytes                 # int32 status words behind the maps (include/smap_hip.h)
+            self.status_words = (B + 30) // 31               # SMAP_STATUS_WORDS: frame f = word f // 31, bit 1 + f % 31
             # outputs_2d = res4 + res3 + res2 (smap.py:417)
             self.ops.append(Op(OP_HEADSUM, aux=[head_t["res4"], head_t["res3"], head_t["res2"]],
                                p=dict(Cout=n_hms, ext_off=self.out_layout["hms"][0], **flip_p)))
@@ -1012,7 +1024,7 @@ class Graph:
         hdr.magic, hdr.version, hdr.sizeof_op, hdr.header_bytes = b"SMAPPLN1", 1, C.sizeof(_L.SmapOp), C.sizeof(hdr)
         hdr.n_ops, hdr.ops_offset = n_ops, ops_off
         hdr.weights_offset, hdr.weights_bytes = w_off, len(wblob)
-        hdr.arena_bytes, hdr.out_bytes = self.arena_bytes, self.out_bytes + 4
+        hdr.arena_bytes, hdr.out_bytes = self.arena_bytes, self.out_bytes + 4 * self.status_words
         i = hdr.info
         i.frames, i.H, i.W, i.out_h, i.out_w = self.frames, self.H, self.W, self.out_h, self.out_w
         i.n_hms, i.n_det, i.n_root, i.precision = self.kpt_paf, self.paf, 1, int(self.x3)
@@ -1046,6 +1058,11 @@ class BackboneEngine:
         sd = {k: v.detach().cpu() for k, v in state_dict.items()}
         g = Graph(sd, B, H, W, stage_num, chl, kpt_paf, paf, precision=precision, flip_pair=flip_pair)
         g.allocate(reuse=reuse)
+        budget = arena_budget(self.device)
+        if g.arena_bytes > budget:
+            raise ArenaTooLarge(f"the activation arena of a {B}-frame schedule ({precision}{', flip-TTA' if flip_pair is not None else ''}) takes "
+                                f"{g.arena_bytes / 2 ** 30:.2f} GiB, the budget is {budget / 2 ** 30:.2f} GiB (SMAP_MAX_ARENA_BYTES / 45 % of the "
+                                "free device memory): use smaller launches")
         self.graph, self.B, self.H, self.W = g, B, H, W
         self.h, self.w = g.out_h, g.out_w
         self.ops = g.emit()
@@ -1058,6 +1075,7 @@ class BackboneEngine:
         self.handle = handle
         self.kpt_paf, self.paf = kpt_paf, paf
         self.out_floats = g.out_bytes // 4
+        self.status_words = g.status_words
         self.out = self.new_output()                      # default output buffer
         self.hms, self.det_d, self.root_d = self.views(self.out)
         self.flops_per_batch = g.flops
@@ -1076,15 +1094,22 @@ class BackboneEngine:
         return e
 
     def new_output(self):
-        """A fresh fp32 output buffer (hms | det_d | root_d | status word); pass it to run(out=...) to double-buffer.
+        """A fresh fp32 output buffer (hms | det_d | root_d | status words); pass it to run(out=...) to double-buffer.
         Zero-filled: a partial run(first, count) (debug / trace tools) must not hand back uninitialised memory."""
-        return torch.zeros((self.out_floats + 1,), dtype=torch.float32, device=self.device)
+        return torch.zeros((self.out_floats + self.status_words,), dtype=torch.float32, device=self.device)
 
     def status(self, out=None):
         """The status word of the last run into `out` (synchronises): bit 0 = a non-finite value reached the output
         maps, i.e. an activation left the fp16 range on the way (split precision has fp16's range, not fp32's)."""
         buf = self.out if out is None else out
         return int(buf[self.out_floats:self.out_floats + 1].view(torch.int32).item())
+
+    def bad_frames(self, out=None):
+        """Output frames of the last run into `out` whose maps hold a non-finite value (synchronises): frame f is bit 1 + f % 31 of
+        status word f // 31."""
+        buf = self.out if out is None else out
+        words = buf[self.out_floats:self.out_floats + self.status_words].view(torch.int32).tolist()
+        return [f for f in range(self.B) if (words[f // 31] >> (1 + f % 31)) & 1]
 
     def raise_if_nonfinite(self, out=None):
         if self.status(out) & 1:
@@ -1122,9 +1147,9 @@ class BackboneEngine:
         parts = [t.contiguous() for t in parts]
         dev0 = parts[0].device
         if out is not None and (out.dtype != torch.float32 or out.device != dev0 or not out.is_contiguous()
-                                or out.numel() < self.out_floats + 1):
-            # the maps are followed by the status word: a buffer of the pre-round-3 size would be written 4 bytes past its end
-            raise ValueError(f"out must be a contiguous float32 tensor of >= {self.out_floats + 1} elements on {dev0} "
+                                or out.numel() < self.out_floats + self.status_words):
+            # the maps are followed by the status words: a buffer of the pre-round-3 size would be written past its end
+            raise ValueError(f"out must be a contiguous float32 tensor of >= {self.out_floats + self.status_words} elements on {dev0} "
                              f"(BackboneEngine.new_output()), got {out.dtype} x {out.numel()} on {out.device}")
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         outp = C.c_void_p((self.out if out is None else out).data_ptr())

@@ -48,9 +48,10 @@ class _Slot:
         self.host = [dict(p2=mk((B, MAXP, NJ, 4), torch.float32), p3=mk((B, MAXP, NJ, 4), torch.float64),
                           rz=mk((B, MAXP), torch.float64), counts=mk((B,), torch.int32))
                      for _ in range(1 + n_extra)]
-        self.status = engine.out_floats                                      # index of the engine's status word in `out`
-        # host copy of every launch's status word (bit 0: non-finite maps, bit 1 + f mod 31: frame f of the launch is affected)
-        self.status_host = torch.zeros((len(self.outs),), dtype=torch.float32).pin_memory()
+        self.status = engine.out_floats                                      # index of the engine's status words in `out`
+        self.status_words = engine.status_words
+        # host copy of every launch's status words (word f // 31: bit 0 = non-finite maps, bit 1 + f % 31 = frame f of the launch)
+        self.status_host = torch.zeros((len(self.outs), engine.status_words), dtype=torch.float32).pin_memory()
         self.p2_f64 = None               # ground-truth modes: the f64 pred_2d (allocated on first use)
         self.ev_bb = torch.cuda.Event()
         self.ev_post = torch.cuda.Event()       # the host waits on this one: PosePipeline._wait
@@ -78,8 +79,9 @@ class PosePipeline:
         # stem reads the mirrored image by index, the head sum merges the mirrored maps (no ATen cat/flip, no merge pass)
         kpt = cfg.DATASET.KEYPOINT.NUM
         self.flip_pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
-        # frames per backbone launch: the whole batch, or the largest divisor of it whose activation arena stays within the conv
-        # kernels' 4 GiB of 32-bit offsets (split precision + flip-TTA at batch 16 = 32 frames of activations does not)
+        # frames per backbone launch: the whole batch, or the largest divisor of it that the engine accepts (ArenaTooLarge: one tensor
+        # beyond a 4 GiB addressing window -- 53+ frames in split precision -- or an arena beyond the memory budget, SMAP_MAX_ARENA_BYTES /
+        # 45 % of the free device memory: every backbone in flight has its own arena)
         from .engine import ArenaTooLarge
         limit = max_frames_per_launch or int(os.environ.get("SMAP_MAX_FRAMES_PER_LAUNCH", "0")) or batch
         self.chunk = None
@@ -212,7 +214,7 @@ class PosePipeline:
                 p1.record()
                 self.post_events.append((tag if isinstance(tag, str) else "+".join(sorted(set(tag))), p0, p1))
             for j, o in enumerate(slot.outs):
-                slot.status_host[j:j + 1].copy_(o[slot.status:slot.status + 1], non_blocking=True)
+                slot.status_host[j].copy_(o[slot.status:slot.status + slot.status_words], non_blocking=True)
             timed_post("network", slot, 0, slot.hms, slot.det_d, slot.root_d, cams_d, scale=True, gt=gt)
             for j, (tag, hms, rd, dd) in enumerate(extra):
                 row = 0
@@ -269,13 +271,13 @@ class PosePipeline:
         self._wait(slot.ev_post)
         self.wait_s += time.perf_counter() - t0          # back-pressure: the host sleeping until the GPU has finished a batch
         tags, extra_tags, annotations = slot.meta
-        words = slot.status_host.view(torch.int32).tolist()
-        if any(w & 1 for w in words):
+        words = slot.status_host.view(torch.int32).tolist()                   # [launch][word]
+        if any(w[0] & 1 for w in words):
             # The reference's fp32 forward has no such failure; its loop would carry on with the other frames (the result file
             # is only written at the end of the run, test.py:147-151).  So: the frames whose maps are not finite have no
             # result and are dropped with a warning, the other frames of the launch keep theirs; strict mode raises instead.
             c = self.engine.B                                                   # output frames per launch
-            bad = [j * c + f for j, w in enumerate(words) for f in range(c) if (w >> (1 + f % 31)) & 1]
+            bad = [j * c + f for j, w in enumerate(words) for f in range(c) if (w[f // 31] >> (1 + f % 31)) & 1]
             names = [tags[i] for i in bad if tags[i] is not None]
             if self.strict_nonfinite:
                 slot.busy = False
@@ -338,6 +340,10 @@ class CoalescedPipeline:
     post_events = property(lambda self: self.inner.post_events)
     frames_per_launch = property(lambda self: self.inner.chunk)
     wait_s = property(lambda self: self.inner.wait_s + self._small.wait_s)
+    # frames dropped for non-finite maps, by either schedule (PosePipeline.dropped_frames), and the strict switch of both
+    dropped_frames = property(lambda self: self.inner.dropped_frames + self._small.dropped_frames)
+    strict_nonfinite = property(lambda self: self.inner.strict_nonfinite,
+                                lambda self, v: (setattr(self.inner, "strict_nonfinite", bool(v)), setattr(self._small, "strict_nonfinite", bool(v)))[0])
 
     def last_maps(self):
         """Maps of the most recent COALESCED launch (group * batch frames, in submission order), or None if none ran."""

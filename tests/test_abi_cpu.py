@@ -26,6 +26,12 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(so, n), f"{n} declared in include/smap_hip.h but not exported"
     assert sorted(L.SYMBOLS) == names
+    # ... and the converse: the dynamic symbol table holds NOTHING but the header's functions (-fvisibility=hidden + the linker
+    # version script of smap_amd/build.py: no mangled internals, no debug helpers, no __hip_cuid_* markers)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", L.SO_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == names, sorted(set(exported) ^ set(names))
     L.load()
     assert "gfx950" in L.version()
     assert so.smap_sizeof_op() == ctypes.sizeof(L.SmapOp)
@@ -66,6 +72,28 @@ def test_plan_blob_round_trip_and_workspace_bytes():
         hdr.arena_bytes = 4096                                                                       # header smaller than what the ops touch
         lied = bytes(hdr) + blob[C.sizeof(hdr):]
         assert lib.smap_plan_create_from_blob(lied, len(lied), C.byref(plan), None) == -1
+        # ... the sizes in `info` (what the header tells a host to allocate from) are held to the same ops
+        hdr = L.BlobHeader.from_buffer_copy(blob[:C.sizeof(L.BlobHeader)])
+        hdr.info.out_bytes = 16
+        lied = bytes(hdr) + blob[C.sizeof(hdr):]
+        assert lib.smap_plan_create_from_blob(lied, len(lied), C.byref(plan), None) == -1
+        # offsets + sizes that wrap int64, and a weight section that ends before the packed weights of an op do
+        for field, val in (("ops_offset", 2 ** 63 - 8), ("weights_offset", 2 ** 63 - 8), ("weights_bytes", 2 ** 63 - 1)):
+            hdr = L.BlobHeader.from_buffer_copy(blob[:C.sizeof(L.BlobHeader)])
+            setattr(hdr, field, val)
+            lied = bytes(hdr) + blob[C.sizeof(hdr):]
+            assert lib.smap_plan_create_from_blob(lied, len(lied), C.byref(plan), None) == -1, field
+        hdr = L.BlobHeader.from_buffer_copy(blob[:C.sizeof(L.BlobHeader)])
+        nops, so = hdr.n_ops, C.sizeof(L.SmapOp)
+        ops = (L.SmapOp * nops).from_buffer_copy(blob[hdr.ops_offset:hdr.ops_offset + nops * so])
+        last_w = max(range(nops), key=lambda i: ops[i].w_off if ops[i].kind == 0 else -1)        # the conv whose weights lie last in the section
+        for field in ("w_off", "bias_off") + (("head_w_off", "tail_w_off", "tail_bias_off", "head_bias_off") if precision == "x3" else ()):
+            i = last_w if field in ("w_off", "bias_off") else next(i for i in range(nops) if ops[i].head_cin > 0)
+            cut = bytearray(blob)
+            o = L.SmapOp.from_buffer_copy(cut[hdr.ops_offset + i * so:hdr.ops_offset + (i + 1) * so])
+            setattr(o, field, hdr.weights_bytes - 16)                                            # START inside the section, extent beyond its end
+            cut[hdr.ops_offset + i * so:hdr.ops_offset + (i + 1) * so] = bytes(o)
+            assert lib.smap_plan_create_from_blob(bytes(cut), len(cut), C.byref(plan), None) == -1, field
 
 
 @pytest.mark.parametrize("spec", ["", "64:90", "64:91", "64:91+64:93", "64:91,128:94+64:93"])

@@ -275,6 +275,91 @@ def test_one_overflowing_frame_does_not_condemn_its_launch(flip, chunk):
     strict.submit(bad, cams, tags)
     with pytest.raises(RuntimeError, match="f2"):
         strict.flush()
+    if not flip and chunk is None:      # the same through the front end test.py gets for small batches (make_pipeline -> CoalescedPipeline)
+        from smap_amd.pipeline import CoalescedPipeline, make_pipeline
+        co = make_pipeline(net, cfg, 2, 64, 96, dev, launch_frames=4)
+        assert isinstance(co, CoalescedPipeline) and co.dropped_frames == [] and co.strict_nonfinite is False
+        co.submit(bad[:2], cams[:2], tags[:2])
+        co.submit(bad[2:], cams[2:], tags[2:])
+        with pytest.warns(RuntimeWarning, match="fp16 range"):
+            got2 = co.flush()
+        assert co.dropped_frames == ["f2"] and {r["image_path"] for r in got2} == set(tags) - {"f2"}
+        co.strict_nonfinite = True
+        assert co.inner.strict_nonfinite and co._small.strict_nonfinite
+
+
+def test_arena_budget_splits_a_batch_into_smaller_launches(monkeypatch):
+    """SMAP_MAX_ARENA_BYTES (default: 45 % of the free device memory) bounds ONE activation arena; a batch whose schedule would exceed
+    it runs as several smaller launches (PosePipeline's split loop), same records."""
+    from model.smap import SMAP
+    from smap_amd.engine import ArenaTooLarge, Graph
+    from smap_amd.pipeline import PosePipeline
+    from exps.stage3_root2.config import cfg
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((16, 24))).eval()
+    sd = recipe_state_dict(net.state_dict())
+    for k in list(sd):
+        if k.endswith("up4.res_conv2.bn.bias"):
+            sd[k] = sd[k] + 60.0
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    B = 4
+    x = torch.randn(B, 3, 64, 96, generator=torch.Generator().manual_seed(3)).to(dev)
+    cams = np.tile(np.array([0.5, 192, 128, 96, 64, 192, 192, 96, 64], np.float64), (B, 1))
+    tags = [f"f{j}" for j in range(B)]
+    key = lambda recs: [(r["image_path"], r["pred_2d"], r["root_d"]) for r in recs]
+    whole = PosePipeline(net, cfg, B, 64, 96, dev)
+    assert whole.chunk == B
+    whole.submit(x, cams, tags)
+    want = whole.flush()
+    need = {b: Graph(sd, b, 64, 96, precision=net.precision).allocate() for b in (1, 2, 4)}
+    assert need[1] < need[2] < need[4]
+    net.invalidate_engine()
+    monkeypatch.setenv("SMAP_MAX_ARENA_BYTES", str(need[2] + 4096))
+    split = PosePipeline(net, cfg, B, 64, 96, dev)
+    assert split.chunk == 2 and split.engine.graph.arena_bytes <= need[2] + 4096
+    split.submit(x, cams, tags)
+    got = split.flush()
+    assert [k_[0] for k_ in key(got)] == [k_[0] for k_ in key(want)] and len(got) == len(want)
+    monkeypatch.setenv("SMAP_MAX_ARENA_BYTES", str(need[1] - 1))
+    net.invalidate_engine()
+    with pytest.raises(ArenaTooLarge, match="budget"):
+        PosePipeline(net, cfg, B, 64, 96, dev)
+
+
+def test_status_words_cover_launches_beyond_31_frames():
+    """One status bit per output frame, SMAP_STATUS_WORDS(B) words (include/smap_hip.h): in a 40-frame launch the overflow of frame 33
+    must not be booked on frame 2 (round 4 kept ONE word and folded frames modulo 31), and the pipeline drops exactly that frame."""
+    from model.smap import SMAP
+    from smap_amd.pipeline import PosePipeline
+    from exps.stage3_root2.config import cfg
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((16, 24))).eval()
+    sd = recipe_state_dict(net.state_dict())
+    for k in list(sd):
+        if k.endswith("up4.res_conv2.bn.bias"):
+            sd[k] = sd[k] + 60.0
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    B = 40
+    x = torch.randn(B, 3, 64, 96, generator=torch.Generator().manual_seed(3)).to(dev)
+    x[33] *= 1e5
+    x[31] *= 1e5
+    eng = net.engine(B, 64, 96, torch.device(dev))
+    assert eng.status_words == 2
+    out = eng.new_output()
+    hms, _, _ = eng.run(x, out=out)
+    torch.cuda.synchronize()
+    assert eng.status(out) & 1 and eng.bad_frames(out) == [31, 33]
+    assert [f for f in range(B) if not torch.isfinite(hms[f]).all()] == [31, 33]
+    cams = np.tile(np.array([0.5, 192, 128, 96, 64, 192, 192, 96, 64], np.float64), (B, 1))
+    pipe = PosePipeline(net, cfg, B, 64, 96, dev, depth=1)
+    pipe.submit(x, cams, [f"f{j}" for j in range(B)])
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        got = pipe.flush()
+    assert pipe.dropped_frames == ["f31", "f33"] and {r["image_path"] for r in got} == {f"f{j}" for j in range(B)} - {"f31", "f33"}
 
 
 def test_device_preprocess_equals_host_dataset(tmp_path):

@@ -52,7 +52,8 @@ def main():
             run()
         e1.record()
         torch.cuda.synchronize()
-        occ = lib.smap_debug_convc_occupancy() if tile == 94 else lib.smap_debug_convb_occupancy(tile)
+        # (exported by diagnostics builds only: tools/build_ablate.py --one convb.hip SMAP_DEBUG_EXPORTS=1)
+        occ = "n/a" if not hasattr(lib, "smap_debug_convb_occupancy") else (lib.smap_debug_convc_occupancy() if tile == 94 else lib.smap_debug_convb_occupancy(tile))
         if sums:
             print(f"   checksum(s) of the arena after each of 12 launches: {sorted(sums)}")
         print(f"{os.path.basename(L.SO_PATH):28s} occupancy {occ} tile {tile} ({g.ops[idx].out.name}): {e0.elapsed_time(e1) / n * 1e3:8.1f} us per launch (warm, back to back)")
