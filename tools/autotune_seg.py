@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--batch", type=int, action="append")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--write", action="store_true", help="merge the winners into smap_amd/tile_table_x3.json")
+    ap.add_argument("--out", default="", help="write the merged table here instead (a GPU visit: gpurun_out/..., then SMAP_TILE_TABLE_X3=<path>)")
     args = ap.parse_args()
     from types import SimpleNamespace as NS
     from smap_amd.model.smap import SMAP
@@ -109,9 +110,9 @@ def main():
             ranked = sorted(res, key=res.get)
             print(key, f"x{count}", "shipped", cur, {t: round(res[t], 1) for t in ranked[:6]}, flush=True)
             table[key] = ranked[0]
-    if args.write:
-        json.dump(table, open(path, "w"), indent=0, sort_keys=True)
-        print("wrote", path)
+    if args.write or args.out:
+        json.dump(table, open(args.out or path, "w"), indent=0, sort_keys=True)
+        print("wrote", args.out or path)
 
 
 if __name__ == "__main__":

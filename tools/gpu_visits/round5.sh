@@ -1,0 +1,48 @@
+#!/bin/bash
+# Round 5: what each GPU visit ran, one function per visit (the logs under profiles/r5_v<N>_* came from these).
+#     gpurun -- bash tools/gpu_visits/round5.sh <N>
+R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"
+export TMPDIR=/tmp
+line() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); c=d['config']; r=d['roofline']; print('$1', round(d['value'],1),'fps', round(d['ms_per_step'],3),'ms/step', 'lf0', c.get('value_launch_frames_0') and round(c['value_launch_frames_0'],1), 'fpl', c.get('frames_per_launch'), 'mfma', round(r['frac'],4), 'pipe', round(r.get('pipe_frac',0),4))
+"; }
+
+v1() {
+# visit 1: the whole suite on hardware (merged 1x1 launches, RCCL one-rank gather, status words, arena budget, derived lifter-tie
+# bounds), tile search for the merged launches, A/B merged vs one launch each, the bench line, a depth-1 per-layer trace
+O=gpurun_out/r5v1; mkdir -p $O
+python -c "from smap_amd import lib; print(lib.version())" > $O/version.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -25 $O/pytest.log
+timeout 600 python tools/autotune_seg.py --batch 8 --batch 16 --iters 15 --out $R/$O/tile_table_x3_seg.json > $O/autotune_seg.log 2>&1; tail -40 $O/autotune_seg.log
+for rep in 1 2; do
+  for m in 0 1; do
+    SMAP_MERGE_1X1=$m SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep merge=$m shipped-table" >> $O/ab_merge.log
+  done
+  SMAP_TILE_TABLE_X3=$R/$O/tile_table_x3_seg.json SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep merge=1 tuned-table" >> $O/ab_merge.log
+done
+for m in 0 1; do
+  SMAP_MERGE_1X1=$m SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 --launch-frames 0 2>>$O/ab.err | line "merge=$m depth1 lf0" >> $O/ab_merge.log
+done
+SMAP_TILE_TABLE_X3=$R/$O/tile_table_x3_seg.json SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 --launch-frames 0 2>>$O/ab.err | line "merge=1 tuned depth1 lf0" >> $O/ab_merge.log
+cat $O/ab_merge.log
+SMAP_TILE_TABLE_X3=$R/$O/tile_table_x3_seg.json timeout 400 python bench.py > $O/bench_x3.json 2> $O/bench_x3.err; echo "rc $?" >> $O/bench_x3.err
+python - <<'PY'
+import json
+try:
+    d = json.load(open("gpurun_out/r5v1/bench_x3.json")); c = d["config"]
+    print("bench", round(d["value"], 1), "lf0", c.get("value_launch_frames_0"), json.dumps(d["roofline"])[:600])
+    print(json.dumps(c.get("e2e_parity"))[:1800])
+except Exception as e:
+    print("bench ERR", e)
+PY
+cd /tmp
+SMAP_TILE_TABLE_X3=$R/$O/tile_table_x3_seg.json SMAP_PRECISION=x3 SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $R/$O/prof_d1 -o smap -- python $R/bench.py --depth 1 --launch-frames 0 --steps 4 --warmup 2 --no-cpu-baseline > $R/$O/rocprof_d1.log 2>&1
+db=$(find $R/$O/prof_d1 -name "*.db" | head -1); (cd $R; SMAP_TILE_TABLE_X3=$R/$O/tile_table_x3_seg.json SMAP_PRECISION=x3 python tools/prof_layers.py $db 8 > $O/layers_d1.txt 2>&1); python $R/tools/prof_export.py $db $R/$O/kernel_stats_d1.csv; rm -rf $R/$O/prof_d1
+tail -25 $R/$O/layers_d1.txt
+}
+
+"v$1"
