@@ -50,7 +50,9 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // do not fill the chip: with <= 256 workgroups of 4 waves there is no second wave on the SIMD to multiply while the first
 // one waits for its fragments, its LDS-DMA requests or the barrier (a lone wave CAN issue an MFMA every 32 cycles:
 // tools/ubench/mfma_issue.hip; what it cannot do is hide its own stalls).
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3>
+// SPLITK = true: the instance that also takes a.ksplit > 1 (its own template argument: the extra paths cost the plain instances
+// registers and 4 bytes of LDS that tip 80 KiB tiles from two workgroups per CU to one).
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3, bool SPLITK = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a)
 {
     constexpr int NPL = X3 ? 2 : 1;                    // fp16 planes per operand
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     constexpr int STAGE = NPL * (BM + BN) * ROWB;      // [A planes][B planes]
     constexpr int LPT = NPL * (LA + LB);               // LDS-DMA loads per thread per K tile
     static_assert((STAGES - 2) * LPT <= 63, "vmcnt is 6 bits");
-    constexpr int LDS_BYTES = STAGES * STAGE > BM * BN * 4 ? STAGES * STAGE : BM * BN * 4;   // pipeline | fp32 epilogue tile
+    constexpr int LDS_BYTES = (STAGES * STAGE > BM * BN * 4 ? STAGES * STAGE : BM * BN * 4) + (SPLITK ? 16 : 0);   // pipeline | fp32 epilogue tile (+ the split-K flag)
     static_assert(LDS_BYTES <= 160 * 1024, "LDS is 160 KiB per CU");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
@@ -93,7 +95,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int m_tile = logical / a.n_tiles, n_tile = logical - m_tile * a.n_tiles;
+    // SPLIT K (a.ksplit = S > 1: the launches of small schedules whose m_tiles x n_tiles do not fill the chip): S consecutive workgroups
+    // -- neighbours in the logical order, hence mostly on one XCD / one L2 -- share an output tile and take the K tiles
+    // [ks n / S, (ks + 1) n / S) each; their raw accumulators meet in a scratch buffer and the LAST one to arrive (a ticket per tile) sums
+    // them in the fixed order 0 .. S-1 and runs the epilogue: deterministic, no second launch (epilogue 1 below).
+    const int S = SPLITK ? a.ksplit : 1;
+    const int tile_id = S > 1 ? logical / S : logical, ks = logical - tile_id * S;
+    const int m_tile = tile_id / a.n_tiles, n_tile = tile_id - m_tile * a.n_tiles;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     // ---- N segments (smap_op.seg_*: several 1x1 convs on one input as one launch): the output tensor, channel count, ReLU flag and
     //      accumulator scale of this workgroup's rows of the weight matrix.  Wave-uniform (from blockIdx): SGPR selects.  Residual,
@@ -145,7 +153,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         for (int j = 0; j < NPL * LB; ++j)
             __builtin_amdgcn_global_load_lds((gbl_void*)(gB + w_off[j]), (lds_void*)(sB + (j * RPR + wave * RPW) * ROWB), 16, 0, 0);
     };
-    if (!(SMAP_ABLATE & 1)) issue_b(0, 0);
+    // (the K range of a split-K workgroup is known only further down: its first weight tile goes out there)
+    if (!(SMAP_ABLATE & 1) && !SPLITK) issue_b(0, 0);
 
     // Per staged A row: byte offset (from the arena base) of tap (0,0), channel granule gch, and the mask
     // of in-range taps (bit kh*ksize+kw).  m -> (b, oy, ox) costs two integer divisions ONCE per thread;
@@ -182,11 +191,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         }
     }
     const int cchunks = a.Cin / BK;
-    const int n_iter = a.ksize * a.ksize * cchunks;
+    const int n_all = a.ksize * a.ksize * cchunks;             // K tiles of the op
+    const int it_lo = S > 1 ? ks * n_all / S : 0;              // this workgroup's share (all of them without split K)
+    const int n_iter = (S > 1 ? (ks + 1) * n_all / S : n_all) - it_lo;
 
     // staging cursor (all wave-uniform -> SGPRs): tap (s_kh, s_kw), channel chunk s_cc
     int s_kh = 0, s_kw = 0, s_cc = 0;
-    int s_it = 0;                                              // K tile the cursor stands on
+    int s_it = it_lo;                                          // K tile the cursor stands on
+    if (S > 1) {
+        const int tap = it_lo / cchunks;
+        s_cc = it_lo - tap * cchunks;
+        s_kh = tap / a.ksize;
+        s_kw = tap - s_kh * a.ksize;
+    }
     unsigned a_cur[LA];                                        // per-lane offsets of the current tap (0 = zero page)
     auto set_tap = [&]() {
         const unsigned tap_off = (unsigned)((s_kh * a.W + s_kw) * a.in_stride_c * 2);
@@ -219,7 +236,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         issue_b(buf, s_it);
         advance();
     };
-    if (!(SMAP_ABLATE & 1)) { issue_a(0); advance(); }           // activation half of K tile 0
+    if (!(SMAP_ABLATE & 1)) {                                     // activation half of K tile 0 (+ its weight half in a split-K workgroup)
+        if (SPLITK) issue_b(0, it_lo);
+        issue_a(0);
+        advance();
+    }
 
     // ---- residual prefetch: the epilogue's residual tile (8 channels x PASSES pixels per thread) is
     //      requested before the K loop so that its HBM latency hides under the whole main loop
@@ -228,7 +249,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     constexpr int PASSES = BM * CG / NT;
     static_assert(BM * CG % NT == 0, "tile/thread mismatch");
     half8 rres[PASSES][NPL];
-    if (o_res) {
+    auto load_res = [&]() {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int idx = p * NT + tid;
@@ -239,7 +260,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             for (int pl = 0; pl < NPL; ++pl)
                 rres[p][pl] = *reinterpret_cast<const half8*>(o_res + dense + pl * o_cout8);
         }
-    }
+    };
+    if (o_res && !SPLITK) load_res();                          // (split K: only the workgroup that runs the epilogue needs it)
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -325,10 +347,42 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * (BM / WM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                Cs[row * BN + col] = X3 ? acc[mi][ni][r] * o_scale + bias : acc[mi][ni][r] + bias;
+                Cs[row * BN + col] = S > 1 ? acc[mi][ni][r] : (X3 ? acc[mi][ni][r] * o_scale + bias : acc[mi][ni][r] + bias);
             }
     }
     __syncthreads();
+    if (SPLITK && S == 1 && o_res) load_res();
+    if (SPLITK && S > 1) {
+        // raw partial tile -> scratch [tile][k part][BM * BN]; release; ticket.  Everyone but the last arriver is done.
+        float4* part = reinterpret_cast<float4*>(a.kpart) + (size_t)tile_id * S * (BM * BN / 4);
+        const float4* Cs4 = reinterpret_cast<const float4*>(Cs);
+        for (int i = tid; i < BM * BN / 4; i += NT) part[(size_t)ks * (BM * BN / 4) + i] = Cs4[i];
+        __threadfence();                                         // this thread's stores are visible device-wide (L2 write-back across XCDs)
+        __syncthreads();
+        volatile int* s_last = reinterpret_cast<volatile int*>(smem + LDS_BYTES - 16);     // behind the epilogue tile
+        if (tid == 0) {
+            const unsigned t = atomicAdd(a.kcount + tile_id, 1u);
+            *s_last = t == (unsigned)(S - 1);
+            if (t == (unsigned)(S - 1)) atomicExch(a.kcount + tile_id, 0u);      // ready for the next launch
+        }
+        __syncthreads();
+        if (!*s_last) return;
+        __threadfence();                                         // acquire: the other parts' stores
+        if (o_res) load_res();
+        for (int i = tid; i < BM * BN / 4; i += NT) {            // fixed order 0 .. S-1 whoever arrives last (own part re-read too)
+            float4 v = part[i];
+            for (int q = 1; q < S; ++q) {
+                const float4 u = part[(size_t)q * (BM * BN / 4) + i];
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            const int col = (i * 4) % BN;
+            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n0 + col);
+            if (X3) { v.x = v.x * o_scale + b4.x; v.y = v.y * o_scale + b4.y; v.z = v.z * o_scale + b4.z; v.w = v.w * o_scale + b4.w; }
+            else { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+            reinterpret_cast<float4*>(Cs)[i] = v;
+        }
+        __syncthreads();
+    }
 
     // ---- epilogue 2: 8 consecutive channels of one pixel per thread.  Software-pipelined over the
     //      passes: the global loads of pass p+1 (bilinear taps, post-ReLU addends) are issued before the
@@ -448,6 +502,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     SMAP_TL_END(a)
 }
 
+// the split-K instances (tile ids smap_conv_tile_has_splitk: 2, 20, 22 -- what the small schedules run)
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool X3>
+hipError_t launch_splitk(const ConvArgs& a, hipStream_t st)
+{
+    const dim3 grid(a.m_tiles * a.n_tiles * a.ksplit);
+    if (a.up || a.add1 || a.add2)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, true, X3, true>), grid, dim3(WM * WN * 64), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, X3, true>), grid, dim3(WM * WN * 64), 0, st, a);
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64>
 hipError_t launch(const ConvArgs& a, hipStream_t st)
 {
@@ -518,6 +584,9 @@ extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
     }
 }
 
+// tiles that have a split-K instance (both precisions)
+int smap_conv_tile_has_splitk(int tile) { return tile == 2 || tile == 20 || tile == 22; }
+
 // tiles that have a split-precision instance (plan.hip::validate asks)
 int smap_conv_tile_has_x3(int tile)
 {
@@ -530,6 +599,14 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
     if (tile >= 60 && tile < 80) return smap_launch_convp(a, tile, st);      // persistent wave-specialised kernel, both precisions
     if (tile >= 80 && tile < 90) return smap_launch_convf(a, tile, st);      // 3x3 + fused 1x1 tail, both precisions
     if (tile >= 90 && tile < 100) return smap_launch_convb(a, tile, st);     // whole identity Bottleneck, split precision
+    if (a.ksplit > 1) {                                     // split K: its own instances of three tiles (plan.hip::validate asked smap_conv_tile_has_splitk)
+        switch (tile) {
+            case 2: return a.x3 ? launch_splitk<64, 64, 2, 2, 2, 64, true>(a, st) : launch_splitk<64, 64, 2, 2, 2, 64, false>(a, st);
+            case 22: return a.x3 ? launch_splitk<64, 64, 2, 2, 2, 32, true>(a, st) : launch_splitk<64, 64, 2, 2, 2, 32, false>(a, st);
+            case 20: return a.x3 ? launch_splitk<128, 128, 2, 2, 2, 32, true>(a, st) : launch_splitk<128, 128, 2, 2, 2, 32, false>(a, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     if (a.x3) {
         if (tile >= 30 && tile < 50) return smap_launch_conv3(a, tile, st);     // halo-tiled 3x3, split-precision instance
         switch (tile) {                                     // LDS = max(STAGES * 2 * (BM + BN) * row bytes, fp32 epilogue tile)

@@ -36,6 +36,15 @@
 #ifndef SMAP_CONVB_LDS_KB
 #define SMAP_CONVB_LDS_KB 80     // LDS per workgroup (two per CU); experiments: 64
 #endif
+// 4 x 16 pixel tiles (tile ids 90, 92) need 148 VGPRs: a THIRD workgroup per CU (three waves per SIMD) fits the register file; it
+// fits the LDS at 52 KiB per workgroup (y1 32 KiB + a ring of two weight slots; four 12 KiB stages in phase 1).  Experiment of
+// round 5 (EXPERIMENTS R5.2): -DSMAP_CONVB_WGS4=3 -DSMAP_CONVB_LDS4_KB=52; the shipped build keeps 2 x 80 KiB.
+#ifndef SMAP_CONVB_WGS4
+#define SMAP_CONVB_WGS4 2
+#endif
+#ifndef SMAP_CONVB_LDS4_KB
+#define SMAP_CONVB_LDS4_KB SMAP_CONVB_LDS_KB
+#endif
 #ifndef SMAP_CONVB_ABLATE
 #define SMAP_CONVB_ABLATE 0      // diagnostics builds only (tools/build_ablate.py --convb N), identity kernel: 1 no x loads, 2 no MFMA,
 #endif                           // 4 no global stores, 8 no weight loads (W1 stages and the slot ring)
@@ -78,7 +87,7 @@ __device__ __forceinline__ f32x16 MFMA_(half8 x, half8 y, f32x16 c, int, int, in
 }
 
 template <int TH>
-__global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, int tiles_x, int tiles_y)
+__global__ __launch_bounds__(256, TH == 4 ? SMAP_CONVB_WGS4 : 2) void bottleneck_kernel(const ConvArgs a, int tiles_x, int tiles_y)
 {
     constexpr int P = 64, C = 4 * P, TW = 16, CH = 32, ROWB = 128;
     constexpr int PW = TW + 2, PH = TH + 2;
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
     constexpr int Y1_BYTES = KC2 * PROWS * ROWB;                // 32 | 48 KiB
     constexpr int Y2_BYTES = KC2 * BM * ROWB;                   // 16 | 32 KiB: y2 takes over the start of y1's region
     static_assert(Y2_BYTES + C * 4 <= Y1_BYTES && C == 256, "room for the tail-bias table; one bias value per thread");
-    constexpr int LDS_BYTES = SMAP_CONVB_LDS_KB * 1024;
+    constexpr int LDS_BYTES = (TH == 4 ? SMAP_CONVB_LDS4_KB : SMAP_CONVB_LDS_KB) * 1024;
     // phase 1 stages 16 channels at a time (64-byte rows [hi16 | lo16], one MFMA K step per stage): a 12 | 16 KiB stage, so that
     // 5 | 4 of them are in flight behind the one being multiplied -- x comes from HBM, and with 32-channel stages (3 | 2 of them in
     // 80 KiB) a workgroup waited a full memory latency per stage (profiles/r4_v2_*: 172 us per block)
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(const ConvArgs a, in
 }
 
 template <int TH>
-__global__ __launch_bounds__(256, 2) void bottleneck_first_kernel(const ConvArgs a, int tiles_x, int tiles_y)
+__global__ __launch_bounds__(256, TH == 4 ? SMAP_CONVB_WGS4 : 2) void bottleneck_first_kernel(const ConvArgs a, int tiles_x, int tiles_y)
 {
     constexpr int P = 64, C = 4 * P, TW = 16, CH = 32, ROWB = 128;
     constexpr int PW = TW + 2, PH = TH + 2;
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_first_kernel(const ConvArgs
     constexpr int Y1_BYTES = KC2 * PROWS * ROWB;                // 32 | 48 KiB
     constexpr int Y2_BYTES = KC2 * BM * ROWB;                   // 16 | 32 KiB: y2 takes over the start of y1's region
     static_assert(Y2_BYTES + C * 4 + P * 4 <= Y1_BYTES && C == 256, "room for the bias tables; one tail-bias value per thread");
-    constexpr int LDS_BYTES = SMAP_CONVB_LDS_KB * 1024;
+    constexpr int LDS_BYTES = (TH == 4 ? SMAP_CONVB_LDS4_KB : SMAP_CONVB_LDS_KB) * 1024;
     constexpr int SLOT = P * ROWB;                              // 8 KiB weight slot of phases 2 and 3: 64 rows x one 32-channel chunk
     constexpr int NS = (LDS_BYTES - Y1_BYTES) / SLOT;           // ring slots behind y1: 6 | 4
     constexpr int LS = SLOT / 4096;                             // 2 per thread

@@ -39,6 +39,10 @@ struct ConvArgs {
     float acc_scale0;
     const _Float16* wd;      // tile ids 92, 93: packed [n chunk][k chunk][64 rows][128 B] weights of the 1x1 SHORTCUT conv of a layer's first
     float acc_scale_d;       // block (head_cin -> tail_cout, no ReLU; its bias is folded into bias2), or null
+    // split K (smap_op.ksplit, conv.hip only): K parts per output tile, scratch for the raw partial tiles, one ticket per tile
+    int ksplit;
+    float* kpart;
+    unsigned* kcount;
     // N segments (smap_op.seg_*): rows >= seg_n1 / seg_n2 of the weight matrix belong to outputs 1 / 2 (INT_MAX = no such segment)
     int seg_n1, seg_n2;
     void* seg_out1; void* seg_out2;
@@ -72,6 +76,7 @@ __device__ __forceinline__ Lerp lerp_index(int dst, int in_size, int out_size)
     return r;
 }
 
+int smap_conv_tile_has_splitk(int tile);                                    // conv.hip: tile ids with a split-K instance
 int smap_conv_tile_has_x3(int tile);                                        // conv.hip: tile ids with a split-precision instance
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st);
 int smap_conv3_tile_dims(int tile, int* bm, int* bn);                       // conv3.hip (tile ids 30..33, halo-tiled 3x3)

@@ -547,6 +547,7 @@ inline int grid_for(long long total, int block)
 struct smap_plan {
     std::vector<smap_op> ops;
     std::vector<int64_t> windows;          // arena offsets of the zero pages this schedule's conv launches address through
+    int64_t kcount_lo = 0, kcount_hi = 0;  // arena byte range that holds the split-K tickets of every op (one contiguous region)
 };
 
 // ZERO PAGES and WINDOWS.  The conv kernels address their input with (64-bit uniform base in SGPRs) + (32-bit byte offset per
@@ -637,6 +638,15 @@ static int validate(const smap_op& o)
                     return SMAP_E_ARG;
             }
             if ((int64_t)o.cout_pad * o.ksize * o.ksize * o.Cin * 2 * (1 + o.precision) > ((int64_t)1 << 32)) return SMAP_E_ARG;
+            if (o.ksplit < 0 || o.ksplit > 16) return SMAP_E_ARG;
+            if (o.ksplit > 1) {                          // split K: conv.hip's tiles; scratch and tickets inside the arena, off the zero pages
+                const int bk = smap_conv_tile_bk(o.tile, o.precision);
+                if (!smap_conv_tile_has_splitk(o.tile) || bk <= 0 || o.ksplit > o.ksize * o.ksize * o.Cin / bk) return SMAP_E_ARG;
+                const int64_t tiles = (((int64_t)o.B * o.Ho * o.Wo + bm - 1) / bm) * (o.cout_pad / bn);
+                const int64_t pbytes = tiles * o.ksplit * bm * bn * 4, cbytes = tiles * 4;
+                if (o.kpart_off < SMAP_ZERO_PAGE || o.kcount_off < SMAP_ZERO_PAGE || o.kpart_off % 16 || o.kcount_off % 4) return SMAP_E_ARG;
+                if (hits_zero_page(o.kpart_off, pbytes) || hits_zero_page(o.kcount_off, cbytes)) return SMAP_E_ARG;
+            }
             if (o.seg_n[0] == 0 && o.seg_n[1] != 0) return SMAP_E_ARG;
             if (o.seg_n[0] != 0) {                       // N segments: conv.hip's tiles, 1x1, fp16 outputs; every segment starts on an N tile
                 const bool igemm = (o.tile >= 0 && o.tile < 30) || (o.tile >= 50 && o.tile < 60);
@@ -721,7 +731,16 @@ int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan)
             bool have = false;
             for (int64_t x : p->windows) have = have || x == w;
             if (!have) p->windows.push_back(w);
+            if (ops[i].ksplit > 1) {
+                int bm = 0, bn = 1;
+                smap_conv_tile_dims(ops[i].tile, &bm, &bn);
+                const int64_t tiles = (((int64_t)ops[i].B * ops[i].Ho * ops[i].Wo + bm - 1) / bm) * (ops[i].cout_pad / bn);
+                const int64_t lo = ops[i].kcount_off, hi = lo + tiles * 4;
+                if (p->kcount_hi == p->kcount_lo) { p->kcount_lo = lo; p->kcount_hi = hi; }
+                else { if (lo < p->kcount_lo) p->kcount_lo = lo; if (hi > p->kcount_hi) p->kcount_hi = hi; }
+            }
         }
+        if (p->kcount_hi - p->kcount_lo > (1 << 22)) { delete p; return SMAP_E_ARG; }      // tickets of one schedule live in ONE small region (the packer's contract)
     *plan = p;
     return 0;
 }
@@ -748,6 +767,8 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
     const bool have_input = n_inputs > 0 && inputs[0];
     for (int64_t w : plan->windows)
         if (hipError_t e = hipMemsetAsync(ar + w, 0, SMAP_ZERO_PAGE, st); e != hipSuccess) return hip_rc(e);
+    if (plan->kcount_hi > plan->kcount_lo)               // split-K tickets: zero before the first op (the kernels leave them at zero; an aborted run may not)
+        if (hipError_t e = hipMemsetAsync(ar + plan->kcount_lo, 0, (size_t)(plan->kcount_hi - plan->kcount_lo), st); e != hipSuccess) return hip_rc(e);
     for (int i = first; i < first + count; ++i)          // the status word (one per schedule) starts every run at 0
         if (plan->ops[i].kind == SMAP_OP_HEADSUM && plan->ops[i].status_off > 0 && out) {
             if (hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(out) + plan->ops[i].status_off, 0, 4 * (size_t)SMAP_STATUS_WORDS(plan->ops[i].B), st); e != hipSuccess) return hip_rc(e);
@@ -803,6 +824,9 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
                 a.acc_scale0 = o.head_acc_scale;
                 a.wd = o.head_cin > 0 && o.short_acc_scale > 0.f ? reinterpret_cast<const _Float16*>(wb + o.short_w_off) : nullptr;
                 a.acc_scale_d = o.short_acc_scale;
+                a.ksplit = o.ksplit > 1 ? o.ksplit : 1;
+                a.kpart = o.ksplit > 1 ? reinterpret_cast<float*>(ar + o.kpart_off) : nullptr;
+                a.kcount = o.ksplit > 1 ? reinterpret_cast<unsigned*>(ar + o.kcount_off) : nullptr;
                 a.seg_n1 = o.seg_n[0] > 0 ? o.seg_n[0] : INT32_MAX;
                 a.seg_n2 = o.seg_n[1] > 0 ? o.seg_n[1] : INT32_MAX;
                 a.seg_out1 = o.seg_n[0] > 0 ? ar + o.seg_out_off[0] : nullptr;
@@ -922,6 +946,13 @@ int smap_workspace_bytes(const smap_plan* plan, int64_t* arena_bytes, int64_t* o
                 up(ar, o.aux_off[0], (int64_t)o.B * o.aux_h[0] * o.aux_w[0] * c8 * 2 * pl);
                 for (int j = 0; j < 2; ++j)
                     if (o.seg_n[j] > 0) up(ar, o.seg_out_off[j], M * o.seg_out_stride_c[j] * 2);
+                if (o.ksplit > 1) {
+                    int bm = 0, bn = 1;
+                    smap_conv_tile_dims(o.tile, &bm, &bn);
+                    const int64_t tiles = ((M + bm - 1) / bm) * (o.cout_pad / bn);
+                    up(ar, o.kpart_off, tiles * o.ksplit * bm * bn * 4);
+                    up(ar, o.kcount_off, tiles * 4);
+                }
                 break;
             }
             case SMAP_OP_STEM: case SMAP_OP_STEMPOOL: up(ar, o.out_off, M * 64 * 2 * pl); break;

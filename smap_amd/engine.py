@@ -86,6 +86,7 @@ ALIGN = 256
 ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
 WINDOW = 1 << 32              # csrc/plan.hip SMAP_WINDOW: bytes [k * WINDOW, k * WINDOW + ZERO_PAGE) of the arena are reserved
 PRECISIONS = ("f16", "x3")
+SPLITK_TILES = (2, 20, 22)     # csrc/conv.hip tiles with a split-K instance (smap_conv_tile_has_splitk)
 X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 60, 61, 62, 63, 64, 65)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
 
 
@@ -320,6 +321,7 @@ class Op:
     aux: list = field(default_factory=list)
     p: dict = field(default_factory=dict)
     outs: list = field(default_factory=list)      # further output tensors (N segments 1, 2 of a merged 1x1 launch)
+    scratch: list = field(default_factory=list)   # arena scratch that lives for this op only (split K: the partial tiles)
 
 
 def pick_tile_heuristic(M, cout):
@@ -414,6 +416,7 @@ class Graph:
         self.sd, self.B, self.H, self.W = sd, B, H, W
         self.w_pairs = use_w_pairs(B, H, W)                  # layout of the packed 32-half weight tiles (whole schedule)
         self.ops, self.tensors = [], []
+        self.scratch_tensors, self.kcount, self.kcount_tiles = [], None, 0      # split K: partial-tile scratch per op, one ticket region per schedule
         self.wchunks, self.woff = [], 0
         self.stage_num, self.chl, self.kpt_paf, self.paf = stage_num, chl, kpt_paf, paf
         self.flops = 0
@@ -425,6 +428,39 @@ class Graph:
         t = Tensor(name, self.B, H, W, C, esize, 2 if (self.x3 and esize == 2) else 1)
         self.tensors.append(t)
         return t
+
+    def split_k(self, tile, M, cout_pad, K):
+        """K parts per output tile for a conv.hip launch of this shape (include/smap_hip.h smap_op.ksplit), or 1.  Small schedules only
+        (batch 1: configs[1]): a launch with fewer output tiles than half the CUs whose K loop is long enough to share out -- the 32x52
+        and 16x26 levels run 26-104 workgroups of 16-72 K tiles each there.  SMAP_SPLITK=0 switches it off, SMAP_SPLITK=<n> forces n
+        parts wherever the tile allows."""
+        env = os.environ.get("SMAP_SPLITK", "")
+        if env == "0" or tile not in SPLITK_TILES:
+            return 1
+        bm, bn = TILES[tile]
+        tiles = -(-M // bm) * (cout_pad // bn)
+        n_k = K // tile_bk(tile, self.x3)
+        if env and env != "1":
+            return max(1, min(int(env), 16, n_k))
+        if tiles >= 128 or n_k < 8:
+            return 1
+        s = min(8, 256 // tiles, n_k // 4)
+        return s if s >= 2 else 1
+
+    def _split_k_fields(self, name, tile, M, cout_pad, ks):
+        """Scratch tensor + ticket slice of a split-K op -> (dict for Op.p, [scratch tensor])."""
+        if ks <= 1:
+            return {}, []
+        bm, bn = TILES[tile]
+        tiles = -(-M // bm) * (cout_pad // bn)
+        part = Tensor(name + ".kpart", 1, 1, 1, tiles * ks * bm * bn, 4, 1)
+        self.scratch_tensors.append(part)
+        if self.kcount is None:
+            self.kcount = Tensor("split_k.tickets", 1, 1, 1, 0, 4, 1)
+        first_ticket = self.kcount_tiles
+        self.kcount_tiles += tiles
+        self.kcount.C = self.kcount_tiles
+        return dict(ksplit=ks, kcount_first=first_ticket), [part]
 
     def _add_w(self, t):
         t = t.contiguous()
@@ -492,8 +528,9 @@ class Graph:
               + wk.numel() * 2 + sum(t.nbytes * nfr // self.B for t in (res, add1, add2, up) if t is not None))
         self.flops += fl
         self.alg_bytes += by
-        self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, aux=[up] if up is not None else [], p=dict(
-            flops=fl, alg_bytes=by, kinds="1x1" if ksize == 1 else "3x3",
+        skf, scratch = self._split_k_fields(name, tile, M, cout_pad, self.split_k(tile, M, cout_pad, K))
+        self.ops.append(Op(OP_CONV, out=out, inp=x, res=res, add1=add1, add2=add2, aux=[up] if up is not None else [], scratch=scratch, p=dict(
+            flops=fl, alg_bytes=by, kinds="1x1" if ksize == 1 else "3x3", **skf,
             Cin=cin, in_c_off=in_c_off, Cout=cout, ksize=ksize, stride=stride, pad=pad, relu=int(relu),
             cout_pad=cout_pad, tile=tile, out_fp32=int(out_fp32), w_off=self._add_w(wk), bias_off=self._add_w(bk),
             acc_scale=acc_scale, frames=nfr, w_pairs=w_pairs,
@@ -559,8 +596,9 @@ class Graph:
         self.flops += fl
         self.alg_bytes += by
         keep = self.keep_ref
-        self.ops.append(Op(OP_CONV, out=outs[0], inp=x, aux=[up] if up is not None else [], outs=outs[1:], p=dict(
-            flops=fl, alg_bytes=by, kinds="1x1",
+        skf, scratch = self._split_k_fields(segs[0][0], tile, M, cout_pad, self.split_k(tile, M, cout_pad, cin))
+        self.ops.append(Op(OP_CONV, out=outs[0], inp=x, aux=[up] if up is not None else [], outs=outs[1:], scratch=scratch, p=dict(
+            flops=fl, alg_bytes=by, kinds="1x1", **skf,
             Cin=cin, in_c_off=0, Cout=couts[0], ksize=1, stride=1, pad=0, relu=int(segs[0][2]), cout_pad=cout_pad, tile=tile, out_fp32=0,
             w_off=self._add_w(wk), bias_off=self._add_w(bk), acc_scale=scales[0], frames=self.B, w_pairs=self.w_pairs,
             segs=[dict(n0=st, cout=c, relu=int(r), acc_scale=sc, w_ref=w if keep else None, b_ref=b if keep else None)
@@ -881,18 +919,23 @@ class Graph:
             for t in ([op.out] if op.out is not None else []) + list(op.outs):
                 t.first = i
                 t.last = max(t.last, i)
+            for t in op.scratch:
+                t.first = t.last = i
+        if self.kcount is not None:                                # the tickets of every split-K op: one region, alive for the whole schedule
+            self.kcount.first, self.kcount.last = 0, len(self.ops) - 1
+        every = self.tensors + self.scratch_tensors + ([self.kcount] if self.kcount is not None else [])
         # arena[k * WINDOW : k * WINDOW + ZERO_PAGE] are the conv kernels' zero pages (csrc/plan.hip): never allocated, so no
         # tensor crosses a window boundary and every conv input is within 32 bits of its window's base
         free, top = [], ZERO_PAGE    # free: list of (off, size)
-        for t in self.tensors:
+        for t in every:
             if _rup(t.nbytes, ALIGN) > WINDOW - ZERO_PAGE:
                 raise ArenaTooLarge(f"{t.name}: {t.nbytes / 2 ** 30:.2f} GiB ({self.B} frames, precision {self.precision}) does not fit a "
                                     "4 GiB addressing window of the conv kernels -- use a smaller batch (PosePipeline splits by itself)")
         by_first = {}
-        for t in self.tensors:
+        for t in every:
             by_first.setdefault(t.first, []).append(t)
         expiring = {}
-        for t in self.tensors:
+        for t in every:
             expiring.setdefault(t.last, []).append(t)
         for i in range(len(self.ops)):
             for t in by_first.get(i, []):
@@ -927,7 +970,7 @@ class Graph:
                             merged.append((o, sz))
                     free = merged
         self.arena_bytes = max(top, ALIGN)
-        for t in self.tensors:
+        for t in every:
             if t.off >= 0:
                 assert t.off % WINDOW >= ZERO_PAGE and t.off // WINDOW == (t.off + t.nbytes - 1) // WINDOW, t.name
         return self.arena_bytes
@@ -974,6 +1017,8 @@ class Graph:
                     t = op.aux[0]
                     assert t.C == y.C and t.esize == 2
                     o.aux_off[0], o.aux_h[0], o.aux_w[0] = t.off, t.H, t.W
+                if p.get("ksplit", 1) > 1:
+                    o.ksplit, o.kpart_off, o.kcount_off = p["ksplit"], op.scratch[0].off, self.kcount.off + 4 * p["kcount_first"]
                 for j, (sg, t) in enumerate(zip(p.get("segs", []), op.outs)):
                     assert (t.H, t.W, t.C) == (y.H, y.W, sg["cout"]) and t.esize == 2
                     o.seg_n[j], o.seg_cout[j], o.seg_relu[j], o.seg_acc_scale[j] = sg["n0"], sg["cout"], sg["relu"], sg["acc_scale"]

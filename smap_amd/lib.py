@@ -46,6 +46,7 @@ class SmapOp(C.Structure):
         ("short_w_off", C.c_int64), ("short_acc_scale", C.c_float), ("reserved0", C.c_int32),
         ("seg_n", C.c_int32 * 2), ("seg_cout", C.c_int32 * 2), ("seg_relu", C.c_int32 * 2), ("seg_out_stride_c", C.c_int32 * 2),
         ("seg_acc_scale", C.c_float * 2), ("seg_out_off", C.c_int64 * 2),
+        ("ksplit", C.c_int32), ("reserved1", C.c_int32), ("kpart_off", C.c_int64), ("kcount_off", C.c_int64),
     ]
 
 

@@ -772,6 +772,61 @@ def test_small_schedule_merged_shared_input_launches(golden_dir, small, monkeypa
         assert np.abs(a.numpy() - z[k]).max() < (2e-5 if precision == "x3" else 1e-2) * np.abs(z[k]).max(), k
 
 
+@pytest.mark.parametrize("precision,tol", [("x3", 2e-5), ("f16", 2e-2)])
+@pytest.mark.parametrize("splitk,x3tile", [("", None), ("0", None), ("3", None), ("3", "2"), ("16", "20")],
+                         ids=["rule", "off", "three_parts", "three_parts_tile2", "sixteen_parts_tile20"])
+def test_small_schedule_split_k_launches(golden_dir, small, monkeypatch, splitk, x3tile, precision, tol):
+    """Split K (include/smap_hip.h smap_op.ksplit): S workgroups per output tile, each over 1/S of the K tiles, partial tiles summed in
+    a fixed order by the last one to arrive -- what the batch-1 schedule runs on its 32x52 / 16x26 levels.  The small schedule has
+    few output tiles everywhere, so the engine's rule splits most of its launches (1x1, 3x3, strided, residual / skip-add epilogues,
+    fused bilinear add, merged multi-output launches); forced to 3 parts (K tiles do not divide evenly) and to the maximum: every
+    tensor against the torch interpretation, outputs against the imported reference, and two runs bit for bit."""
+    from smap_amd.engine import BackboneEngine, Graph
+    from oracle.graph_interp import run_graph
+    _, sd = small
+    if splitk:
+        monkeypatch.setenv("SMAP_SPLITK", splitk)
+    if x3tile:
+        if precision != "x3":
+            pytest.skip("SMAP_X3_TILE forces split-precision tiles")
+        monkeypatch.setenv("SMAP_X3_TILE", x3tile)       # the other two tiles with a split-K instance (2: what batch 1 at 512x832 runs)
+    monkeypatch.setenv("SMAP_BLOCK", "")                 # layer by layer: more launches of the kernel under test
+    monkeypatch.setenv("SMAP_BLOCK_FIRST", "")
+    z = np.load(f"{golden_dir}/backbone_small.npz")
+    x = torch.from_numpy(z["x"])
+    eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=True, precision=precision)
+    n_split = sum(1 for op in eng.graph.ops if op.p.get("ksplit", 1) > 1)
+    assert (n_split == 0) if splitk == "0" else (n_split >= 30), n_split
+    if splitk in ("3", "16"):
+        assert max(op.p.get("ksplit", 1) for op in eng.graph.ops) == int(splitk)
+    if x3tile:
+        assert sum(1 for op in eng.graph.ops if op.p.get("ksplit", 1) > 1 and op.p["tile"] == int(x3tile)) >= 30
+    runs = []
+    for _ in range(3):
+        out = eng.new_output()
+        eng.run(x.to(DEV), out=out)
+        torch.cuda.synchronize()
+        runs.append(out.cpu())
+    assert torch.equal(runs[0].view(torch.int32), runs[1].view(torch.int32)) and torch.equal(runs[0].view(torch.int32), runs[2].view(torch.int32))
+    eng2 = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision=precision)
+    outs = [o.cpu() for o in eng2.run(x.to(DEV))]
+    torch.cuda.synchronize()
+    g = Graph(sd, 2, 64, 96, keep_ref=True, precision=precision)
+    with torch.no_grad():
+        *ref, T = run_graph(g, x.double() if precision == "x3" else x, quantize=precision == "f16", keep=True)
+    worst = []
+    for t in eng2.graph.tensors:
+        got = eng2.read_tensor(t.name).cpu().double().permute(0, 3, 1, 2)
+        want = T[t.name].double()
+        e = (got[:, :want.shape[1]] - want).abs().max().item()
+        worst.append((e / (want.abs().max().item() + 1e-6), t.name))
+    worst.sort(reverse=True)
+    assert worst[0][0] < tol, worst[:5]
+    for a, k in zip(outs, ("hms", "det_d", "root_d")):
+        assert np.abs(a.numpy() - z[k]).max() < (2e-5 if precision == "x3" else 1e-2) * np.abs(z[k]).max(), k
+    assert torch.equal(torch.cat([o.reshape(-1) for o in outs]), runs[0][:sum(o.numel() for o in outs)])     # reuse=True arena: same bits
+
+
 SEG_CASES = [   # B, H, W, Cin, couts, relus, up (low-res size or None), tile
     (2, 13, 21, 256, (256, 64), (1, 1), None, 20),
     (2, 13, 21, 256, (256, 64, 256), (1, 1, 0), None, 21),
