@@ -815,18 +815,25 @@ class Graph:
         # Upsample_module (smap.py:244-286): up1 on x4 ... up4 on x1
         out, s1, s2, cross = None, [None] * 4, [None] * 4, None
         head_t = {}
-        merge = os.environ.get("SMAP_MERGE_1X1", "1") != "0"     # shared-input 1x1s of an Upsample_unit as one launch (A/B hook: "0" = one launch each)
+        # Shared-input 1x1s of an Upsample_unit as ONE launch with one output per conv (conv_seg).  Measured (profiles/r5_v1_*): the
+        # launches on `out` (skip2 | cross_conv | res_conv1 | the next unit's up_conv) are 3-33 % faster merged than one by one at every
+        # level; u_skip | skip1 on x is faster merged where u_skip has no fused bilinear add (up1: 228 vs 244 us at 16 frames) and SLOWER
+        # where it has one (128x208: 712 vs 610 us; 32x52: 277 vs 256): the wide skip1 half then runs under the bilinear epilogue's
+        # register budget.  SMAP_MERGE_1X1: "1" (default) = the merges that pay, "2" = all of them, "0" = one launch per conv.
+        merge_mode = os.environ.get("SMAP_MERGE_1X1", "1")
+        merge = merge_mode != "0"
         tl = None                                                 # up_conv@low of the unit at hand (a segment of the previous unit's launch on `out`)
         for ind, xin in enumerate((x4, x3, x2, x1)):
             u = f"{pre}upsample.up{ind + 1}"
             un = f"{pre}upsample.up{ind + 2}"                     # the next unit: its up_conv reads this unit's `out` (commuted with the upsample)
             if merge:
                 # launch 1, on x:   out = relu(u_skip(x) [+ bilinear(up_conv@low)])  |  skip1 = relu(skip1(x))
-                if gen_skip:
-                    lvl = 3 - ind
-                    out, s1[lvl] = self.conv_seg([(u + ".out", u + ".u_skip", True), (u + ".skip1", u + ".skip1", True)], xin, up=tl)
+                if gen_skip and (tl is None or merge_mode == "2"):
+                    out, s1[3 - ind] = self.conv_seg([(u + ".out", u + ".u_skip", True), (u + ".skip1", u + ".skip1", True)], xin, up=tl)
                 else:
                     out = self.conv(u + ".out", [u + ".u_skip"], xin, relu=True, up=tl)
+                    if gen_skip:
+                        s1[3 - ind] = self.conv(u + ".skip1", [u + ".skip1"], xin, relu=True)
                 # launch 2, on out: skip2 | cross_conv (stages with skips), res_conv1 (last stage), the next unit's up_conv@low
                 sg = []
                 if gen_skip:

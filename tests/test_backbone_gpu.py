@@ -742,7 +742,7 @@ def test_small_schedule_split_precision_every_tensor(golden_dir, small, monkeypa
 
 
 @pytest.mark.parametrize("precision,tol", [("x3", 2e-5), ("f16", 2e-2)])
-@pytest.mark.parametrize("merge", ["1", "0"], ids=["merged_1x1", "one_launch_each"])
+@pytest.mark.parametrize("merge", ["1", "2", "0"], ids=["merged_1x1", "all_merges", "one_launch_each"])
 def test_small_schedule_merged_shared_input_launches(golden_dir, small, monkeypatch, merge, precision, tol):
     """The shared-input 1x1 convs of every Upsample_unit (smap.py:210-241: u_skip | skip1 on x; skip2 | cross_conv | res_conv1 | the
     next unit's up_conv on `out`) as ONE launch with one output tensor per conv (smap_op.seg_*) -- and, SMAP_MERGE_1X1=0, as one
@@ -754,7 +754,7 @@ def test_small_schedule_merged_shared_input_launches(golden_dir, small, monkeypa
     z = np.load(f"{golden_dir}/backbone_small.npz")
     x = torch.from_numpy(z["x"])
     eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision=precision)
-    assert sum(len(op.outs) for op in eng.graph.ops) == (18 if merge == "1" else 0)
+    assert sum(len(op.outs) for op in eng.graph.ops) == {"2": 18, "1": 12, "0": 0}[merge]
     outs = [o.cpu() for o in eng.run(x.to(DEV))]
     torch.cuda.synchronize()
     g = Graph(sd, 2, 64, 96, keep_ref=True, precision=precision)

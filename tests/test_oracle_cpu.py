@@ -191,7 +191,7 @@ def test_backbone_ref_matches_reference_at_full_size(golden_dir):
     print("full-size oracle vs imported reference (sampled, channel sums):", worst)
 
 
-@pytest.mark.parametrize("merge", ["1", "0"])
+@pytest.mark.parametrize("merge", ["1", "2", "0"])
 def test_schedule_wiring_matches_reference_golden(golden_dir, small_model, monkeypatch, merge):
     """The engine's op list, interpreted in fp32 on CPU, reproduces the reference outputs:
     folding, dead-head removal, commuted up_conv, merged heads, epilogue skip adds -- with the shared-input 1x1s of every
@@ -203,9 +203,10 @@ def test_schedule_wiring_matches_reference_golden(golden_dir, small_model, monke
     monkeypatch.setenv("SMAP_MERGE_1X1", merge)
     g = Graph(sd, 2, 64, 96, keep_ref=True)
     g.allocate()
-    # 203 convs + stem + maxpool + 3 head sums; merged: 2 launches fewer per Upsample_unit of stages 0 / 1, 1 fewer for up2 / up3 of stage 2
-    assert len(g.ops) == (208 - 18 if merge == "1" else 208)
-    assert sum(len(op.outs) for op in g.ops) == (18 if merge == "1" else 0)
+    # 203 convs + stem + maxpool + 3 head sums; "2" (every shared-input pair): 2 launches fewer per Upsample_unit of stages 0 / 1, 1 fewer
+    # for up2 / up3 of stage 2; "1" (default: the merges that measured faster) keeps u_skip | skip1 apart where u_skip has the bilinear add
+    saved = {"2": 18, "1": 12, "0": 0}[merge]
+    assert len(g.ops) == 208 - saved and sum(len(op.outs) for op in g.ops) == saved
     with torch.no_grad():
         outs = run_graph(g, torch.from_numpy(z["x"]), quantize=False)
         outs_q = run_graph(g, torch.from_numpy(z["x"]), quantize=True)
