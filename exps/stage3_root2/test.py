@@ -52,20 +52,50 @@ def get_logger(name, log_dir, filename):
 
 class DevicePreprocLoader:
     """Batches of (imgs on the device, names, scales) with decode on the host and resize / pad /
-    normalise in one HIP kernel per image (smap_amd/preprocess.py)."""
+    normalise in one HIP kernel per image (smap_amd/preprocess.py).  The decodes run AHEAD of the consumer on a small thread pool
+    (PIL's decoders and numpy's file reads release the GIL): at ~800 frames/s of engine, one thread decoding a 1080p JPEG in ~10 ms
+    would be the whole run (profiles/r5_cli_e2e.json).  SMAP_DECODE_THREADS (default: up to 8 of the allowed CPUs; 1 = decode in
+    the consumer's thread, the round-4 behaviour)."""
 
     def __init__(self, dataset, indices, batch_size, cfg, device):
         self.ds, self.idx, self.bs, self.cfg, self.device = dataset, list(indices), batch_size, cfg, device
+        try:
+            allowed = len(os.sched_getaffinity(0))
+        except AttributeError:
+            allowed = os.cpu_count() or 1
+        self.threads = int(os.environ.get("SMAP_DECODE_THREADS", "0")) or max(1, min(8, allowed))
 
     def __len__(self):
         return (len(self.idx) + self.bs - 1) // self.bs
 
     def __iter__(self):
         from smap_amd.preprocess import preprocess_batch
-        for s in range(0, len(self.idx), self.bs):
-            raws, names = zip(*[self.ds.raw(i) for i in self.idx[s:s + self.bs]])
-            imgs, scales = preprocess_batch(raws, self.cfg.INPUT.MEANS, self.cfg.INPUT.STDS, self.device)
-            yield imgs, list(names), scales
+        if self.threads <= 1:
+            for s in range(0, len(self.idx), self.bs):
+                raws, names = zip(*[self.ds.raw(i) for i in self.idx[s:s + self.bs]])
+                imgs, scales = preprocess_batch(raws, self.cfg.INPUT.MEANS, self.cfg.INPUT.STDS, self.device)
+                yield imgs, list(names), scales
+            return
+        import collections
+        from concurrent.futures import ThreadPoolExecutor
+        ahead = max(2 * self.threads, 3 * self.bs)           # images being decoded or waiting: bounds the host memory (~6 MB per 1080p frame)
+        with ThreadPoolExecutor(self.threads) as ex:
+            todo, futs = iter(self.idx), collections.deque()
+
+            def fill():
+                while len(futs) < ahead:
+                    try:
+                        futs.append(ex.submit(self.ds.raw, next(todo)))
+                    except StopIteration:
+                        return
+            fill()
+            while futs:
+                n = min(self.bs, len(futs))
+                got = [futs.popleft().result() for _ in range(n)]       # in submission order: frame order is kept
+                fill()
+                raws, names = zip(*got)
+                imgs, scales = preprocess_batch(raws, self.cfg.INPUT.MEANS, self.cfg.INPUT.STDS, self.device)
+                yield imgs, list(names), scales
 
 
 class _DryRunPipeline:
@@ -122,7 +152,17 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
         drain(p.flush())
         dropped.extend(getattr(p, "dropped_frames", []))
 
-    for batch in it:
+    import time
+    clock = {"loader_s": 0.0, "submit_s": 0.0, "frames": 0, "t0": time.perf_counter()}     # where the host's time goes (SMAP_CLI_TIMING)
+    batches = iter(it)
+    while True:
+        t_ = time.perf_counter()
+        try:
+            batch = next(batches)
+        except StopIteration:
+            break
+        clock["loader_s"] += time.perf_counter() - t_
+        t_sub = time.perf_counter()
         annotations = None
         if cfg.TEST_MODE == "run_inference":
             imgs, img_path, scales = batch
@@ -148,8 +188,23 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
                                 depth=int(os.environ.get("SMAP_PIPELINE_DEPTH", 2)))   # two backbones in flight (+19 %)
         with torch.no_grad():
             drain(pipe.submit(imgs, cams, list(img_path), annotations=annotations))
+        clock["submit_s"] += time.perf_counter() - t_sub
+        if "first_submit_s" not in clock:                        # builds the engine (schedule, weight packing, plan, arenas): seconds, once
+            clock["first_submit_s"] = time.perf_counter() - t_sub
+        clock["frames"] += sum(1 for p_ in img_path if p_ is not None)
+    t_ = time.perf_counter()
     if pipe is not None:
         retire(pipe)
+    clock["flush_s"] = time.perf_counter() - t_
+    clock["loop_s"] = time.perf_counter() - clock.pop("t0")
+    if os.environ.get("SMAP_CLI_TIMING") and rank == 0:
+        # steady-state split of the run_inference loop: loader_s = waiting for the next batch (decode [+ host resize] + H2D + GPU
+        # pre-processing enqueue), submit_s = enqueue + back-pressure of the pipeline + record building, flush_s = draining the tail
+        steady = clock["loop_s"] - clock.get("first_submit_s", 0.0)
+        clock.update(frames_per_s=clock["frames"] / clock["loop_s"] if clock["loop_s"] > 0 else None,
+                     frames_per_s_after_engine_build=clock["frames"] / steady if steady > 0 else None, wait_gpu_s=getattr(pipe, "wait_s", None))
+        with open(os.environ["SMAP_CLI_TIMING"], "w") as f:
+            json.dump(clock, f)
     if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SMAP_FORCE_GATHER", "") == "1"):
         parts = gather_records(result["3d_pairs"], device)
         result["3d_pairs"] = [r for part in parts for r in part]                # rank order == frame order

@@ -45,4 +45,49 @@ db=$(find $R/$O/prof_d1 -name "*.db" | head -1); (cd $R; SMAP_TILE_TABLE_X3=$R/$
 tail -25 $R/$O/layers_d1.txt
 }
 
+v2() {
+# visit 2: split-K / merge tests; merge policy A/B (0 = one launch per conv, 1 = the merges that pay, 2 = all); the 4x16 whole-block
+# tiles with THREE workgroups per CU (diagnostics build) against the shipped 8x16 tiles; batch 1: split K off / rule / forced, graph form,
+# per-layer trace; the shipped CLI end to end on a generated image folder
+O=gpurun_out/r5v2; mkdir -p $O
+timeout 900 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "split_k or merged" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -6 $O/pytest.log
+for rep in 1 2; do
+  for m in 0 1 2; do
+    SMAP_MERGE_1X1=$m SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep merge=$m" >> $O/ab_merge.log
+  done
+done
+cat $O/ab_merge.log
+V3=$R/smap_amd/csrc/obj/libsmap_hip_convb_convb_wgs43_convb_lds4_kb52.so
+for rep in 1 2; do
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep 8x16 tiles (shipped)" >> $O/ab_convb.log
+  SMAP_BLOCK="64:90,128:94" SMAP_BLOCK_FIRST="64:92" SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep 4x16 tiles, 2 workgroups per CU" >> $O/ab_convb.log
+  SMAP_HIP_LIB=$V3 SMAP_BLOCK="64:90,128:94" SMAP_BLOCK_FIRST="64:92" SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep 4x16 tiles, 3 workgroups per CU" >> $O/ab_convb.log
+done
+SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 --launch-frames 0 2>>$O/ab.err | line "depth1 lf0 8x16 tiles (shipped)" >> $O/ab_convb.log
+SMAP_HIP_LIB=$V3 SMAP_BLOCK="64:90,128:94" SMAP_BLOCK_FIRST="64:92" SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 --launch-frames 0 2>>$O/ab.err | line "depth1 lf0 4x16 tiles, 3 workgroups per CU" >> $O/ab_convb.log
+cat $O/ab_convb.log
+b1() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$1', round(d['value'],1),'fps', round(d['ms_per_step'],3),'ms/frame', d['config']['launch'])
+"; }
+for sk in 0 1 2 4 8; do
+  SMAP_SPLITK=$sk timeout 300 python bench.py --forward-only --batch 1 --steps 300 --warmup 30 2>>$O/ab.err | b1 "b1 SMAP_SPLITK=$sk" >> $O/ab_b1.log
+done
+SMAP_SPLITK=0 timeout 300 python bench.py --forward-only --batch 1 --steps 300 --warmup 30 --graph 2>>$O/ab.err | b1 "b1 SMAP_SPLITK=0 graph" >> $O/ab_b1.log
+timeout 300 python bench.py --forward-only --batch 1 --steps 300 --warmup 30 --graph 2>>$O/ab.err | b1 "b1 rule graph" >> $O/ab_b1.log
+SMAP_MERGE_1X1=0 SMAP_SPLITK=0 timeout 300 python bench.py --forward-only --batch 1 --steps 300 --warmup 30 2>>$O/ab.err | b1 "b1 round-4 schedule (no merges, no split K)" >> $O/ab_b1.log
+cat $O/ab_b1.log
+cd /tmp
+for sk in 0 1; do
+  SMAP_SPLITK=$sk SMAP_PRECISION=x3 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $R/$O/prof_b1_$sk -o smap -- python $R/bench.py --forward-only --batch 1 --steps 20 --warmup 5 > $R/$O/rocprof_b1_$sk.log 2>&1
+  db=$(find $R/$O/prof_b1_$sk -name "*.db" | head -1); (cd $R; SMAP_SPLITK=$sk SMAP_PRECISION=x3 python tools/prof_layers.py $db 1 > $O/layers_b1_splitk$sk.txt 2>&1); rm -rf $R/$O/prof_b1_$sk
+  tail -22 $R/$O/layers_b1_splitk$sk.txt
+done
+cd $R
+timeout 1500 python tools/cli_e2e.py --images 256 --out $R/$O/cli_e2e.json > $O/cli_e2e.log 2>&1; tail -8 $O/cli_e2e.log
+}
+
 "v$1"
