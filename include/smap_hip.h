@@ -237,6 +237,14 @@ typedef struct smap_op {
        0 or 1 = off.  S <= 16 and S <= the number of K tiles (K / smap_conv_tile_bk). */
     int32_t ksplit, reserved1;
     int64_t kpart_off, kcount_off;
+    /* LANES (smap_plan_set_lanes): independent branches of the schedule -- the head chains of an Upsample_unit (model/smap.py:219-229)
+       next to the unit that follows -- may run on forked streams.  lane = 0 (the caller's stream) .. SMAP_MAX_LANES - 1; wait_op = indices
+       of EARLIER ops on OTHER lanes whose results this op reads (-1 = unused; n_wait of them).  smap_plan_run makes the op's stream wait
+       for those ops and joins every lane into the caller's stream at the end; inside a stream capture the lanes become parallel branches
+       of the graph.  With lanes off (the default) every op runs on the caller's stream in order and the fields are ignored.  The packer
+       guarantees that buffers touched by an op on a side lane are not reused before the end of the schedule. */
+    int32_t lane, n_wait;
+    int32_t wait_op[4];
 } smap_op;
 
 #define SMAP_STATUS_WORDS(frames) (((frames) + 30) / 31)      /* int32 status words of a schedule with `frames` output frames */
@@ -252,6 +260,7 @@ int smap_conv_tile_bk(int tile, int precision);
 int smap_conv_tile_tail_bn(int tile);
 
 typedef struct smap_plan smap_plan;
+#define SMAP_MAX_LANES 4
 
 /* Copies `ops`; validates geometry.  n_ops <= 4096.  Arena contract: the conv kernels address their input with a 64-bit
  * base (the input's WINDOW: its arena offset rounded down to a multiple of 4 GiB) plus 32-bit lane offsets, and read zeros
@@ -272,6 +281,9 @@ int smap_plan_run(const smap_plan* plan, const float* input, void* arena, const 
 #define SMAP_MAX_INPUTS 8
 int smap_plan_run_inputs(const smap_plan* plan, const float* const* inputs, int n_inputs, void* arena,
                          const void* weights, float* out, void* stream);
+/* Lanes on (1) / off (0, the default): see smap_op.lane.  Side streams and events are created on the device that is current at the first
+ * run after switching them on, and destroyed with the plan. */
+int smap_plan_set_lanes(smap_plan* plan, int on);
 /* Bytes of arena and of output buffer the schedule touches, computed from the ops (either pointer may be NULL). */
 int smap_workspace_bytes(const smap_plan* plan, int64_t* arena_bytes, int64_t* out_bytes);
 

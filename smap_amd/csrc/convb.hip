@@ -45,6 +45,22 @@
 #ifndef SMAP_CONVB_LDS4_KB
 #define SMAP_CONVB_LDS4_KB SMAP_CONVB_LDS_KB
 #endif
+// Experiment (EXPERIMENTS R5.2): the two workgroups that share a CU start together and walk through their phases (x streaming, 3x3
+// multiplying, tail + stores) in step, so neither fills the other's gaps.  -DSMAP_CONVB_STAGGER_US=<n>: the second half of the FIRST
+// wave of workgroups (ids 256 .. 511: the ones that take the CUs' second slots) starts n microseconds late; later workgroups inherit the
+// offset, since a slot's next workgroup starts when its predecessor ends.  0 = off (shipped).
+#ifndef SMAP_CONVB_STAGGER_US
+#define SMAP_CONVB_STAGGER_US 0
+#endif
+__device__ __forceinline__ void convb_stagger()
+{
+#if SMAP_CONVB_STAGGER_US > 0
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+        const long long t0 = __builtin_amdgcn_s_memrealtime();             // 100 MHz
+        while (__builtin_amdgcn_s_memrealtime() - t0 < 100LL * SMAP_CONVB_STAGGER_US) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
+}
 #ifndef SMAP_CONVB_ABLATE
 #define SMAP_CONVB_ABLATE 0      // diagnostics builds only (tools/build_ablate.py --convb N), identity kernel: 1 no x loads, 2 no MFMA,
 #endif                           // 4 no global stores, 8 no weight loads (W1 stages and the slot ring)
@@ -118,6 +134,7 @@ __global__ __launch_bounds__(256, TH == 4 ? SMAP_CONVB_WGS4 : 2) void bottleneck
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];   // ONE array: a second __shared__ object makes hipcc drain vmcnt
 
     SMAP_TL_BEGIN
+    convb_stagger();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef SMAP_TRACE
@@ -547,6 +564,7 @@ __global__ __launch_bounds__(256, TH == 4 ? SMAP_CONVB_WGS4 : 2) void bottleneck
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];   // ONE array: a second __shared__ object makes hipcc drain vmcnt
 
     SMAP_TL_BEGIN
+    convb_stagger();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef SMAP_TRACE

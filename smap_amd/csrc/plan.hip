@@ -548,6 +548,13 @@ struct smap_plan {
     std::vector<smap_op> ops;
     std::vector<int64_t> windows;          // arena offsets of the zero pages this schedule's conv launches address through
     int64_t kcount_lo = 0, kcount_hi = 0;  // arena byte range that holds the split-K tickets of every op (one contiguous region)
+    // lanes (smap_op.lane): side streams 1 .. SMAP_MAX_LANES - 1 and one event per op some other lane waits for; created on first use
+    bool lanes_on = false, lanes_ready = false;
+    int n_lanes = 1;
+    hipStream_t side[SMAP_MAX_LANES] = {};
+    std::vector<hipEvent_t> ev;            // per op, null unless signalled
+    std::vector<char> signalled;
+    hipEvent_t join_ev[SMAP_MAX_LANES] = {};
 };
 
 // ZERO PAGES and WINDOWS.  The conv kernels address their input with (64-bit uniform base in SGPRs) + (32-bit byte offset per
@@ -724,6 +731,17 @@ int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan)
     smap_plan* p = new (std::nothrow) smap_plan();
     if (!p) return SMAP_E_ARG;
     p->ops.assign(ops, ops + n_ops);
+    p->signalled.assign(n_ops, 0);
+    for (int i = 0; i < n_ops; ++i) {                    // lanes: every wait names an EARLIER op of ANOTHER lane
+        const smap_op& o = ops[i];
+        if (o.lane < 0 || o.lane >= SMAP_MAX_LANES || o.n_wait < 0 || o.n_wait > 4) { delete p; return SMAP_E_ARG; }
+        if (o.lane + 1 > p->n_lanes) p->n_lanes = o.lane + 1;
+        for (int k = 0; k < o.n_wait; ++k) {
+            const int w = o.wait_op[k];
+            if (w < 0 || w >= i || ops[w].lane == o.lane) { delete p; return SMAP_E_ARG; }
+            p->signalled[w] = 1;
+        }
+    }
     p->windows.push_back(0);
     for (int i = 0; i < n_ops; ++i)
         if (ops[i].kind == SMAP_OP_CONV) {
@@ -748,7 +766,35 @@ int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan)
 void smap_plan_destroy(smap_plan* plan)
 {
     if (!plan) return;
+    for (hipEvent_t e : plan->ev) if (e) hipEventDestroy(e);
+    for (int l = 0; l < SMAP_MAX_LANES; ++l) {
+        if (plan->join_ev[l]) hipEventDestroy(plan->join_ev[l]);
+        if (plan->side[l]) hipStreamDestroy(plan->side[l]);
+    }
     delete plan;
+}
+
+int smap_plan_set_lanes(smap_plan* plan, int on)
+{
+    if (!plan) return SMAP_E_ARG;
+    plan->lanes_on = on != 0;
+    return 0;
+}
+
+// side streams + events of a plan whose lanes were switched on (device = the current one)
+static int lanes_setup(smap_plan* p)
+{
+    if (p->lanes_ready) return 0;
+    for (int l = 1; l < p->n_lanes; ++l)
+        if (hipError_t e = hipStreamCreateWithFlags(&p->side[l], hipStreamNonBlocking); e != hipSuccess) return hip_rc(e);
+    for (int l = 0; l < p->n_lanes; ++l)
+        if (hipError_t e = hipEventCreateWithFlags(&p->join_ev[l], hipEventDisableTiming); e != hipSuccess) return hip_rc(e);
+    p->ev.assign(p->ops.size(), nullptr);
+    for (size_t i = 0; i < p->ops.size(); ++i)
+        if (p->signalled[i])
+            if (hipError_t e = hipEventCreateWithFlags(&p->ev[i], hipEventDisableTiming); e != hipSuccess) return hip_rc(e);
+    p->lanes_ready = true;
+    return 0;
 }
 
 static int run_ops(const smap_plan* plan, int first, int count, const float* const* inputs, int n_inputs, void* arena,
@@ -774,9 +820,24 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
             if (hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(out) + plan->ops[i].status_off, 0, 4 * (size_t)SMAP_STATUS_WORDS(plan->ops[i].B), st); e != hipSuccess) return hip_rc(e);
             break;
         }
+    // lanes: only for whole-schedule runs (a partial range may start behind a fork)
+    const bool lanes = plan->lanes_on && plan->n_lanes > 1 && first == 0 && count == (int)plan->ops.size();
+    hipStream_t const st0 = st;
+    if (lanes) {
+        if (int rc = lanes_setup(const_cast<smap_plan*>(plan))) return rc;
+        // the side lanes start behind what the caller's stream holds so far (its earlier work, the memsets above)
+        if (hipError_t e = hipEventRecord(plan->join_ev[0], st0); e != hipSuccess) return hip_rc(e);
+        for (int l = 1; l < plan->n_lanes; ++l)
+            if (hipError_t e = hipStreamWaitEvent(plan->side[l], plan->join_ev[0], 0); e != hipSuccess) return hip_rc(e);
+    }
     for (int i = first; i < first + count; ++i) {
         const smap_op& o = plan->ops[i];
         hipError_t e = hipSuccess;
+        if (lanes) {
+            st = o.lane > 0 ? plan->side[o.lane] : st0;
+            for (int k = 0; k < o.n_wait; ++k)
+                if (hipError_t e2 = hipStreamWaitEvent(st, plan->ev[o.wait_op[k]], 0); e2 != hipSuccess) return hip_rc(e2);
+        }
         switch (o.kind) {
             case SMAP_OP_CONV: {
                 ConvArgs a;
@@ -925,7 +986,14 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
                 return SMAP_E_ARG;
         }
         if (e != hipSuccess) return hip_rc(e);
+        if (lanes && plan->signalled[i])
+            if (hipError_t e2 = hipEventRecord(plan->ev[i], st); e2 != hipSuccess) return hip_rc(e2);
     }
+    if (lanes)                                           // join: the caller's stream continues when every lane is done
+        for (int l = 1; l < plan->n_lanes; ++l) {
+            if (hipError_t e = hipEventRecord(plan->join_ev[l], plan->side[l]); e != hipSuccess) return hip_rc(e);
+            if (hipError_t e = hipStreamWaitEvent(st0, plan->join_ev[l], 0); e != hipSuccess) return hip_rc(e);
+        }
     return 0;
 }
 

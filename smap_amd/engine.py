@@ -183,6 +183,13 @@ def tile_bk(tile, x3):
 # gives the next K tile (batch 1: 226 vs 195 frames/s); larger schedules are bandwidth-bound and prefer one contiguous block
 # per K tile (batch 8: 751 vs 738).  A per-launch rule (pairs for <= 512 workgroups) sits in between on both (226 / 745):
 # profiles/r3_ab_wpairs*.log.  SMAP_WPAIRS=0|1 forces one layout.
+def use_lanes(frames, H, W):
+    """Forked streams for the independent head chains (smap_op.lane): small schedules only -- at batch 1 a launch fills a fraction of the
+    chip and two of them run side by side; at batch 8 every launch fills it.  SMAP_LANES=0|1 forces."""
+    forced = os.environ.get("SMAP_LANES", "")
+    return int(forced) if forced in ("0", "1") else int(frames * H * W <= 2 * 512 * 832)
+
+
 def use_w_pairs(frames, H, W):
     forced = os.environ.get("SMAP_WPAIRS", "")
     return int(forced) if forced in ("0", "1") else int(frames * H * W <= 2 * 512 * 832)
@@ -320,6 +327,7 @@ class Op:
     add2: Tensor = None
     aux: list = field(default_factory=list)
     p: dict = field(default_factory=dict)
+    lane: int = 0                                 # stream lane (smap_op.lane): 0 = the caller's stream
     outs: list = field(default_factory=list)      # further output tensors (N segments 1, 2 of a merged 1x1 launch)
     scratch: list = field(default_factory=list)   # arena scratch that lives for this op only (split K: the partial tiles)
 
@@ -397,8 +405,10 @@ def arena_budget(device):
 
 class Graph:
     def __init__(self, sd, B, H, W, stage_num=3, chl=256, kpt_paf=43, paf=14, keep_ref=False, precision="f16",
-                 flip_pair=None):
-        """flip_pair (43 ints: KEYPOINT.FLIP_ORDER + [15 + c for c in PAF.FLIP_CHANNEL]) switches the flip-TTA of
+                 flip_pair=None, build=True):
+        """build=False: an EMPTY schedule with all the book-keeping in place (single-op harnesses of tests / tools append to it with
+        Graph.tensor / conv / conv_seg and then allocate() / emit()).
+        flip_pair (43 ints: KEYPOINT.FLIP_ORDER + [15 + c for c in PAF.FLIP_CHANNEL]) switches the flip-TTA of
         test.py:55-70 on INSIDE the schedule: B input frames run as a 2B batch whose second half the stem reads mirrored,
         and the head sum merges the mirrored maps back (no flipped copy of the images, no separate merge pass); the
         depth heads, which the reference takes from the un-mirrored pass only, run on the first B frames."""
@@ -412,22 +422,41 @@ class Graph:
             if sorted(self.flip_pair) != list(range(kpt_paf)):      # the head sum indexes LDS with these values
                 raise ValueError("flip_pair must be a permutation of the %d output channels (cfg FLIP_ORDER / PAF.FLIP_CHANNEL)" % kpt_paf)
             B = 2 * B                         # frames of every activation tensor
-        assert H % 32 == 0 and W % 32 == 0, "input must be a multiple of 32 (5 stride-2 levels)"
+        assert not build or (H % 32 == 0 and W % 32 == 0), "input must be a multiple of 32 (5 stride-2 levels)"
         self.sd, self.B, self.H, self.W = sd, B, H, W
         self.w_pairs = use_w_pairs(B, H, W)                  # layout of the packed 32-half weight tiles (whole schedule)
+        self.lanes = use_lanes(B, H, W)                      # head chains on forked streams (BackboneEngine switches the plan's lanes on)
+        self.cur_lane = 0                                    # lane of the ops being appended (Graph.on_lane)
         self.ops, self.tensors = [], []
         self.scratch_tensors, self.kcount, self.kcount_tiles = [], None, 0      # split K: partial-tile scratch per op, one ticket region per schedule
         self.wchunks, self.woff = [], 0
         self.stage_num, self.chl, self.kpt_paf, self.paf = stage_num, chl, kpt_paf, paf
         self.flops = 0
         self.alg_bytes = 0                    # unfused per-launch traffic: input + output + weights + residual / skip adds / taps
-        self._build()
+        if build:
+            self._build()
 
     # -- helpers
     def tensor(self, name, H, W, C, esize=2):
         t = Tensor(name, self.B, H, W, C, esize, 2 if (self.x3 and esize == 2) else 1)
         self.tensors.append(t)
         return t
+
+    def on_lane(self, lane):
+        """Context manager: ops appended inside run on stream lane `lane` (0 when the schedule has no lanes)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            prev, self.cur_lane = self.cur_lane, (lane if self.lanes else 0)
+            n0 = len(self.ops)
+            try:
+                yield
+            finally:
+                for op in self.ops[n0:]:
+                    op.lane = self.cur_lane
+                self.cur_lane = prev
+        return cm()
 
     def split_k(self, tile, M, cout_pad, K):
         """K parts per output tile for a conv.hip launch of this shape (include/smap_hip.h smap_op.ksplit), or 1.  Small schedules only
@@ -859,12 +888,15 @@ class Graph:
                         m = self.conv(u + ".heads1x1", [u + ".res_conv1", u + ".res_d_conv1", u + ".res_rd_conv1"], out, relu=True)
                         c = self.chl
                         head_t["res4"] = self.conv(u + ".res", [u + ".res_conv2"], m, 3, relu=False, in_c_off=0, cin=c, out_fp32=True)
-                        head_t["res_d"] = self.conv(u + ".res_d", [u + ".res_d_conv2"], m, 3, relu=False, in_c_off=c, cin=c, out_fp32=True,
-                                                    frames=self.frames)
-                        head_t["res_rd"] = self.conv(u + ".res_rd", [u + ".res_rd_conv2"], m, 3, relu=False, in_c_off=2 * c, cin=c,
-                                                     out_fp32=True, frames=self.frames)
+                        with self.on_lane(1):     # the three 3x3 heads read disjoint channel slices of m: side by side
+                            head_t["res_d"] = self.conv(u + ".res_d", [u + ".res_d_conv2"], m, 3, relu=False, in_c_off=c, cin=c, out_fp32=True,
+                                                        frames=self.frames)
+                        with self.on_lane(2):
+                            head_t["res_rd"] = self.conv(u + ".res_rd", [u + ".res_rd_conv2"], m, 3, relu=False, in_c_off=2 * c, cin=c,
+                                                         out_fp32=True, frames=self.frames)
                     elif ind >= 1:
-                        head_t[f"res{ind + 1}"] = self.conv(u + ".res", [u + ".res_conv2"], got[u + ".res1"], 3, relu=False, out_fp32=True)
+                        with self.on_lane(1):     # the 3x3 head of this unit runs beside the next unit's launches
+                            head_t[f"res{ind + 1}"] = self.conv(u + ".res", [u + ".res_conv2"], got[u + ".res1"], 3, relu=False, out_fp32=True)
                 continue
             if ind == 0:
                 out = self.conv(u + ".out", [u + ".u_skip"], xin, relu=True)
@@ -913,8 +945,10 @@ class Graph:
             # outputs_2d = res4 + res3 + res2 (smap.py:417)
             self.ops.append(Op(OP_HEADSUM, aux=[head_t["res4"], head_t["res3"], head_t["res2"]],
                                p=dict(Cout=n_hms, ext_off=self.out_layout["hms"][0], **flip_p)))
-            self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_d"]], p=dict(Cout=n_d, ext_off=self.out_layout["det_d"][0])))
-            self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_rd"]], p=dict(Cout=1, ext_off=self.out_layout["root_d"][0])))
+            with self.on_lane(1):
+                self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_d"]], p=dict(Cout=n_d, ext_off=self.out_layout["det_d"][0])))
+            with self.on_lane(2):
+                self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_rd"]], p=dict(Cout=1, ext_off=self.out_layout["root_d"][0])))
         return cross, (s1 if gen_skip else None), (s2 if gen_skip else None)
 
     # -- arena: liveness-based first-fit allocation
@@ -928,6 +962,22 @@ class Graph:
                 t.last = max(t.last, i)
             for t in op.scratch:
                 t.first = t.last = i
+        # Lanes: an op on a side lane may start as soon as its producers are done and end as late as the schedule does.  What it WRITES is
+        # therefore live from the op after its last producer, what it READS stays live to the end of the schedule (smap_op.lane's contract).
+        producer = {}
+        for i, op in enumerate(self.ops):
+            for t in ([op.out] if op.out is not None else []) + list(op.outs):
+                producer[id(t)] = i
+        n_last = len(self.ops) - 1
+        for i, op in enumerate(self.ops):
+            if not op.lane:
+                continue
+            reads = [t for t in [op.inp, op.res, op.add1, op.add2] + list(op.aux) if t is not None]
+            start = 1 + max([producer.get(id(t), -1) for t in reads] + [-1])
+            for t in ([op.out] if op.out is not None else []) + list(op.outs) + list(op.scratch):
+                t.first = min(t.first, start)
+            for t in reads + list(op.scratch):
+                t.last = n_last
         if self.kcount is not None:                                # the tickets of every split-K op: one region, alive for the whole schedule
             self.kcount.first, self.kcount.last = 0, len(self.ops) - 1
         every = self.tensors + self.scratch_tensors + ([self.kcount] if self.kcount is not None else [])
@@ -984,9 +1034,26 @@ class Graph:
 
     def emit(self):
         arr = (_L.SmapOp * len(self.ops))()
+        producer = {}
+        for i, op in enumerate(self.ops):
+            for t in ([op.out] if op.out is not None else []) + list(op.outs):
+                producer[id(t)] = i
         for i, op in enumerate(self.ops):
             o = arr[i]
             C.memset(C.byref(o), 0, C.sizeof(o))
+            # lanes: wait for the latest producer on every OTHER lane (ops of one lane are ordered by their stream)
+            o.lane = op.lane
+            waits = {}
+            for t in [op.inp, op.res, op.add1, op.add2] + list(op.aux):
+                pi = producer.get(id(t)) if t is not None else None
+                if pi is not None and self.ops[pi].lane != op.lane:
+                    ln = self.ops[pi].lane
+                    waits[ln] = max(waits.get(ln, -1), pi)
+            for k in range(4):
+                o.wait_op[k] = -1
+            for k, pi in enumerate(sorted(waits.values())):
+                o.wait_op[k] = pi
+            o.n_wait = len(waits)
             o.kind = op.kind
             o.B = self.B
             o.res_off = o.add1_off = o.add2_off = -1
@@ -1125,6 +1192,8 @@ class BackboneEngine:
         with torch.cuda.device(self.device):
             _L.check(self.lib.smap_plan_create(self.ops, self.n_ops, C.byref(handle)), "smap_plan_create")
         self.handle = handle
+        if g.lanes:
+            _L.check(self.lib.smap_plan_set_lanes(handle, 1), "smap_plan_set_lanes")
         self.kpt_paf, self.paf = kpt_paf, paf
         self.out_floats = g.out_bytes // 4
         self.status_words = g.status_words

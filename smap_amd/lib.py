@@ -18,7 +18,7 @@ SO_PATH = os.environ.get("SMAP_HIP_LIB") or os.path.join(HERE, "libsmap_hip.so")
 SYMBOLS = [
     "smap_version", "smap_scale_hms", "smap_flip_merge", "smap_nms", "smap_paf_score", "smap_group", "smap_lift",
     "smap_refine", "smap_register_gt", "smap_lift_gt", "smap_refine_gt", "smap_refine_mlp", "smap_preprocess", "smap_sizeof_op", "smap_conv_tile_dims", "smap_conv_tile_bk", "smap_conv_tile_tail_bn", "smap_plan_create", "smap_plan_destroy", "smap_plan_run", "smap_plan_run_range",
-    "smap_plan_run_inputs", "smap_workspace_bytes", "smap_plan_create_from_blob",
+    "smap_plan_run_inputs", "smap_workspace_bytes", "smap_plan_create_from_blob", "smap_plan_set_lanes",
 ]
 MAX_INPUTS = 8                         # SMAP_MAX_INPUTS
 
@@ -47,6 +47,7 @@ class SmapOp(C.Structure):
         ("seg_n", C.c_int32 * 2), ("seg_cout", C.c_int32 * 2), ("seg_relu", C.c_int32 * 2), ("seg_out_stride_c", C.c_int32 * 2),
         ("seg_acc_scale", C.c_float * 2), ("seg_out_off", C.c_int64 * 2),
         ("ksplit", C.c_int32), ("reserved1", C.c_int32), ("kpart_off", C.c_int64), ("kcount_off", C.c_int64),
+        ("lane", C.c_int32), ("n_wait", C.c_int32), ("wait_op", C.c_int32 * 4),
     ]
 
 
@@ -107,6 +108,7 @@ def load():
     lib.smap_plan_run.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.smap_plan_run_range.argtypes = [vp, ip, ip, vp, vp, vp, vp, vp]
     lib.smap_plan_run_inputs.argtypes = [vp, C.POINTER(vp), ip, vp, vp, vp, vp]
+    lib.smap_plan_set_lanes.argtypes = [vp, ip]
     lib.smap_workspace_bytes.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.smap_plan_create_from_blob.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(BlobInfo)]
     for s in SYMBOLS:

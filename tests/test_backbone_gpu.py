@@ -827,6 +827,49 @@ def test_small_schedule_split_k_launches(golden_dir, small, monkeypatch, splitk,
     assert torch.equal(torch.cat([o.reshape(-1) for o in outs]), runs[0][:sum(o.numel() for o in outs)])     # reuse=True arena: same bits
 
 
+@pytest.mark.parametrize("precision", ["x3", "f16"])
+def test_lanes_fork_the_head_chains_and_change_nothing(small, monkeypatch, precision):
+    """smap_op.lane / smap_plan_set_lanes: the 3x3 head of an Upsample_unit runs on a forked stream beside the next unit, the three
+    heads of up4 and the three head sums side by side (model/smap.py:219-229 are independent of the unit that follows).  Same kernels,
+    same operands: the outputs must equal the single-stream run BIT FOR BIT, launched directly, replayed from a captured graph (the
+    lanes become parallel branches) and ten times over (a missing wait shows as a difference sooner or later)."""
+    from smap_amd.engine import BackboneEngine
+    _, sd = small
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(5)).to(DEV)
+    monkeypatch.setenv("SMAP_LANES", "0")
+    e0 = BackboneEngine(sd, 2, 64, 96, DEV, precision=precision)
+    assert not e0.graph.lanes and all(op.lane == 0 for op in e0.graph.ops)
+    o0 = e0.new_output()
+    e0.run(x, out=o0)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("SMAP_LANES", "1")
+    e1 = BackboneEngine(sd, 2, 64, 96, DEV, precision=precision)
+    ops = e1.graph.emit()
+    assert e1.graph.lanes and sorted({op.lane for op in e1.graph.ops}) == [0, 1, 2]
+    assert sum(1 for o in ops if o.n_wait) >= 5 and all(ops[o.wait_op[k]].lane != o.lane for o in ops for k in range(o.n_wait))
+    for _ in range(10):
+        o1 = e1.new_output()
+        e1.run(x, out=o1)
+        torch.cuda.synchronize()
+        assert torch.equal(o0.view(torch.int32), o1.view(torch.int32))
+    og = e1.new_output()
+    replay = e1.capture(og)
+    for _ in range(5):
+        og.zero_()
+        replay(x)
+        torch.cuda.synchronize()
+        assert torch.equal(o0.view(torch.int32), og.view(torch.int32))
+    s2 = torch.cuda.Stream()                              # a sibling (PosePipeline depth 2) shares the plan and its side streams
+    e2 = e1.sibling()
+    o2 = e2.new_output()
+    with torch.cuda.stream(s2):
+        e2.run(x, out=o2)
+    o3 = e1.new_output()
+    e1.run(x, out=o3)
+    torch.cuda.synchronize()
+    assert torch.equal(o0.view(torch.int32), o2.view(torch.int32)) and torch.equal(o0.view(torch.int32), o3.view(torch.int32))
+
+
 SEG_CASES = [   # B, H, W, Cin, couts, relus, up (low-res size or None), tile
     (2, 13, 21, 256, (256, 64), (1, 1), None, 20),
     (2, 13, 21, 256, (256, 64, 256), (1, 1, 0), None, 21),
@@ -858,10 +901,8 @@ def test_merged_1x1_launch_matches_torch(case, x3):
         sd[pre + ".bn.running_mean"] = torch.randn(c, generator=gen) * 0.1
         sd[pre + ".bn.running_var"] = torch.rand(c, generator=gen) + 0.5
         segs.append((f"y{j}", pre, bool(r)))
-    g = E.Graph.__new__(E.Graph)
-    g.precision, g.x3, g.keep_ref, g.flip_pair, g.frames = ("x3" if x3 else "f16"), x3, True, None, B
-    g.sd, g.B, g.H, g.W, g.w_pairs = sd, B, H * 4, W * 4, 1
-    g.ops, g.tensors, g.wchunks, g.woff, g.flops, g.alg_bytes = [], [], [], 0, 0, 0
+    g = E.Graph(sd, B, H * 4, W * 4, keep_ref=True, precision="x3" if x3 else "f16", build=False)
+    g.w_pairs = 1
     xt = g.tensor("x", H, W, cin)
     ut = g.tensor("up", up[0], up[1], couts[0]) if up else None
     outs = g.conv_seg(segs, xt, up=ut, tile=tile)

@@ -43,6 +43,8 @@ def test_x3_graph_emits_split_strides_and_weights(small_sd, monkeypatch, blocks)
     if not blocks:                      # the layer-by-layer schedule: op for op the fp16 one (the default fuses layer1's Bottlenecks)
         monkeypatch.setenv("SMAP_BLOCK", "")
         monkeypatch.setenv("SMAP_BLOCK_FIRST", "")
+    monkeypatch.setenv("SMAP_SPLITK", "0")          # (this test is about the split-precision STORAGE: no split-K scratch, no lanes, whose
+    monkeypatch.setenv("SMAP_LANES", "0")           #  extended lifetimes would blur the arena comparison at the end)
     g16 = Graph(small_sd, 2, 64, 96)
     g = Graph(small_sd, 2, 64, 96, precision="x3")
     g.allocate()
@@ -141,14 +143,18 @@ def test_shipped_launcher_settings_are_plannable():
 
 
 def test_tile_tables_name_existing_tiles():
-    from smap_amd.engine import TILES, X3_TILES, _table_entry
+    from smap_amd.engine import TILES, X3_TILES, _table_entry, tile_family
     t16 = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table.json")))
     tx3 = json.load(open(os.path.join(ROOT, "smap_amd", "tile_table_x3.json")))
     assert t16 and all(t in TILES for v in t16.values() for t in _table_entry(v))
     assert tx3 and all(t in X3_TILES + (3,) + tuple(range(30, 46)) for v in tx3.values() for t in _table_entry(v))
     for key, v in tx3.items():
-        B, H, W, cin, cout, k, s = map(int, key.split(",")[:7])              # optional 8th field: "up" (ops with a fused bilinear add)
-        assert key.split(",")[7:] in ([], ["up"])
+        f = key.split(",")                                                   # optional 8th field: "up" (ops with a fused bilinear add)
+        merged = "+" in f[4]                                                 # "c0+c1[+c2]": a merged 1x1 launch (Graph.conv_seg, tools/autotune_seg.py)
+        B, H, W, cin, k, s = map(int, f[:4] + f[5:7])
+        cout = sum(map(int, f[4].split("+")))
+        assert f[7:] in ([], ["up"])
+        assert not merged or (k == 1 and s == 1 and all(tile_family(t) == "igemm" for t in _table_entry(v)))
         for t in _table_entry(v):
             assert B in (1, 8, 16) and (t < 30 or t >= 40 or (k == 3 and s == 1))   # (1 = configs[1], 16 = the flip-TTA schedule of batch 8); halo tiles: plain 3x3 stride 1 only
             assert cout > 32 or t in (3, 38, 39)

@@ -21,11 +21,7 @@ from smap_amd import engine as E  # noqa: E402
 
 def single_op_graph(sd, B, x_shape, segs, up_shape, tile):
     """A Graph holding ONE merged launch: input tensor, optional low-resolution `up` tensor, the op."""
-    g = E.Graph.__new__(E.Graph)
-    g.precision, g.x3, g.keep_ref, g.flip_pair, g.frames = "x3", True, False, None, B
-    g.sd, g.B, g.H, g.W = sd, B, 512, 832
-    g.w_pairs = E.use_w_pairs(B, 512, 832)
-    g.ops, g.tensors, g.wchunks, g.woff, g.flops, g.alg_bytes = [], [], [], 0, 0, 0
+    g = E.Graph(sd, B, 512, 832, precision="x3", build=False)
     x = g.tensor("x", *x_shape)
     up = g.tensor("up", *up_shape) if up_shape else None
     g.conv_seg(segs, x, up=up, tile=tile)
