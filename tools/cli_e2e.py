@@ -4,9 +4,10 @@
     python exps/stage3_root2/test.py -t run_inference -d test --batch_size 8 --dataset_path <folder> [--device_preprocess 1]
 
 decode -> [host resize | H2D of the uint8 image + GPU pre-processing] -> backbone -> association -> lifting -> records -> JSON, timed
-inside the CLI's own loop (SMAP_CLI_TIMING) and around the whole process.  The folder is generated here: N images, half 1920x1080
-JPEG (quality 90), half 1280x720 PNG, smooth synthetic content (decode cost of photographs, not of noise); a second folder holds the
-same pictures as .npy (no decoder).  Weights: the bench's workload (benchkit/workload.py), so every frame carries ~20 skeletons.
+inside the CLI's own loop (SMAP_CLI_TIMING) and around the whole process.  The folder is generated here: N images of two source
+resolutions -- the bench's 8 frames as 832x512 PNGs and as 1664x1024 JPEGs (every pixel doubled: the pre-processing's 2x shrink gives
+the frame back) -- so that the network sees the workload the bench line is quoted on (~20 skeletons per frame: association, lifting
+and record building do real work); a second folder holds the same pictures as .npy (no decoder).
 
     python tools/cli_e2e.py [--images 256] [--out profiles/r5_cli_e2e.json]
 """
@@ -24,23 +25,18 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def picture(rng, h, w):
-    """Smooth colour fields + a few soft blobs + mild grain: compresses like a photograph."""
-    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-    img = np.zeros((h, w, 3), np.float32)
-    for c in range(3):
-        a, b, p, q = rng.uniform(0.002, 0.01, 4)
-        img[..., c] = 110 + 60 * np.sin(a * xx + p * 50) * np.cos(b * yy + q * 50)
-    for _ in range(12):
-        cx, cy, r = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(20, 120)
-        img += rng.uniform(-60, 60, 3) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * r * r))[..., None]
-    img += rng.normal(0, 3, img.shape)
-    return np.clip(img, 0, 255).astype(np.uint8)
+def bench_frames_as_images(cfg_means, cfg_stds):
+    """The bench's 8 input frames (randn, seed 1234: the frames the workload's heads were calibrated on, ~20 skeletons each) as uint8
+    BGR images of the network size: pixel = (x * std + mean) * 255, rounded and clipped -- what a decoder hands the pre-processing."""
+    x = torch.randn(8, 3, 512, 832, generator=torch.Generator().manual_seed(1234))
+    mean = torch.tensor(cfg_means).view(1, 3, 1, 1)
+    std = torch.tensor(cfg_stds).view(1, 3, 1, 1)
+    return ((x * std + mean) * 255.0).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().numpy()     # [8,512,832,3]
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--images", type=int, default=256)
+    ap.add_argument("--images", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "cli_e2e.json"))
     args = ap.parse_args()
@@ -50,30 +46,44 @@ def main():
     tmp = tempfile.mkdtemp(prefix="smap_cli_e2e_")
     enc, raw = os.path.join(tmp, "encoded"), os.path.join(tmp, "npy")
     os.makedirs(enc), os.makedirs(raw)
-    rng = np.random.default_rng(7)
+    from exps.stage3_root2.config import cfg as run_cfg
     t0 = time.perf_counter()
-    base = [picture(rng, 1080, 1920) for _ in range(4)] + [picture(rng, 720, 1280) for _ in range(4)]
+    base = bench_frames_as_images(list(run_cfg.INPUT.MEANS), list(run_cfg.INPUT.STDS))
     sizes = []
+    # two source resolutions: 832x512 (no resize) as PNG, and 1664x1024 = every pixel doubled (the 2x shrink of the pre-processing is the
+    # 2x2 box mean: it returns the original frame) as JPEG quality 98 (4:4:4); 8 + 8 files are written, the rest of the folder links to them
+    written = {}
     for i in range(args.images):
-        img = np.roll(base[(i % 2) * 4 + (i // 2) % 4], (i * 37) % 200, axis=1)       # BGR in memory; PIL writes RGB
-        if i % 2 == 0:
-            path = os.path.join(enc, f"im{i:04d}.jpg")
-            Image.fromarray(img[:, :, ::-1]).save(path, quality=90)
-        else:
-            path = os.path.join(enc, f"im{i:04d}.png")
-            Image.fromarray(img[:, :, ::-1]).save(path, compress_level=3)
-        sizes.append(os.path.getsize(path))
-        np.save(os.path.join(raw, f"im{i:04d}.npy"), img)
+        f, big = i % 8, (i // 8) % 2
+        ext = "jpg" if big else "png"
+        if (f, big) not in written:
+            img = base[f] if not big else np.repeat(np.repeat(base[f], 2, axis=0), 2, axis=1)
+            path = os.path.join(enc, f"src_{f}_{big}.{ext}.data")
+            if big:
+                Image.fromarray(img[:, :, ::-1]).save(path, format="JPEG", quality=98, subsampling=0)      # 4:4:4: the frame comes back within 0.6 grey levels
+            else:
+                Image.fromarray(img[:, :, ::-1]).save(path, format="PNG", compress_level=1)
+            npy = os.path.join(raw, f"src_{f}_{big}.data")
+            np.save(npy, img)
+            written[(f, big)] = (path, npy + ".npy")
+            sizes.append(os.path.getsize(path))
+        os.symlink(written[(f, big)][0], os.path.join(enc, f"im{i:05d}.{ext}"))
+        os.symlink(written[(f, big)][1], os.path.join(raw, f"im{i:05d}.npy"))
     gen_s = time.perf_counter() - t0
     torch.manual_seed(0)
     net = SMAP(make_cfg((128, 208))).eval()
     sd = people_state_dict(net.state_dict(), "smooth")
     torch.save({"model": sd}, os.path.join(tmp, "SMAP.pth"))
     runs = []
-    cases = [("encoded jpg/png, GPU pre-processing, decode threads (default)", enc, ["--device_preprocess", "1"], {}),
+    cases = [("encoded jpg/png, GPU pre-processing, 8 decode threads (default)", enc, ["--device_preprocess", "1"], {}),
+             ("encoded jpg/png, GPU pre-processing, 32 decode threads", enc, ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "32"}),
              ("encoded jpg/png, GPU pre-processing, ONE decode thread (round-4 loader)", enc, ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "1"}),
-             ("encoded jpg/png, host pre-processing (the reference's DataLoader path)", enc, [], {}),
-             (".npy frames (no decoder), GPU pre-processing", raw, ["--device_preprocess", "1"], {})]
+             (".npy frames (no decoder), GPU pre-processing", raw, ["--device_preprocess", "1"], {}),
+             ("encoded jpg/png, host pre-processing (the reference's DataLoader path), first 128 images", enc + "_few", [], {})]
+    os.makedirs(enc + "_few")
+    for n in sorted(os.listdir(enc)):
+        if n.startswith("im") and int(n[2:7]) < 128:
+            os.symlink(os.path.realpath(os.path.join(enc, n)), os.path.join(enc + "_few", n))
     for name, folder, extra, env_extra in cases:
         timing = os.path.join(tmp, "timing.json")
         env = dict(os.environ, PROJECT_HOME=tmp, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), SMAP_CLI_TIMING=timing, **env_extra)
@@ -93,7 +103,7 @@ def main():
             rec["stderr_tail"] = r.stderr[-1500:]
         runs.append(rec)
         print(json.dumps(rec), flush=True)
-    out = {"images": args.images, "batch_size": args.batch, "sources": "half 1920x1080 JPEG q90, half 1280x720 PNG (synthetic smooth content)",
+    out = {"images": args.images, "batch_size": args.batch, "sources": "the bench's 8 frames: 832x512 PNG and 1664x1024 JPEG q98 4:4:4 (pixel-doubled), alternating in groups of 8",
            "mean_file_KB": float(np.mean(sizes)) / 1e3, "generation_s": gen_s, "host_cpus_allowed": len(os.sched_getaffinity(0)),
            "gpu": torch.cuda.get_device_name(0) if torch.cuda.is_available() else None, "runs": runs}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
