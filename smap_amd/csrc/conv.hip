@@ -353,11 +353,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     __syncthreads();
     if (SPLITK && S == 1 && o_res) load_res();
     if (SPLITK && S > 1) {
-        // raw partial tile -> scratch [tile][k part][BM * BN]; release; ticket.  Everyone but the last arriver is done.
-        float4* part = reinterpret_cast<float4*>(a.kpart) + (size_t)tile_id * S * (BM * BN / 4);
-        const float4* Cs4 = reinterpret_cast<const float4*>(Cs);
-        for (int i = tid; i < BM * BN / 4; i += NT) part[(size_t)ks * (BM * BN / 4) + i] = Cs4[i];
-        __threadfence();                                         // this thread's stores are visible device-wide (L2 write-back across XCDs)
+        // raw partial tile -> scratch [tile][k part][BM * BN]; ticket.  Everyone but the last arriver is done.
+        // Coherence WITHOUT fences: the parts of a tile may run on different XCDs, whose L2s are not coherent with each other; an
+        // agent-scope release fence (__threadfence) writes back the WHOLE L2 of the XCD -- measured: a batch-1 forward 3.7 -> 10+ ms
+        // with two parts per tile (profiles/r5_v2_ab_b1.log).  Instead the partials are written and read with agent-scope relaxed
+        // atomic accesses (sc1: written through / read around the non-coherent caches), the writers wait for their stores to be
+        // acknowledged (vmcnt counts stores on gfx9) before the barrier that precedes the ticket, and the ticket is an agent-scope
+        // atomic: when the last arriver sees S - 1, every part is in memory.
+        float* part = a.kpart + (size_t)tile_id * S * (BM * BN);
+        for (int i = tid; i < BM * BN; i += NT) __hip_atomic_store(part + (size_t)ks * (BM * BN) + i, Cs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         volatile int* s_last = reinterpret_cast<volatile int*>(smem + LDS_BYTES - 16);     // behind the epilogue tile
         if (tid == 0) {
@@ -367,19 +372,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         }
         __syncthreads();
         if (!*s_last) return;
-        __threadfence();                                         // acquire: the other parts' stores
         if (o_res) load_res();
-        for (int i = tid; i < BM * BN / 4; i += NT) {            // fixed order 0 .. S-1 whoever arrives last (own part re-read too)
-            float4 v = part[i];
-            for (int q = 1; q < S; ++q) {
-                const float4 u = part[(size_t)q * (BM * BN / 4) + i];
-                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-            }
-            const int col = (i * 4) % BN;
-            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n0 + col);
-            if (X3) { v.x = v.x * o_scale + b4.x; v.y = v.y * o_scale + b4.y; v.z = v.z * o_scale + b4.z; v.w = v.w * o_scale + b4.w; }
-            else { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
-            reinterpret_cast<float4*>(Cs)[i] = v;
+        for (int i = tid; i < BM * BN; i += NT) {                // fixed order 0 .. S-1 whoever arrives last (own part re-read too)
+            float v = __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 1; q < S; ++q) v += __hip_atomic_load(part + (size_t)q * (BM * BN) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float bias = a.bias[n0 + i % BN];
+            Cs[i] = X3 ? v * o_scale + bias : v + bias;
         }
         __syncthreads();
     }

@@ -469,11 +469,14 @@ class Graph:
         bm, bn = TILES[tile]
         tiles = -(-M // bm) * (cout_pad // bn)
         n_k = K // tile_bk(tile, self.x3)
-        if env and env != "1":
-            return max(1, min(int(env), 16, n_k))
-        if tiles >= 128 or n_k < 8:
+        if tiles >= 128 or n_k < 8:                      # the launch fills half the chip by itself, or has no K loop to share out
             return 1
-        s = min(8, 256 // tiles, n_k // 4)
+        if env.startswith("t"):                          # "t384": aim at that many workgroups per launch (A/B hook; the rule is t256)
+            s = min(8, int(env[1:]) // tiles, n_k // 4)
+        elif env and env != "1":                         # "3": that many parts wherever a launch qualifies (tests)
+            s = min(int(env), 16, n_k)
+        else:
+            s = min(8, 256 // tiles, n_k // 4)
         return s if s >= 2 else 1
 
     def _split_k_fields(self, name, tile, M, cout_pad, ks):
@@ -759,11 +762,15 @@ class Graph:
 
     def block_tile(self, planes, stride, has_ds):
         """Tile id of the whole-block launch for this Bottleneck, or None.  Identity blocks (no shortcut conv) of stride 1 in
-        split precision only; SMAP_BLOCK="64:91" chooses per width (A/B hook), default BLOCK_DEFAULT."""
+        split precision only; SMAP_BLOCK="64:91" chooses per width (A/B hook), default BLOCK_DEFAULT -- without layer2's entry in small
+        schedules: at batch 1 the 64x104 level has 52 tiles of the eight-wave kernel for 256 CUs, 55-57 us per block where the three
+        launches take ~42 (profiles/r5_v2_x3_layers_batch1.txt)."""
         if stride != 1 or has_ds or not self.x3:
             return None
         spec = os.environ.get("SMAP_BLOCK")
         table = BLOCK_DEFAULT if spec is None else {int(k): int(v) for k, v in (kv.split(":") for kv in spec.split(",") if ":" in kv)}
+        if spec is None and planes == 128 and self.B * self.H * self.W <= 2 * 512 * 832:
+            return None
         return table.get(planes)
 
     # -- the network (smap.py:313-353 structure, :403-419 data flow)

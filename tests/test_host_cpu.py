@@ -43,6 +43,8 @@ def test_x3_graph_emits_split_strides_and_weights(small_sd, monkeypatch, blocks)
     if not blocks:                      # the layer-by-layer schedule: op for op the fp16 one (the default fuses layer1's Bottlenecks)
         monkeypatch.setenv("SMAP_BLOCK", "")
         monkeypatch.setenv("SMAP_BLOCK_FIRST", "")
+    else:                               # (named explicitly: a schedule this small drops layer2's whole-block launches by default)
+        monkeypatch.setenv("SMAP_BLOCK", "64:91,128:94")
     monkeypatch.setenv("SMAP_SPLITK", "0")          # (this test is about the split-precision STORAGE: no split-K scratch, no lanes, whose
     monkeypatch.setenv("SMAP_LANES", "0")           #  extended lifetimes would blur the arena comparison at the end)
     g16 = Graph(small_sd, 2, 64, 96)

@@ -90,4 +90,48 @@ cd $R
 timeout 1500 python tools/cli_e2e.py --images 256 --out $R/$O/cli_e2e.json > $O/cli_e2e.log 2>&1; tail -8 $O/cli_e2e.log
 }
 
+v3() {
+# visit 3: split K without fences (sc1 accesses), lanes, small schedules without layer2's whole-block launches: tests, batch-1 sweeps and
+# per-layer trace; the staggered start of the 8x16 whole-block tiles in situ; the CLI end to end on 1024 images with skeletons
+O=gpurun_out/r5v3; mkdir -p $O
+timeout 900 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "split_k or merged or lanes or graph_replay or overlapping" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -6 $O/pytest.log
+timeout 900 python -m pytest tests/test_entry_gpu.py tests/test_abi_gpu.py -m gpu -q --tb=short -p no:cacheprovider > $O/pytest_entry.log 2>&1; echo "pytest rc $?" >> $O/pytest_entry.log
+tail -6 $O/pytest_entry.log
+b1() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$1', round(d['value'],1),'fps', round(d['ms_per_step'],3),'ms/frame', d['config']['launch'])
+"; }
+B1="--forward-only --batch 1 --steps 300 --warmup 30"
+SMAP_SPLITK=0 SMAP_LANES=0 SMAP_BLOCK="64:91,128:94" SMAP_MERGE_1X1=0 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 round-4 schedule" >> $O/ab_b1.log
+SMAP_SPLITK=0 SMAP_LANES=0 SMAP_BLOCK="64:91,128:94" timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 + merged 1x1" >> $O/ab_b1.log
+SMAP_SPLITK=0 SMAP_LANES=0 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 + layer2 blocks as three launches" >> $O/ab_b1.log
+SMAP_SPLITK=0 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 + lanes" >> $O/ab_b1.log
+SMAP_LANES=0 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 + split K (rule t256), no lanes" >> $O/ab_b1.log
+timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 default (split K t256 + lanes)" >> $O/ab_b1.log
+SMAP_SPLITK=t384 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 split K t384 + lanes" >> $O/ab_b1.log
+SMAP_SPLITK=t512 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 split K t512 + lanes" >> $O/ab_b1.log
+timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "b1 default, graph" >> $O/ab_b1.log
+SMAP_LANES=0 timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "b1 default without lanes, graph" >> $O/ab_b1.log
+cat $O/ab_b1.log
+for rep in 1 2; do
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep shipped" >> $O/ab_stagger.log
+  for us in 10 20; do
+    SMAP_HIP_LIB=$R/smap_amd/csrc/obj/libsmap_hip_convb_convb_stagger_us$us.so SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep layer1 blocks: second slots start $us us late" >> $O/ab_stagger.log
+  done
+done
+for lib in "" $R/smap_amd/csrc/obj/libsmap_hip_convb_convb_stagger_us10.so $R/smap_amd/csrc/obj/libsmap_hip_convb_convb_stagger_us20.so; do
+  SMAP_HIP_LIB=$lib SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 --launch-frames 0 2>>$O/ab.err | line "depth1 lf0 lib=$(basename "$lib")" >> $O/ab_stagger.log
+done
+cat $O/ab_stagger.log
+cd /tmp
+SMAP_PRECISION=x3 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $R/$O/prof_b1 -o smap -- python $R/bench.py --forward-only --batch 1 --steps 20 --warmup 5 > $R/$O/rocprof_b1.log 2>&1
+db=$(find $R/$O/prof_b1 -name "*.db" | head -1); (cd $R; SMAP_PRECISION=x3 python tools/prof_layers.py $db 1 > $O/layers_b1.txt 2>&1); rm -rf $R/$O/prof_b1
+tail -22 $R/$O/layers_b1.txt
+cd $R
+timeout 1500 python tools/cli_e2e.py --images 1024 --out $R/$O/cli_e2e.json > $O/cli_e2e.log 2>&1; tail -8 $O/cli_e2e.log | cut -c1-600
+}
+
 "v$1"
