@@ -54,8 +54,8 @@ class DevicePreprocLoader:
     """Batches of (imgs on the device, names, scales) with decode on the host and resize / pad /
     normalise in one HIP kernel per image (smap_amd/preprocess.py).  The decodes run AHEAD of the consumer on a small thread pool
     (PIL's decoders and numpy's file reads release the GIL): at ~800 frames/s of engine, one thread decoding a 1080p JPEG in ~10 ms
-    would be the whole run (profiles/r5_cli_e2e.json).  SMAP_DECODE_THREADS (default: up to 8 of the allowed CPUs; 1 = decode in
-    the consumer's thread, the round-4 behaviour)."""
+    would be the whole run (profiles/r5_cli_e2e.json: 62 frames/s with one thread, 333 with 8, 461 with 32).  SMAP_DECODE_THREADS
+    (default: up to 16 of the allowed CPUs; 1 = decode in the consumer's thread, the round-4 behaviour)."""
 
     def __init__(self, dataset, indices, batch_size, cfg, device):
         self.ds, self.idx, self.bs, self.cfg, self.device = dataset, list(indices), batch_size, cfg, device
@@ -63,7 +63,7 @@ class DevicePreprocLoader:
             allowed = len(os.sched_getaffinity(0))
         except AttributeError:
             allowed = os.cpu_count() or 1
-        self.threads = int(os.environ.get("SMAP_DECODE_THREADS", "0")) or max(1, min(8, allowed))
+        self.threads = int(os.environ.get("SMAP_DECODE_THREADS", "0")) or max(1, min(16, allowed))
 
     def __len__(self):
         return (len(self.idx) + self.bs - 1) // self.bs

@@ -184,10 +184,11 @@ def tile_bk(tile, x3):
 # per K tile (batch 8: 751 vs 738).  A per-launch rule (pairs for <= 512 workgroups) sits in between on both (226 / 745):
 # profiles/r3_ab_wpairs*.log.  SMAP_WPAIRS=0|1 forces one layout.
 def use_lanes(frames, H, W):
-    """Forked streams for the independent head chains (smap_op.lane): small schedules only -- at batch 1 a launch fills a fraction of the
-    chip and two of them run side by side; at batch 8 every launch fills it.  SMAP_LANES=0|1 forces."""
-    forced = os.environ.get("SMAP_LANES", "")
-    return int(forced) if forced in ("0", "1") else int(frames * H * W <= 2 * 512 * 832)
+    """Forked streams for the independent head chains (smap_op.lane).  OFF by default: measured at batch 1 (profiles/r5_v3_ab_b1.log) the
+    forward is SLOWER with them, launched kernel by kernel (3.619 -> 3.706 ms) and replayed from a graph (3.129 -> 3.436 ms): the head
+    chains are 6 of 170 launches, and every fork / join costs an event round trip on the critical path.  SMAP_LANES=1 switches them on
+    (the mechanism stays tested: tests/test_backbone_gpu.py::test_lanes_fork_the_head_chains_and_change_nothing)."""
+    return int(os.environ.get("SMAP_LANES", "0") == "1")
 
 
 def use_w_pairs(frames, H, W):
@@ -471,12 +472,17 @@ class Graph:
         n_k = K // tile_bk(tile, self.x3)
         if tiles >= 128 or n_k < 8:                      # the launch fills half the chip by itself, or has no K loop to share out
             return 1
-        if env.startswith("t"):                          # "t384": aim at that many workgroups per launch (A/B hook; the rule is t256)
+        if env.startswith("t"):                          # "t384": aim at that many workgroups per launch, any K (A/B hook)
             s = min(8, int(env[1:]) // tiles, n_k // 4)
         elif env and env != "1":                         # "3": that many parts wherever a launch qualifies (tests)
             s = min(int(env), 16, n_k)
         else:
-            s = min(8, 256 // tiles, n_k // 4)
+            # Measured at batch 1 (profiles/r5_v3_*): a part costs ~9 us (partial tile to memory and back, ticket, late epilogue), so
+            # only long K loops gain: K = 4608 with 4 parts 57.6 -> 33.0 us, K = 2304 with 2 parts 30.2 -> 25.1, K = 2048 with 4
+            # parts 27.9 -> 25.8; K = 1024 with 2 parts LOSES (17.0 -> 19.0), and aiming at 384 / 512 workgroups instead of 256 loses too
+            if K < 2048:
+                return 1
+            s = min(4, 256 // tiles, n_k // 8)
         return s if s >= 2 else 1
 
     def _split_k_fields(self, name, tile, M, cout_pad, ks):

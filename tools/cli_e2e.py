@@ -63,9 +63,9 @@ def main():
                 Image.fromarray(img[:, :, ::-1]).save(path, format="JPEG", quality=98, subsampling=0)      # 4:4:4: the frame comes back within 0.6 grey levels
             else:
                 Image.fromarray(img[:, :, ::-1]).save(path, format="PNG", compress_level=1)
-            npy = os.path.join(raw, f"src_{f}_{big}.data")
+            npy = os.path.join(tmp, f"src_{f}_{big}.npy")          # (outside the folder: the loader lists every *.npy below it)
             np.save(npy, img)
-            written[(f, big)] = (path, npy + ".npy")
+            written[(f, big)] = (path, npy)
             sizes.append(os.path.getsize(path))
         os.symlink(written[(f, big)][0], os.path.join(enc, f"im{i:05d}.{ext}"))
         os.symlink(written[(f, big)][1], os.path.join(raw, f"im{i:05d}.npy"))
@@ -75,7 +75,8 @@ def main():
     sd = people_state_dict(net.state_dict(), "smooth")
     torch.save({"model": sd}, os.path.join(tmp, "SMAP.pth"))
     runs = []
-    cases = [("encoded jpg/png, GPU pre-processing, 8 decode threads (default)", enc, ["--device_preprocess", "1"], {}),
+    cases = [("encoded jpg/png, GPU pre-processing, 16 decode threads (default)", enc, ["--device_preprocess", "1"], {}),
+             ("encoded jpg/png, GPU pre-processing, 8 decode threads", enc, ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "8"}),
              ("encoded jpg/png, GPU pre-processing, 32 decode threads", enc, ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "32"}),
              ("encoded jpg/png, GPU pre-processing, ONE decode thread (round-4 loader)", enc, ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "1"}),
              (".npy frames (no decoder), GPU pre-processing", raw, ["--device_preprocess", "1"], {}),
