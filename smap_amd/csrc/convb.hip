@@ -52,6 +52,16 @@
 #ifndef SMAP_CONVB_STAGGER_US
 #define SMAP_CONVB_STAGGER_US 0
 #endif
+// Experiment (EXPERIMENTS R5.2): -DSMAP_CONVB_SETPRIO=1 raises the wave's issue priority for the duration of every MFMA group (conv3.hip's
+// staggered tiles do that), so that the co-resident workgroup's VALU / LDS / LDS-DMA issue cannot delay the matrix pipe.  0 = off (shipped).
+#ifndef SMAP_CONVB_SETPRIO
+#define SMAP_CONVB_SETPRIO 0
+#endif
+#if SMAP_CONVB_SETPRIO
+#define CONVB_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define CONVB_PRIO(x)
+#endif
 __device__ __forceinline__ void convb_stagger()
 {
 #if SMAP_CONVB_STAGGER_US > 0
@@ -252,6 +262,7 @@ __global__ __launch_bounds__(256, TH == 4 ? SMAP_CONVB_WGS4 : 2) void bottleneck
             xf[pl] = *reinterpret_cast<const half8*>(sX + (wave * 32 + l31) * ROW1 + slot);
             if (MB1 == 6) xe[pl] = *reinterpret_cast<const half8*>(sX + (xmb * 32 + l31) * ROW1 + slot);
         }
+        CONVB_PRIO(1);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {                        // small cross terms first, then hi*hi (conv3.hip's order)
             acc1[nb] = MFMA_(wf[0][nb], xf[1], acc1[nb], 0, 0, 0);
@@ -269,6 +280,7 @@ __global__ __launch_bounds__(256, TH == 4 ? SMAP_CONVB_WGS4 : 2) void bottleneck
                 acc1[NB1 - 1] = MFMA_(wf[0][0], xe[0], acc1[NB1 - 1], 0, 0, 0);
             }
         }
+        CONVB_PRIO(0);
     }
     lds_barrier();                                              // every wave is done with the staging buffers (all DMA has landed)
     TRB(2);
@@ -370,12 +382,14 @@ __global__ __launch_bounds__(256, TH == 4 ? SMAP_CONVB_WGS4 : 2) void bottleneck
                 }
                 bf[pl] = *reinterpret_cast<const half8*>(sB + b_row0 * ROWB + (((g + 4 * pl) ^ fswz) << 4));
             }
+            CONVB_PRIO(1);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 acc2[mi] = MFMA_(bf[0], af[1][mi], acc2[mi], 0, 0, 0);
                 acc2[mi] = MFMA_(bf[1], af[0][mi], acc2[mi], 0, 0, 0);
                 acc2[mi] = MFMA_(bf[0], af[0][mi], acc2[mi], 0, 0, 0);
             }
+            CONVB_PRIO(0);
         }
         wait_slots(s, s + 1 < NS2 ? s + 1 : s + 2);            // the last tap also waits for both slots of the first tail chunk
     }
@@ -453,12 +467,14 @@ __global__ __launch_bounds__(256, TH == 4 ? SMAP_CONVB_WGS4 : 2) void bottleneck
                         pf[pl][mi] = *reinterpret_cast<const half8*>(sY2 + (kc * BM + p_row0 + mi * 32) * ROWB + (((g + 4 * pl) ^ fswz) << 4));
                     wf[pl] = *reinterpret_cast<const half8*>(sW + c_row0 * ROWB + (((g + 4 * pl) ^ fswz) << 4));
                 }
+                CONVB_PRIO(1);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     acc3[mi] = MFMA_(wf[0], pf[1][mi], acc3[mi], 0, 0, 0);
                     acc3[mi] = MFMA_(wf[1], pf[0][mi], acc3[mi], 0, 0, 0);
                     acc3[mi] = MFMA_(wf[0], pf[0][mi], acc3[mi], 0, 0, 0);
                 }
+                CONVB_PRIO(0);
             }
             if (kc == KC2 - 1) wait_slots(s, s + 2);            // both slots of the next chunk, BEFORE this chunk's stores
         }

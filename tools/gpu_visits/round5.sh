@@ -134,4 +134,30 @@ cd $R
 timeout 1500 python tools/cli_e2e.py --images 1024 --out $R/$O/cli_e2e.json > $O/cli_e2e.log 2>&1; tail -8 $O/cli_e2e.log | cut -c1-600
 }
 
+v4() {
+# visit 4: the 8x16 whole-block tiles of layer1 with a staggered start of the CUs' second slots and / or raised issue priority during MFMA
+# groups (diagnostics builds), in situ and at depth 1; batch 1 with the final split-K rule
+O=gpurun_out/r5v4; mkdir -p $O
+OBJ=$R/smap_amd/csrc/obj
+for lib in "" $OBJ/libsmap_hip_convb_convb_stagger_us10.so $OBJ/libsmap_hip_convb_convb_stagger_us20.so $OBJ/libsmap_hip_convb_convb_setprio1.so $OBJ/libsmap_hip_convb_convb_setprio1_convb_stagger_us20.so ""; do
+  SMAP_HIP_LIB=$lib SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "depth2 lib=$(basename "$lib")" >> $O/ab_convb.log
+done
+for lib in "" $OBJ/libsmap_hip_convb_convb_stagger_us10.so $OBJ/libsmap_hip_convb_convb_stagger_us20.so $OBJ/libsmap_hip_convb_convb_setprio1.so $OBJ/libsmap_hip_convb_convb_setprio1_convb_stagger_us20.so; do
+  SMAP_HIP_LIB=$lib SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 --launch-frames 0 2>>$O/ab.err | line "depth1 lf0 lib=$(basename "$lib")" >> $O/ab_convb.log
+done
+cat $O/ab_convb.log; tail -3 $O/ab.err
+b1() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$1', round(d['value'],1),'fps', round(d['ms_per_step'],3),'ms/frame', d['config']['launch'])
+"; }
+B1="--forward-only --batch 1 --steps 300 --warmup 30"
+SMAP_SPLITK=0 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 no split K" >> $O/ab_b1.log
+timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 default (split K where K >= 2048)" >> $O/ab_b1.log
+timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "b1 default, graph" >> $O/ab_b1.log
+SMAP_SPLITK=0 timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "b1 no split K, graph" >> $O/ab_b1.log
+cat $O/ab_b1.log
+}
+
 "v$1"
