@@ -160,4 +160,12 @@ SMAP_SPLITK=0 timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "b1 no s
 cat $O/ab_b1.log
 }
 
+v5() {
+# visit 5: the entry / ABI tests with the summation order pinned (split K off in that file), the CLI end to end with the final loader
+O=gpurun_out/r5v5; mkdir -p $O
+timeout 900 python -m pytest tests/test_entry_gpu.py tests/test_abi_gpu.py -m gpu -q --tb=short -p no:cacheprovider > $O/pytest_entry.log 2>&1; echo "pytest rc $?" >> $O/pytest_entry.log
+tail -6 $O/pytest_entry.log
+timeout 1500 python tools/cli_e2e.py --images 1024 --out $R/$O/cli_e2e.json > $O/cli_e2e.log 2>&1; tail -8 $O/cli_e2e.log | cut -c1-700
+}
+
 "v$1"
