@@ -79,13 +79,18 @@ class DevicePreprocLoader:
         import collections
         from concurrent.futures import ThreadPoolExecutor
         ahead = max(2 * self.threads, 3 * self.bs)           # images being decoded or waiting: bounds the host memory (~6 MB per 1080p frame)
+        def decode(i):
+            # ... and leave the frame in PAGE-LOCKED memory (torch's caching host allocator recycles the blocks): the consumer's
+            # upload is then an asynchronous DMA instead of a blocking pageable copy (~1 ms per 1080p frame of the consumer's time)
+            img, name = self.ds.raw(i)
+            return torch.from_numpy(np.ascontiguousarray(img)).pin_memory(), name
         with ThreadPoolExecutor(self.threads) as ex:
             todo, futs = iter(self.idx), collections.deque()
 
             def fill():
                 while len(futs) < ahead:
                     try:
-                        futs.append(ex.submit(self.ds.raw, next(todo)))
+                        futs.append(ex.submit(decode, next(todo)))
                     except StopIteration:
                         return
             fill()

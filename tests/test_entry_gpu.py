@@ -24,8 +24,10 @@ def _summation_order_independent_of_the_batch(monkeypatch):
     """Several tests of this file compare schedules of DIFFERENT batch sizes bit for bit (a 4-frame flip schedule against two 2-frame
     forwards, coalesced 6-frame launches against 2-frame ones, the CLI against in-process calls).  That needs the same summation order
     per layer on both sides: they already take the batch-independent heuristic tiles instead of the measured table, and they switch
-    split K off (its number of K parts follows the number of output tiles, i.e. the batch; tests/test_backbone_gpu.py covers it)."""
+    split K off (its number of K parts follows the number of output tiles, i.e. the batch; tests/test_backbone_gpu.py covers it) and name
+    the whole-block launches explicitly (by default a schedule of <= 2 full-size frames runs layer2's blocks as three launches)."""
     monkeypatch.setenv("SMAP_SPLITK", "0")
+    monkeypatch.setenv("SMAP_BLOCK", "64:91,128:94")
 
 
 def test_run_inference_cli_end_to_end(tmp_path, monkeypatch):
@@ -390,6 +392,36 @@ def test_device_preprocess_equals_host_dataset(tmp_path):
         assert torch.equal(got[i].cpu(), want), (name, (got[i].cpu() - want).abs().max().item())
         for k in scale:
             assert scales[k][i] == scale[k]
+
+
+def test_cli_device_preprocess_loader_equals_host_loader(tmp_path):
+    """`test.py --device_preprocess 1` (decode-ahead thread pool, page-locked staging, resize / pad / normalise on the GPU) writes the same
+    result file as the reference's loader path (DataLoader + host resize), record for record, bit for bit -- the pre-processing kernel
+    is bit-exact and the loader keeps the frame order; five images of four sizes, batch 2 (a ragged last batch)."""
+    from model.smap import SMAP
+    imgdir = tmp_path / "imgs"
+    imgdir.mkdir()
+    rng = np.random.default_rng(9)
+    for i, (h, w) in enumerate([(512, 832), (480, 640), (1080, 1920), (1024, 1664), (300, 900)]):
+        np.save(imgdir / f"f{i}.npy", rng.integers(0, 255, (h, w, 3), dtype=np.uint8))
+    torch.manual_seed(0)
+    net = SMAP(make_cfg((128, 208))).eval()
+    sd = recipe_state_dict(net.state_dict())
+    for k in list(sd):
+        if k.endswith("up4.res_conv2.bn.bias"):
+            sd[k] = sd[k] + 40.0
+    torch.save({"model": sd}, tmp_path / "SMAP.pth")
+    res = {}
+    for tag, extra, env_extra in (("host", [], {}), ("device", ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "3"}),
+                                  ("device1", ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "1"})):
+        env = dict(os.environ, PROJECT_HOME=str(tmp_path), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **env_extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "exps", "stage3_root2", "test.py"), "-p", str(tmp_path / "SMAP.pth"),
+                            "-t", "run_inference", "-d", "test", "--batch_size", "2", "--dataset_path", str(imgdir), "--json_name", tag],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[tag] = json.loads((tmp_path / "model_logs" / "stage3_root2" / "result" / f"stage3_root2_run_inference_test_{tag}.json").read_text())
+    assert len(res["host"]["3d_pairs"]) >= 3, "the set-up must produce frames with persons"
+    assert res["device"] == res["host"] and res["device1"] == res["host"]
 
 
 def _annotated_set(tmp_path, net, dev, sizes, seed):
