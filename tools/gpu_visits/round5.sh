@@ -168,4 +168,9 @@ tail -6 $O/pytest_entry.log
 timeout 1500 python tools/cli_e2e.py --images 1024 --out $R/$O/cli_e2e.json > $O/cli_e2e.log 2>&1; tail -8 $O/cli_e2e.log | cut -c1-700
 }
 
+v6() {
+# the round-end validation (tools/gpu_visits/validate_all.sh): whole suite, smoke, every bench line, traces, PMC passes, host budget, CLI
+bash tools/gpu_visits/validate_all.sh r5final
+}
+
 "v$1"

@@ -14,11 +14,12 @@ timeout 400 python bench.py > $O/bench_x3.json 2> $O/bench_x3.err; echo "rc $?" 
 timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_x3_driver_form.json 2>> $O/bench_x3.err
 timeout 400 python bench.py --flip --steps 40 > $O/bench_x3_flip.json 2> $O/bench_x3_flip.err
 timeout 400 python bench.py --refine --steps 60 > $O/bench_x3_refine.json 2> $O/bench_x3_refine.err
-timeout 300 python bench.py --forward-only --batch 1 --steps 200 --warmup 20 > $O/bench_x3_forward_b1.json 2>> $O/bench_x3.err
+timeout 300 python bench.py --forward-only --batch 1 --graph --steps 300 --warmup 30 > $O/bench_x3_forward_b1.json 2>> $O/bench_x3.err
+timeout 300 python bench.py --forward-only --batch 1 --steps 300 --warmup 30 > $O/bench_x3_forward_b1_kernel_by_kernel.json 2>> $O/bench_x3.err
 timeout 300 python bench.py --precision f16 --steps 60 > $O/bench_f16.json 2>> $O/bench_x3.err
 TAG=$TAG python - <<'PY'
 import json, os
-for f in ("bench_x3", "bench_x3_driver_form", "bench_x3_flip", "bench_x3_refine", "bench_x3_forward_b1", "bench_f16"):
+for f in ("bench_x3", "bench_x3_driver_form", "bench_x3_flip", "bench_x3_refine", "bench_x3_forward_b1", "bench_x3_forward_b1_kernel_by_kernel", "bench_f16"):
     try:
         d = json.load(open("gpurun_out/%s/%s.json" % (os.environ["TAG"], f))); c = d["config"]; m = c.get("e2e_parity") or {}
         print(f, round(d["value"], 1), "lf0", c.get("value_launch_frames_0"), "mfma frac", round(d["roofline"]["frac"], 4), "pipe", round(d["roofline"].get("pipe_frac", 0), 4),
@@ -44,3 +45,4 @@ python $R/tools/prof_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv" 
 rm -rf $O/pmc_mfma
 cd $R
 bash tools/host_budget.sh 24 > $O/host_budget.log 2>&1; cat $O/host_budget.log
+timeout 1500 python tools/cli_e2e.py --images 1024 --out $O/cli_e2e.json > $O/cli_e2e.log 2>&1; tail -7 $O/cli_e2e.log | cut -c1-400
