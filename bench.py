@@ -585,8 +585,11 @@ def main():
                                       f"per step)" if pipe.frames_per_launch > B else "")
                                    + "; one end-of-run gather of the records",
                        "frames_per_launch": pipe.frames_per_launch,
-                       # layer1's Bottlenecks and layer2's identity Bottlenecks as ONE launch each (csrc/convb.hip, convc.hip): conv launches per forward 206 -> 167
+                       # layer1's Bottlenecks and layer2's identity Bottlenecks as ONE launch each (csrc/convb.hip, convc.hip), the shared-input 1x1s
+                       # of the Upsample_units as one launch with several outputs: conv launches per forward 206 -> 164 -> 152
                        "whole_block_launches": sum(1 for op in pipe.engine.graph.ops if "head" in op.p),
+                       "conv_launches_per_forward": sum(1 for op in pipe.engine.graph.ops if op.kind == 0),
+                       "merged_1x1_launches": sum(1 for op in pipe.engine.graph.ops if op.outs),
                        # the same steps with ONE backbone launch per step (no coalescing: a batch's records are not held
                        # back for its group), timed in this process right after the headline region
                        "value_launch_frames_0": fps_lf0 if fps_lf0 is not None else (fps if pipe.frames_per_launch == B * (2 if args.flip else 1) else None),
