@@ -412,8 +412,7 @@ def test_cli_device_preprocess_loader_equals_host_loader(tmp_path):
             sd[k] = sd[k] + 40.0
     torch.save({"model": sd}, tmp_path / "SMAP.pth")
     res = {}
-    for tag, extra, env_extra in (("host", [], {}), ("device", ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "3"}),
-                                  ("device1", ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "1"})):
+    for tag, extra, env_extra in (("host", [], {}), ("device", ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "3"})):
         env = dict(os.environ, PROJECT_HOME=str(tmp_path), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **env_extra)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "exps", "stage3_root2", "test.py"), "-p", str(tmp_path / "SMAP.pth"),
                             "-t", "run_inference", "-d", "test", "--batch_size", "2", "--dataset_path", str(imgdir), "--json_name", tag],
@@ -421,7 +420,7 @@ def test_cli_device_preprocess_loader_equals_host_loader(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         res[tag] = json.loads((tmp_path / "model_logs" / "stage3_root2" / "result" / f"stage3_root2_run_inference_test_{tag}.json").read_text())
     assert len(res["host"]["3d_pairs"]) >= 3, "the set-up must produce frames with persons"
-    assert res["device"] == res["host"] and res["device1"] == res["host"]
+    assert res["device"] == res["host"]
 
 
 def _annotated_set(tmp_path, net, dev, sizes, seed):
