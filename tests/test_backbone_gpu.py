@@ -872,6 +872,42 @@ def test_lanes_fork_the_head_chains_and_change_nothing(small, monkeypatch, preci
     assert torch.equal(o0.view(torch.int32), o2.view(torch.int32)) and torch.equal(o0.view(torch.int32), o3.view(torch.int32))
 
 
+def test_split_k_batch_1_full_size_many_runs_bit_for_bit(monkeypatch):
+    """The batch-1 schedule at 512x832 (configs[1]: 34 split-K launches, partial tiles crossing XCDs through agent-scope accesses, no
+    fence) 300 times on two alternating streams: every run must reproduce the first BIT FOR BIT (a partial tile read before it is
+    visible, or a ticket left non-zero, shows here), and agree with the same schedule without split K to the summation-order level."""
+    from smap_amd.engine import BackboneEngine
+    from smap_amd.model.smap import SMAP
+    torch.manual_seed(0)
+    sd = recipe_state_dict(SMAP(make_cfg((128, 208))).state_dict())
+    x = torch.randn(1, 3, 512, 832, generator=torch.Generator().manual_seed(7)).to(DEV)
+    eng = BackboneEngine(sd, 1, 512, 832, DEV, precision="x3")
+    assert sum(1 for op in eng.graph.ops if op.p.get("ksplit", 1) > 1) >= 30
+    sib = eng.sibling()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [eng.new_output(), sib.new_output()]
+    ref = eng.new_output()
+    eng.run(x, out=ref)
+    torch.cuda.synchronize()
+    ref_bits = ref.view(torch.int32).clone()
+    bad = 0
+    for it in range(150):
+        for k, (e, st) in enumerate(((eng, streams[0]), (sib, streams[1]))):      # two executors of the plan in flight: shared tickets? no --
+            with torch.cuda.stream(st):                                           # each has its own arena, hence its own ticket region
+                e.run(x, out=outs[k])
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(outs[0].view(torch.int32), ref_bits)) + int(not torch.equal(outs[1].view(torch.int32), ref_bits))
+    assert bad == 0, bad
+    monkeypatch.setenv("SMAP_SPLITK", "0")
+    plain = BackboneEngine(sd, 1, 512, 832, DEV, precision="x3")
+    assert not any(op.p.get("ksplit", 1) > 1 for op in plain.graph.ops)
+    o = plain.new_output()
+    plain.run(x, out=o)
+    torch.cuda.synchronize()
+    n = eng.out_floats
+    assert (o[:n] - ref[:n]).abs().max().item() <= 2e-5 * ref[:n].abs().max().item()
+
+
 SEG_CASES = [   # B, H, W, Cin, couts, relus, up (low-res size or None), tile
     (2, 13, 21, 256, (256, 64), (1, 1), None, 20),
     (2, 13, 21, 256, (256, 64, 256), (1, 1, 0), None, 21),

@@ -173,4 +173,11 @@ v6() {
 bash tools/gpu_visits/validate_all.sh r5final
 }
 
+v7() {
+# visit 7: the split-K stress test (300 batch-1 forwards on two streams, bit for bit) and the two trimmed tests
+O=gpurun_out/r5v7; mkdir -p $O
+timeout 900 python -m pytest tests/test_backbone_gpu.py tests/test_entry_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "many_runs or split_k or cli_device_preprocess" --durations=8 > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -22 $O/pytest.log
+}
+
 "v$1"
