@@ -22,6 +22,10 @@
 // thread owns 8 consecutive channels of one pixel: residual (16-B load) -> ReLU ->
 // post-ReLU skip adds -> one 16-B fp16 store (or two 16-B fp32 stores), i.e. full
 // coalesced NHWC lines.  One rounding to fp16 per output value.
+//
+// Round 5: N SEGMENTS (smap_op.seg_*: the 1x1 convs of an Upsample_unit that read the same tensor, model/smap.py:210-241, as one
+// launch -- the epilogue picks output tensor / ReLU / channel count / accumulator scale per N tile) and SPLIT K (smap_op.ksplit, template
+// argument SPLITK: the long-K launches of batch-1 schedules, S workgroups per output tile, deterministic reduction by the last arriver).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "smap_hip.h"

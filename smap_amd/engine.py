@@ -14,6 +14,10 @@ floating-point rounding):
     a 1x1 conv + per-channel affine commutes with the (convex, per-channel) bilinear
     resampling, which moves the 256->256 GEMM to the 4x smaller grid;
   * the three 1x1 head convs of stage-2/up4 share their input and run as one N=768 GEMM;
+  * the 1x1 convs of an Upsample_unit that read the same tensor (smap.py:210-241: skip2 | cross_conv / res_conv1 | the next unit's
+    up_conv on `out`; u_skip | skip1 on x where u_skip has no bilinear add) run as ONE launch with one output tensor each (conv_seg);
+  * layer1's Bottlenecks and layer2's identity Bottlenecks run as one launch each (conv_block*, csrc/convb.hip / convc.hip);
+  * small schedules (batch 1): the long-K launches split their K loop over several workgroups per output tile (split_k);
   * residual add, ReLU and the inter-stage skip adds (smap.py:142-153) run in the
     epilogue of the producing conv.
 Activations are NHWC fp16, accumulation fp32, head outputs fp32 (precision "f16"), or -- precision "x3", the mode
