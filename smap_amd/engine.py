@@ -864,8 +864,9 @@ class Graph:
         # Shared-input 1x1s of an Upsample_unit as ONE launch with one output per conv (conv_seg).  Measured (profiles/r5_v1_*): the
         # launches on `out` (skip2 | cross_conv | res_conv1 | the next unit's up_conv) are 3-33 % faster merged than one by one at every
         # level; u_skip | skip1 on x is faster merged where u_skip has no fused bilinear add (up1: 228 vs 244 us at 16 frames) and SLOWER
-        # where it has one (128x208: 712 vs 610 us; 32x52: 277 vs 256): the wide skip1 half then runs under the bilinear epilogue's
-        # register budget.  SMAP_MERGE_1X1: "1" (default) = the merges that pay, "2" = all of them, "0" = one launch per conv.
+        # where it has one (128x208: 712 vs 610 us; 32x52: 277 vs 256): one tile shape must then serve the bilinear epilogue (which wants
+        # the 256-wide tile) and the plain skip1 (which wants the eight-wave 128x128 one).  SMAP_MERGE_1X1: "1" (default) = the merges
+        # that pay, "2" = all of them, "0" = one launch per conv.
         merge_mode = os.environ.get("SMAP_MERGE_1X1", "1")
         merge = merge_mode != "0"
         tl = None                                                 # up_conv@low of the unit at hand (a segment of the previous unit's launch on `out`)
