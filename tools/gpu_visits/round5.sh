@@ -180,4 +180,14 @@ timeout 900 python -m pytest tests/test_backbone_gpu.py tests/test_entry_gpu.py 
 tail -22 $O/pytest.log
 }
 
+v8() {
+# visit 8: what the driver runs at round end, verbatim, on a fresh box: the suite with -x, smoke, the bench with its short form
+O=gpurun_out/r5v8; mkdir -p $O
+timeout 1500 python -m pytest tests/ -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log; tail -5 $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_form.json 2> $O/bench.err; echo "bench rc $?"
+python -c "
+import json; d=json.load(open('$O/bench_driver_form.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['config'].get('conv_launches_per_forward'), d['cpu_baseline']['value'])"
+}
+
 "v$1"
