@@ -181,9 +181,13 @@ def forward_only(args, dev, rank, world, B):
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"batch={B} x 3x512x832 per GPU, SMAP forward only, no association "
                                    f"(BASELINE configs[1] when batch=1)", "frames_per_step": B * world,
-                       "launch": "one HIP graph per forward" if args.graph else "kernel by kernel"},
+                       "launch": "one HIP graph per forward" if args.graph else "kernel by kernel",
+                       "conv_launches_per_forward": sum(1 for op in eng.graph.ops if op.kind == 0),
+                       "split_k_launches": sum(1 for op in eng.graph.ops if op.p.get("ksplit", 1) > 1)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_TFLOPS, "traffic": None,
+                         "flops_executed_per_algorithmic_flop": 3 if args.precision == "x3" else 1,
+                         "pipe_frac": (3 if args.precision == "x3" else 1) * achieved / PEAK_F16_TFLOPS,
                          "kernel": "all backbone launches of the schedule (HIP events around the K schedules)",
                          "algorithmic_gflop_per_frame": ALG_GFLOP_PER_FRAME}}), flush=True)
     if world > 1:
