@@ -229,7 +229,7 @@ typedef struct smap_op {
     int32_t seg_cout[2], seg_relu[2], seg_out_stride_c[2];
     float seg_acc_scale[2];
     int64_t seg_out_off[2];
-    /* SPLIT K (tile ids 2, 20, 22 of csrc/conv.hip; small schedules -- batch 1 -- whose launches have fewer output tiles than the chip has
+    /* SPLIT K (tile ids 2, 7, 20, 22 of csrc/conv.hip; small schedules -- batch 1 -- whose launches have fewer output tiles than the chip has
        CUs): ksplit = S > 1 workgroups per output tile, each over 1/S of the K tiles; their raw fp32 accumulators meet in the scratch
        area at kpart_off (arena bytes: m_tiles * n_tiles * S * BM * BN * 4, BM x BN = smap_conv_tile_dims) and the last workgroup to
        arrive -- one uint32 ticket per tile at kcount_off (arena; smap_plan_run zeroes the tickets of a schedule before its first op,

@@ -548,7 +548,7 @@ extern "C" int smap_conv_tile_bk(int tile, int precision)
     if (smap_conv_tile_dims(tile, &bm, &bn)) return 0;
     if ((tile >= 30 && tile < 50) || (tile >= 80 && tile < 100)) return precision ? 32 : 64;
     if (tile >= 60 && tile < 80) return 32;
-    if (precision) return (tile <= 4 || tile == 52) ? 64 : 32;
+    if (precision) return (tile <= 4 || tile == 7 || tile == 52) ? 64 : 32;
     return ((tile >= 20 && tile <= 27) || tile == 50 || tile == 51 || tile == 53 || tile == 54 || tile == 55) ? 32 : 64;
 }
 
@@ -587,12 +587,12 @@ extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
 }
 
 // tiles that have a split-K instance (both precisions)
-int smap_conv_tile_has_splitk(int tile) { return tile == 2 || tile == 20 || tile == 22; }
+int smap_conv_tile_has_splitk(int tile) { return tile == 2 || tile == 7 || tile == 20 || tile == 22; }
 
 // tiles that have a split-precision instance (plan.hip::validate asks)
 int smap_conv_tile_has_x3(int tile)
 {
-    return (tile >= 0 && tile <= 4) || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 45) || (tile >= 50 && tile <= 55) || (tile >= 60 && tile <= 65) ||
+    return (tile >= 0 && tile <= 4) || tile == 7 || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 45) || (tile >= 50 && tile <= 55) || (tile >= 60 && tile <= 65) ||
            (tile >= 80 && tile <= 82) || (tile >= 90 && tile <= 94);
 }
 
@@ -605,6 +605,7 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
         switch (tile) {
             case 2: return a.x3 ? launch_splitk<64, 64, 2, 2, 2, 64, true>(a, st) : launch_splitk<64, 64, 2, 2, 2, 64, false>(a, st);
             case 22: return a.x3 ? launch_splitk<64, 64, 2, 2, 2, 32, true>(a, st) : launch_splitk<64, 64, 2, 2, 2, 32, false>(a, st);
+            case 7: return a.x3 ? launch_splitk<64, 64, 2, 2, 4, 64, true>(a, st) : launch_splitk<64, 64, 2, 2, 4, 64, false>(a, st);
             case 20: return a.x3 ? launch_splitk<128, 128, 2, 2, 2, 32, true>(a, st) : launch_splitk<128, 128, 2, 2, 2, 32, false>(a, st);
             default: return hipErrorInvalidValue;
         }
@@ -624,6 +625,9 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
             case 24: return launch_x3<128, 128, 2, 2, 3, 32>(a, st);  // 96 KiB, 2 tiles in flight (fp16 id 24 is 4-stage)
             case 25: return launch_x3<128, 64, 2, 2, 3, 32>(a, st);   // 72 KiB, 2 tiles in flight
             case 26: return launch_x3<64, 64, 2, 2, 4, 32>(a, st);    // 64 KiB, 3 tiles in flight
+            case 7: return launch_x3<64, 64, 2, 2, 4, 64>(a, st);     // 128 KiB: THREE 64-half K tiles in flight (round 5: the small grids of batch-1
+                                                                      // schedules leave the LDS of a CU to one workgroup anyway; their K loops are bound by
+                                                                      // the latency of the one tile a two-stage pipeline keeps in flight)
             case 27: return launch_x3<64, 128, 2, 2, 3, 32>(a, st);   // 72 KiB
             case 50: return launch_x3<128, 128, 2, 4, 2, 32>(a, st);  // 64 KiB, 8 waves of 64x32
             case 51: return launch_x3<128, 128, 4, 2, 2, 32>(a, st);  // 64 KiB, 8 waves of 32x64

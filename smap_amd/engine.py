@@ -90,8 +90,8 @@ ALIGN = 256
 ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
 WINDOW = 1 << 32              # csrc/plan.hip SMAP_WINDOW: bytes [k * WINDOW, k * WINDOW + ZERO_PAGE) of the arena are reserved
 PRECISIONS = ("f16", "x3")
-SPLITK_TILES = (2, 20, 22)     # csrc/conv.hip tiles with a split-K instance (smap_conv_tile_has_splitk)
-X3_TILES = (0, 1, 2, 4, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 60, 61, 62, 63, 64, 65)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
+SPLITK_TILES = (2, 7, 20, 22)     # csrc/conv.hip tiles with a split-K instance (smap_conv_tile_has_splitk)
+X3_TILES = (0, 1, 2, 4, 7, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 60, 61, 62, 63, 64, 65)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
 
 
 def split_f16(w, scaled=True):
@@ -178,7 +178,7 @@ def tile_bk(tile, x3):
     if fam == "persist":
         return 32
     if x3:
-        return 64 if tile in (0, 1, 2, 3, 4, 52) else 32
+        return 64 if tile in (0, 1, 2, 3, 4, 7, 52) else 32
     return 32 if tile in (20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 53, 54, 55) else 64
 
 
@@ -536,6 +536,7 @@ class Graph:
             if x3t and cout > 32 and not (cout <= 64 and TILES[int(x3t)][1] > 64):
                 cands = [int(x3t)] + cands
             tile = next(t for t in cands if legal(t))
+            tile = _tile_remap().get(tile, tile)             # A/B hook (SMAP_TILE_REMAP="2:7"): same tile shape, other pipeline depth
         else:
             tile = pick_tile(M, cout, key)
             tile = {**DEFAULT_REMAP, **_tile_remap()}.get(tile, tile)
@@ -605,7 +606,7 @@ class Graph:
             x3t = os.environ.get("SMAP_X3_TILE", "")         # A/B hook, as in Graph.conv
             if x3t:
                 cands = [int(x3t)] + cands
-            tile = next(t for t in cands if legal(t))
+            tile = _tile_remap().get(next(t for t in cands if legal(t)), None) or next(t for t in cands if legal(t))
         else:
             tile = pick_tile(M, sum(couts), key)
             if not legal(tile):

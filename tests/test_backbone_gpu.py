@@ -217,6 +217,9 @@ X3_CASES = [
     (2, 8, 12, 512, 256, 1, 1, 4, True, False, True),
     (2, 16, 24, 64, 256, 1, 1, 24, False, True, False),      # K shorter than the pipeline depth
     (1, 16, 26, 64, 64, 3, 1, 26, True, False, False),
+    (2, 9, 13, 1024, 256, 1, 1, 7, True, True, True),        # tile 7: three 64-half K tiles in flight (batch-1 schedules), long K
+    (1, 16, 26, 64, 64, 3, 2, 7, True, False, False),        #   ... and K shorter than the pipeline (one tile per tap)
+    (3, 10, 14, 192, 320, 3, 1, 7, True, True, True),
     # eight-wave workgroups
     (3, 10, 14, 192, 320, 3, 1, 50, True, True, True),
     (2, 16, 24, 256, 256, 1, 1, 51, True, True, False),
@@ -773,8 +776,8 @@ def test_small_schedule_merged_shared_input_launches(golden_dir, small, monkeypa
 
 
 @pytest.mark.parametrize("precision,tol", [("x3", 2e-5), ("f16", 2e-2)])
-@pytest.mark.parametrize("splitk,x3tile", [("", None), ("0", None), ("3", None), ("3", "2"), ("16", "20")],
-                         ids=["rule", "off", "three_parts", "three_parts_tile2", "sixteen_parts_tile20"])
+@pytest.mark.parametrize("splitk,x3tile", [("", None), ("0", None), ("3", None), ("3", "2"), ("16", "20"), ("5", "7")],
+                         ids=["rule", "off", "three_parts", "three_parts_tile2", "sixteen_parts_tile20", "five_parts_tile7"])
 def test_small_schedule_split_k_launches(golden_dir, small, monkeypatch, splitk, x3tile, precision, tol):
     """Split K (include/smap_hip.h smap_op.ksplit): S workgroups per output tile, each over 1/S of the K tiles, partial tiles summed in
     a fixed order by the last one to arrive -- what the batch-1 schedule runs on its 32x52 / 16x26 levels.  The small schedule has
@@ -799,7 +802,7 @@ def test_small_schedule_split_k_launches(golden_dir, small, monkeypatch, splitk,
     eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=True, precision=precision)
     n_split = sum(1 for op in eng.graph.ops if op.p.get("ksplit", 1) > 1)
     assert n_split == 0 if splitk == "0" else n_split >= (1 if splitk == "" else 30), n_split     # (the rule splits K >= 2048 only)
-    if splitk in ("3", "16"):
+    if splitk in ("3", "5", "16"):
         assert max(op.p.get("ksplit", 1) for op in eng.graph.ops) == int(splitk)
     if x3tile:
         assert sum(1 for op in eng.graph.ops if op.p.get("ksplit", 1) > 1 and op.p["tile"] == int(x3tile)) >= 30

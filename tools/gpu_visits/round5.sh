@@ -190,4 +190,33 @@ python -c "
 import json; d=json.load(open('$O/bench_driver_form.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['config'].get('conv_launches_per_forward'), d['cpu_baseline']['value'])"
 }
 
+v9() {
+# visit 9: tile 7 (64x64, three 64-half K tiles in flight, 128 KiB) for the batch-1 schedule: parity cases, then batch 1 with every
+# tile-2 launch remapped to it, kernel by kernel, as a graph, and per layer
+O=gpurun_out/r5v9; mkdir -p $O
+timeout 900 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "x1x7] or x2x7] or x1x7 or tile7" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log; tail -5 $O/pytest.log
+b1() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$1', round(d['value'],1),'fps', round(d['ms_per_step'],3),'ms/frame', d['config']['launch'])
+"; }
+B1="--forward-only --batch 1 --steps 300 --warmup 30"
+for rep in 1 2; do
+  timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "rep $rep b1 tile 2" >> $O/ab_b1.log
+  SMAP_TILE_REMAP=2:7 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "rep $rep b1 tile 2 -> 7" >> $O/ab_b1.log
+done
+timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "b1 tile 2, graph" >> $O/ab_b1.log
+SMAP_TILE_REMAP=2:7 timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "b1 tile 2 -> 7, graph" >> $O/ab_b1.log
+SMAP_TILE_REMAP=2:7 SMAP_SPLITK=0 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 tile 2 -> 7, no split K" >> $O/ab_b1.log
+SMAP_TILE_REMAP=2:7 SMAP_SPLITK=t512 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 tile 2 -> 7, split K t512 any K" >> $O/ab_b1.log
+cat $O/ab_b1.log; tail -3 $O/ab.err
+cd /tmp
+for rm in "" "2:7"; do
+  SMAP_TILE_REMAP=$rm SMAP_PRECISION=x3 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $R/$O/prof_b1 -o smap -- python $R/bench.py --forward-only --batch 1 --steps 20 --warmup 5 > $R/$O/rocprof_b1.log 2>&1
+  db=$(find $R/$O/prof_b1 -name "*.db" | head -1); (cd $R; SMAP_TILE_REMAP=$rm SMAP_PRECISION=x3 python tools/prof_layers.py $db 1 > $O/layers_b1_remap_$(echo $rm | tr ':' '_').txt 2>&1); rm -rf $R/$O/prof_b1
+done
+tail -22 $R/$O/layers_b1_remap_2_7.txt
+}
+
 "v$1"
