@@ -447,6 +447,18 @@ class Graph:
         self.tensors.append(t)
         return t
 
+    def deep_pipeline_tile(self, tile, M, cout_pad, K):
+        """Tile 2 (64x64, two LDS stages of 64-half K tiles, 64 KiB) -> tile 7 (the same tile with FOUR stages: three K tiles in flight,
+        128 KiB) for launches of at most 256 workgroups.  Such a launch leaves every CU to one workgroup anyway, so the second
+        workgroup's worth of LDS buys prefetch depth instead: the K loops of these launches are bound by the latency of the ONE tile a
+        two-stage pipeline keeps in flight (~1 us per K tile at batch 1).  Measured at batch 1 per shape (profiles/r5_v9_*): -6 .. -21 %
+        on launches of <= 256 workgroups, +31 .. +41 % on launches of 416 (one workgroup per CU instead of two).  SMAP_DEEP_TILE=0: off."""
+        if not self.x3 or tile != 2 or os.environ.get("SMAP_DEEP_TILE", "1") == "0":
+            return tile
+        bm, bn = TILES[2]
+        wgs = -(-M // bm) * (cout_pad // bn) * self.split_k(2, M, cout_pad, K)
+        return 7 if wgs <= 256 else 2
+
     def on_lane(self, lane):
         """Context manager: ops appended inside run on stream lane `lane` (0 when the schedule has no lanes)."""
         import contextlib
@@ -548,6 +560,7 @@ class Graph:
             hbn = int(hbn) if hbn else min(TILES[tile][1], 128 if cout > 64 else 64)
             tile = {(16, 64): 30, (16, 128): 31, (32, 64): 32, (32, 128): 33}[(int(tw), max(hbn, 64))]
             tile += 4 if os.environ.get("SMAP_HALO3_DEEP") else 0
+        tile = self.deep_pipeline_tile(tile, M, _rup(cout, TILES[tile][1]), ksize * ksize * cin)
         bn = TILES[tile][1]
         cout_pad = _rup(cout, bn)
         K = ksize * ksize * cin
@@ -611,6 +624,8 @@ class Graph:
             tile = pick_tile(M, sum(couts), key)
             if not legal(tile):
                 tile = pick_tile_heuristic(M, sum(couts))
+        if tile == 2:                                            # (the deep-pipeline variant of the 64x64 tile for small launches)
+            tile = self.deep_pipeline_tile(2, M, sum(_rup(c, 64) for c in couts), cin)
         bn = TILES[tile][1]
         starts, n = [], 0
         for c in couts:

@@ -219,4 +219,30 @@ done
 tail -22 $R/$O/layers_b1_remap_2_7.txt
 }
 
+v10() {
+# visit 10: the deep-pipeline rule (tile 2 -> 7 for launches of <= 256 workgroups) as shipped: stress test + smoke, batch 1 kernel by
+# kernel / as a graph / per layer
+O=gpurun_out/r5v10; mkdir -p $O
+timeout 900 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "many_runs or full_size_forward_vs_imported" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log; tail -4 $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+b1() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$1', round(d['value'],1),'fps', round(d['ms_per_step'],3),'ms/frame', d['config']['launch'], d['config'].get('split_k_launches'))
+"; }
+B1="--forward-only --batch 1 --steps 300 --warmup 30"
+for rep in 1 2; do
+  SMAP_DEEP_TILE=0 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "rep $rep b1 tile 2 everywhere" >> $O/ab_b1.log
+  timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "rep $rep b1 shipped rule" >> $O/ab_b1.log
+  timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "rep $rep b1 shipped rule, graph" >> $O/ab_b1.log
+done
+cat $O/ab_b1.log; tail -3 $O/ab.err
+timeout 300 python bench.py $B1 --graph > $O/bench_x3_forward_b1.json 2>>$O/ab.err
+cd /tmp
+SMAP_PRECISION=x3 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $R/$O/prof_b1 -o smap -- python $R/bench.py --forward-only --batch 1 --steps 20 --warmup 5 > $R/$O/rocprof_b1.log 2>&1
+db=$(find $R/$O/prof_b1 -name "*.db" | head -1); (cd $R; SMAP_PRECISION=x3 python tools/prof_layers.py $db 1 > $O/layers_b1.txt 2>&1); rm -rf $R/$O/prof_b1
+tail -20 $R/$O/layers_b1.txt
+}
+
 "v$1"
