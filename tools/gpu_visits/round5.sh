@@ -245,4 +245,24 @@ db=$(find $R/$O/prof_b1 -name "*.db" | head -1); (cd $R; SMAP_PRECISION=x3 pytho
 tail -20 $R/$O/layers_b1.txt
 }
 
+v11() {
+# visit 11: batch 1 with layer1's whole-block launches on 4x16 tiles (416 workgroups of half the work instead of 208)
+O=gpurun_out/r5v11; mkdir -p $O
+b1() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$1', round(d['value'],1),'fps', round(d['ms_per_step'],3),'ms/frame', d['config']['launch'])
+"; }
+B1="--forward-only --batch 1 --steps 300 --warmup 30"
+for rep in 1 2; do
+  timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "rep $rep b1 8x16 whole-block tiles, graph" >> $O/ab_b1.log
+  SMAP_BLOCK="64:90" SMAP_BLOCK_FIRST="64:92" timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "rep $rep b1 4x16 whole-block tiles, graph" >> $O/ab_b1.log
+  SMAP_BLOCK="64:90" SMAP_BLOCK_FIRST="64:93" timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "rep $rep b1 4x16 identity blocks, 8x16 first blocks, graph" >> $O/ab_b1.log
+  SMAP_BLOCK="" SMAP_BLOCK_FIRST="" timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "rep $rep b1 layer1 as three launches per block, graph" >> $O/ab_b1.log
+done
+SMAP_BLOCK="64:90" SMAP_BLOCK_FIRST="64:92" timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "b1 4x16 whole-block tiles, kernel by kernel" >> $O/ab_b1.log
+cat $O/ab_b1.log; tail -3 $O/ab.err
+}
+
 "v$1"
