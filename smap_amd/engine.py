@@ -788,15 +788,19 @@ class Graph:
 
     def block_tile(self, planes, stride, has_ds):
         """Tile id of the whole-block launch for this Bottleneck, or None.  Identity blocks (no shortcut conv) of stride 1 in
-        split precision only; SMAP_BLOCK="64:91" chooses per width (A/B hook), default BLOCK_DEFAULT -- without layer2's entry in small
-        schedules: at batch 1 the 64x104 level has 52 tiles of the eight-wave kernel for 256 CUs, 55-57 us per block where the three
-        launches take ~42 (profiles/r5_v2_x3_layers_batch1.txt)."""
+        split precision only; SMAP_BLOCK="64:91" chooses per width (A/B hook), default BLOCK_DEFAULT -- in small schedules (<= 2 frames of
+        512x832) without layer2's entry (at batch 1 the 64x104 level has 52 tiles of the eight-wave kernel for 256 CUs, 55-57 us per block
+        where the three launches take ~42: profiles/r5_v2_x3_layers_batch1.txt) and with layer1's on 4 x 16 pixel tiles (twice the
+        workgroups: profiles/r5_v11_ab_b1_whole_block_tiles.log)."""
         if stride != 1 or has_ds or not self.x3:
             return None
         spec = os.environ.get("SMAP_BLOCK")
         table = BLOCK_DEFAULT if spec is None else {int(k): int(v) for k, v in (kv.split(":") for kv in spec.split(",") if ":" in kv)}
-        if spec is None and planes == 128 and self.B * self.H * self.W <= 2 * 512 * 832:
+        small = self.B * self.H * self.W <= 2 * 512 * 832
+        if spec is None and planes == 128 and small:
             return None
+        if spec is None and planes == 64 and small:
+            return 90                    # 4 x 16 pixel tiles: 416 workgroups of half the work at batch 1 (2.91 -> 2.84 ms per frame)
         return table.get(planes)
 
     # -- the network (smap.py:313-353 structure, :403-419 data flow)
@@ -839,6 +843,8 @@ class Graph:
             return self.conv_block(pre + ".c3", pre, x, blk, add1=add1, add2=add2)
         spec = os.environ.get("SMAP_BLOCK_FIRST")
         first = (BLOCK_FIRST_DEFAULT if spec is None else {int(k): int(v) for k, v in (kv.split(":") for kv in spec.split(",") if ":" in kv)}).get(planes)
+        if spec is None and first == 93 and self.B * self.H * self.W <= 2 * 512 * 832:
+            first = 92                   # small schedules: the 4 x 16 tiles here too
         if first is not None and self.x3 and has_ds and stride == 1 and x.C == 64 and planes == 64 and add1 is None and add2 is None:
             return self.conv_block_first(pre + ".c3", pre, x, first)
         idn = self.conv(pre + ".downsample", [pre + ".downsample"], x, 1, stride, relu=False) if has_ds else x

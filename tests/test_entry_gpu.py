@@ -25,9 +25,11 @@ def _summation_order_independent_of_the_batch(monkeypatch):
     forwards, coalesced 6-frame launches against 2-frame ones, the CLI against in-process calls).  That needs the same summation order
     per layer on both sides: they already take the batch-independent heuristic tiles instead of the measured table, and they switch
     split K off (its number of K parts follows the number of output tiles, i.e. the batch; tests/test_backbone_gpu.py covers it) and name
-    the whole-block launches explicitly (by default a schedule of <= 2 full-size frames runs layer2's blocks as three launches)."""
+    the whole-block launches explicitly (by default a schedule of <= 2 full-size frames runs layer2's blocks as three launches and layer1's
+    on 4 x 16 pixel tiles)."""
     monkeypatch.setenv("SMAP_SPLITK", "0")
     monkeypatch.setenv("SMAP_BLOCK", "64:91,128:94")
+    monkeypatch.setenv("SMAP_BLOCK_FIRST", "64:93")
 
 
 def test_run_inference_cli_end_to_end(tmp_path, monkeypatch):

@@ -60,7 +60,7 @@ def test_x3_graph_emits_split_strides_and_weights(small_sd, monkeypatch, blocks)
         if op.kind == OP_CONV:
             x, y = op.inp, op.out
             assert x.planes == 2 and o.in_stride_c == 2 * x.C and o.in_c_off + o.Cin <= x.C
-            assert o.tile in X3_TILES + (3,) + tuple(range(30, 46)) + (91, 93, 94) and o.acc_scale > 0
+            assert o.tile in X3_TILES + (3,) + tuple(range(30, 46)) + (90, 91, 92, 93, 94) and o.acc_scale > 0
             assert (y.planes, o.out_stride_c) == ((1, y.C) if o.out_fp32 else (2, 2 * y.C))
             assert o.in_off >= ZERO_PAGE and o.Cin * 2 + o.in_stride_c + 16 <= ZERO_PAGE
             for t in (op.res, op.add1, op.add2):

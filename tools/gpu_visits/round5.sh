@@ -265,4 +265,22 @@ SMAP_BLOCK="64:90" SMAP_BLOCK_FIRST="64:92" timeout 300 python bench.py $B1 2>>$
 cat $O/ab_b1.log; tail -3 $O/ab.err
 }
 
+v12() {
+# visit 12: the final batch-1 schedule (4x16 whole-block tiles in small schedules) -- parity at full size, stress, entry tests, smoke, bench lines
+O=gpurun_out/r5v12; mkdir -p $O
+timeout 900 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "many_runs or full_size or lanes or graph_replay" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log; tail -4 $O/pytest.log
+timeout 900 python -m pytest tests/test_entry_gpu.py tests/test_abi_gpu.py -m gpu -q --tb=short -p no:cacheprovider > $O/pytest_entry.log 2>&1; echo "pytest rc $?" >> $O/pytest_entry.log; tail -4 $O/pytest_entry.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+timeout 300 python bench.py --forward-only --batch 1 --graph --steps 300 --warmup 30 > $O/bench_x3_forward_b1.json 2>>$O/ab.err
+timeout 300 python bench.py --forward-only --batch 1 --steps 300 --warmup 30 > $O/bench_x3_forward_b1_kernel_by_kernel.json 2>>$O/ab.err
+python -c "
+import json
+for f in ('bench_x3_forward_b1','bench_x3_forward_b1_kernel_by_kernel'):
+    d=json.load(open('$O/'+f+'.json')); print(f, round(d['value'],1), round(d['ms_per_step'],3), d['config'])"
+cd /tmp
+SMAP_PRECISION=x3 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $R/$O/prof_b1 -o smap -- python $R/bench.py --forward-only --batch 1 --steps 20 --warmup 5 > $R/$O/rocprof_b1.log 2>&1
+db=$(find $R/$O/prof_b1 -name "*.db" | head -1); (cd $R; SMAP_PRECISION=x3 python tools/prof_layers.py $db 1 > $O/layers_b1.txt 2>&1); rm -rf $R/$O/prof_b1
+tail -18 $R/$O/layers_b1.txt
+}
+
 "v$1"
