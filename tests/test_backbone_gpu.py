@@ -794,7 +794,8 @@ def test_small_schedule_split_k_launches(golden_dir, small, monkeypatch, splitk,
     if x3tile:
         if precision != "x3":
             pytest.skip("SMAP_X3_TILE forces split-precision tiles")
-        monkeypatch.setenv("SMAP_X3_TILE", x3tile)       # the other two tiles with a split-K instance (2: what batch 1 at 512x832 runs)
+        monkeypatch.setenv("SMAP_X3_TILE", x3tile)       # the other tiles with a split-K instance (2 / 7: what batch 1 at 512x832 runs)
+        monkeypatch.setenv("SMAP_DEEP_TILE", "0")        # (keep tile 2 where it is asked for: the rule would turn these small launches into tile 7)
     monkeypatch.setenv("SMAP_BLOCK", "")                 # layer by layer: more launches of the kernel under test
     monkeypatch.setenv("SMAP_BLOCK_FIRST", "")
     z = np.load(f"{golden_dir}/backbone_small.npz")
