@@ -190,3 +190,27 @@ def test_no_kernel_reads_the_dispatch_packet_or_uses_scratch(tmp_path):
                 assert v is not None and int(v.group(1)) == 0, (src, name, field, v and v.group(1))
             n += 1
     assert n >= 100          # conv.hip alone instantiates ~90 kernels
+
+
+def test_status_words_follow_the_frame_count():
+    """SMAP_STATUS_WORDS(frames) int32 words behind the maps (one bit per output frame, 31 per word): the packer, the blob header and the
+    library's own sizing agree for launches of 1, 31, 32 and 40 frames."""
+    import ctypes as C
+    from recipe import recipe_state_dict
+    from smap_amd import lib as L
+    from smap_amd.engine import Graph
+    from smap_amd.model.smap import SMAP
+    lib = L.load()
+    torch.manual_seed(0)
+    sd = recipe_state_dict(SMAP(make_cfg((16, 24))).state_dict())
+    for frames, words in ((1, 1), (31, 1), (32, 2), (40, 2)):
+        g = Graph(sd, frames, 64, 96, precision="x3")
+        g.allocate()
+        assert g.status_words == words
+        blob = g.blob()
+        plan, info = C.c_void_p(), L.BlobInfo()
+        assert lib.smap_plan_create_from_blob(blob, len(blob), C.byref(plan), C.byref(info)) == 0
+        assert info.out_bytes == g.out_bytes + 4 * words and info.status_off == g.out_bytes
+        ob = C.c_int64()
+        assert lib.smap_workspace_bytes(plan, None, C.byref(ob)) == 0 and ob.value == info.out_bytes
+        lib.smap_plan_destroy(plan)

@@ -404,3 +404,107 @@ def test_people_weights_are_calibrated_data_not_weights():
     changed = sorted(k for k in a if not torch.equal(a[k], b[k]))
     assert changed == ["stage2.upsample.up4.res_conv2.bn.bias", "stage2.upsample.up4.res_conv2.bn.weight",
                        "stage2.upsample.up4.res_rd_conv2.bn.bias", "stage2.upsample.up4.res_rd_conv2.bn.weight"]
+
+
+# ------------------------------------------------------------------ round 5: merged launches, split K, small-schedule rules, lanes
+def _full_size_sd():
+    from types import SimpleNamespace as NS
+    from smap_amd.model.smap import SMAP
+    cfg = NS(MODEL=NS(STAGE_NUM=3, UPSAMPLE_CHANNEL_NUM=256), DATASET=NS(KEYPOINT=NS(NUM=15), PAF=NS(NUM=14)),
+             OUTPUT_SHAPE=(128, 208), LOSS=NS(OHKM=True, TOPK=8, COARSE_TO_FINE=True))
+    torch.manual_seed(0)
+    return SMAP(cfg).state_dict()
+
+
+def test_batch_1_schedule_rules_and_arena(monkeypatch):
+    """What the batch-1 schedule (BASELINE configs[1]) is made of, without a GPU: split K only on the long-K launches of the coarse
+    levels (K >= 2048, <= 4 parts, workgroups x parts <= 256 there), the four-stage 64x64 tile exactly on the launches of <= 256
+    workgroups, layer1's whole blocks on 4x16 tiles, layer2's as three launches; every split op has its own scratch and ticket slice,
+    scratch and tickets never share bytes with a live tensor; the library accepts the plan; with lanes on, every wait names an earlier
+    op of another lane and nothing a side-lane op touches is reused before the end of the schedule."""
+    import ctypes as C
+    from smap_amd import lib as L
+    from smap_amd.engine import Graph, OP_CONV, TILES, tile_bk
+    sd = _full_size_sd()
+    for lanes in ("0", "1"):
+        monkeypatch.setenv("SMAP_LANES", lanes)
+        g = Graph(sd, 1, 512, 832, precision="x3")
+        g.allocate()
+        ops = g.emit()
+        convs = [(op, o) for op, o in zip(g.ops, ops) if op.kind == OP_CONV]
+        assert sorted({op.p["tile"] for op, _ in convs if op.p["tile"] >= 90}) == [90, 92]              # layer1: 4 x 16 tiles; no tile 94
+        split = [(op, o) for op, o in convs if o.ksplit > 1]
+        assert 30 <= len(split) <= 40
+        tickets = set()
+        for op, o in split:
+            K = o.ksize * o.ksize * o.Cin
+            bm, bn = TILES[o.tile]
+            tiles = -(-(o.B * o.Ho * o.Wo) // bm) * (o.cout_pad // bn)
+            assert K >= 2048 and 2 <= o.ksplit <= 4 and tiles * o.ksplit <= 256 and o.ksplit <= K // tile_bk(o.tile, True)
+            assert o.kpart_off == op.scratch[0].off and op.scratch[0].nbytes == tiles * o.ksplit * bm * bn * 4
+            lo = o.kcount_off
+            assert g.kcount.off <= lo and lo + 4 * tiles <= g.kcount.off + g.kcount.nbytes
+            assert not tickets & set(range(lo, lo + 4 * tiles, 4))
+            tickets |= set(range(lo, lo + 4 * tiles, 4))
+        for op, o in convs:                                        # the deep-pipeline rule
+            if o.tile in (2, 7):
+                wgs = -(-(o.B * o.Ho * o.Wo) // 64) * (o.cout_pad // 64) * max(1, o.ksplit)
+                assert (o.tile == 7) == (wgs <= 256), (op.out.name, wgs)
+        every = g.tensors + g.scratch_tensors + [g.kcount]
+        live = sorted((t.first, t.last, t.off, t.off + t.nbytes, t.name) for t in every)
+        for i, a in enumerate(live):
+            for b in live[i + 1:]:
+                if b[0] > a[1]:
+                    break
+                assert a[3] <= b[2] or b[3] <= a[2], (a[4], b[4])
+        n = len(g.ops)
+        if lanes == "1":
+            assert sorted({op.lane for op in g.ops}) == [0, 1, 2]
+            for i, (op, o) in enumerate(zip(g.ops, ops)):
+                for k in range(o.n_wait):
+                    assert 0 <= o.wait_op[k] < i and ops[o.wait_op[k]].lane != o.lane
+                if op.lane:
+                    for t in [op.inp, op.res, op.add1, op.add2] + list(op.aux):
+                        assert t is None or t.last == n - 1
+        else:
+            assert all(o.lane == 0 and o.n_wait == 0 for o in ops)
+        h = C.c_void_p()
+        assert L.load().smap_plan_create(ops, n, C.byref(h)) == 0
+        assert L.load().smap_plan_set_lanes(h, int(lanes)) == 0
+        L.load().smap_plan_destroy(h)
+
+
+def test_merged_launch_descriptors_and_validation(small_sd, monkeypatch):
+    """Graph.conv_seg -> smap_op.seg_*: segment starts are multiples of the tile's N extent and in order, every segment has its own
+    output tensor / scale, the plan validates -- and refuses a segment that is mis-aligned, overlaps the next one, or sits on a tile
+    family without the per-segment epilogue."""
+    import ctypes as C
+    from smap_amd import lib as L
+    from smap_amd.engine import Graph, OP_CONV, TILES
+    for merge, n in (("2", 18), ("1", 12), ("0", 0)):
+        monkeypatch.setenv("SMAP_MERGE_1X1", merge)
+        g = Graph(small_sd, 2, 64, 96, precision="x3")
+        g.allocate()
+        ops = g.emit()
+        segd = [(op, o) for op, o in zip(g.ops, ops) if op.kind == OP_CONV and o.seg_n[0] > 0]
+        assert len(segd) == n
+        for op, o in segd:
+            bn = TILES[o.tile][1]
+            starts = [s for s in o.seg_n if s > 0]
+            assert starts == sorted(starts) and all(s % bn == 0 for s in starts) and o.Cout <= starts[0] and o.ksize == 1
+            for j, t in enumerate(op.outs):
+                assert o.seg_out_off[j] == t.off and o.seg_cout[j] == t.C and o.seg_out_stride_c[j] == 2 * t.C and o.seg_acc_scale[j] > 0
+            assert len({op.out.off} | {t.off for t in op.outs}) == 1 + len(op.outs)
+        h = C.c_void_p()
+        assert L.load().smap_plan_create(ops, len(g.ops), C.byref(h)) == 0
+        L.load().smap_plan_destroy(h)
+        if segd:
+            i = next(k for k, op in enumerate(g.ops) if op.outs)
+            for field, val in (("seg_n", ops[i].seg_n[0] + 8), ("seg_cout", ops[i].seg_cout[0] + 4), ("tile", 60), ("ksize", 3)):
+                bad = (L.SmapOp * len(g.ops))()
+                C.memmove(bad, ops, C.sizeof(bad))
+                if field in ("seg_n", "seg_cout"):
+                    getattr(bad[i], field)[0] = val
+                else:
+                    setattr(bad[i], field, val)
+                assert L.load().smap_plan_create(bad, len(g.ops), C.byref(h)) != 0, field
