@@ -291,4 +291,10 @@ python -m pytest tests/test_backbone_gpu.py --collect-only -q -m gpu 2>/dev/null
 timeout 900 python -m pytest $(cat $O/ids.txt) tests/test_e2e_parity_gpu.py tests/test_ref_gpu.py -m gpu -q --tb=short -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log; tail -6 $O/pytest.log
 }
 
+v14() {
+# visit 14: the split-K schedule tests after the test fix of visit 13 (the one the driver's -x run would have stopped at)
+O=gpurun_out/r5v14; mkdir -p $O
+timeout 300 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "small_schedule_split_k" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log; tail -5 $O/pytest.log
+}
+
 "v$1"
