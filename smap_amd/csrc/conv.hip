@@ -56,9 +56,17 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // tools/ubench/mfma_issue.hip; what it cannot do is hide its own stalls).
 // SPLITK = true: the instance that also takes a.ksplit > 1 (its own template argument: the extra paths cost the plain instances
 // registers and 4 bytes of LDS that tip 80 KiB tiles from two workgroups per CU to one).
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3, bool SPLITK = false>
+// REGEPI = true (round 6, tile 56 = 256 x 256): REGISTER epilogue.  The fp32 [BM][BN] staging tile of the LDS epilogue would be 256 KiB, and
+// what this tile is for -- halving the L2 -> LDS bytes per MFMA of the N >= 256 launches (341 B at 128 x 128, 170 B at 256 x 256) --
+// needs all the LDS for its two 64 KiB stages.  The MFMA operands are swapped (weights first: accumulator rows = channels, columns =
+// pixels), a half-wave swap (v_permlane32_swap) leaves every lane with 8 consecutive channels of one pixel, and bias (as the
+// accumulators' start value, b / 2^-s: exact), residual, ReLU and the hi | lo split happen in registers: 16-byte loads and stores
+// straight from / to the NHWC tensors (convp.hip's and convc.hip's epilogue).  Split precision, fp16 outputs, no fused bilinear add
+// or post-ReLU addends, no split K; N segments as everywhere.
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3, bool SPLITK = false, bool REGEPI = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a)
 {
+    static_assert(!REGEPI || (X3 && !FULL && !SPLITK), "register epilogue: split precision, plain epilogue, no split K");
     constexpr int NPL = X3 ? 2 : 1;                    // fp16 planes per operand
     constexpr int NW = WM * WN, NT = NW * 64;          // waves, threads
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     constexpr int STAGE = NPL * (BM + BN) * ROWB;      // [A planes][B planes]
     constexpr int LPT = NPL * (LA + LB);               // LDS-DMA loads per thread per K tile
     static_assert((STAGES - 2) * LPT <= 63, "vmcnt is 6 bits");
-    constexpr int LDS_BYTES = (STAGES * STAGE > BM * BN * 4 ? STAGES * STAGE : BM * BN * 4) + (SPLITK ? 16 : 0);   // pipeline | fp32 epilogue tile (+ the split-K flag)
+    constexpr int LDS_BYTES = REGEPI ? STAGES * STAGE : (STAGES * STAGE > BM * BN * 4 ? STAGES * STAGE : BM * BN * 4) + (SPLITK ? 16 : 0);   // pipeline | fp32 epilogue tile (+ the split-K flag)
     static_assert(LDS_BYTES <= 160 * 1024, "LDS is 160 KiB per CU");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     //      requested before the K loop so that its HBM latency hides under the whole main loop
     //      (a pass-by-pass load in the epilogue exposes one full memory round trip per pass).
     constexpr int CG = BN / 8;                    // channel groups per row
-    constexpr int PASSES = BM * CG / NT;
+    constexpr int PASSES = REGEPI ? 1 : BM * CG / NT;       // (register epilogue: the residual is loaded block by block down there)
     static_assert(BM * CG % NT == 0, "tile/thread mismatch");
     half8 rres[PASSES][NPL];
     auto load_res = [&]() {
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
                 rres[p][pl] = *reinterpret_cast<const half8*>(o_res + dense + pl * o_cout8);
         }
     };
-    if (o_res && !SPLITK) load_res();                          // (split K: only the workgroup that runs the epilogue needs it)
+    if (o_res && !SPLITK && !REGEPI) load_res();               // (split K: only the workgroup that runs the epilogue needs it)
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -277,6 +285,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
+    if (REGEPI) {       // accumulator rows are CHANNELS here: row r of block ni = channel n0 + wn*(BN/WN) + ni*32 + (r&3) + 8*(r>>2) + 4*lhi; start value b / 2^-s
+        const float inv = 1.f / o_scale;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n0 + wn * (BN / WN) + ni * 32 + 8 * q + 4 * lhi);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    acc[mi][ni][4 * q + 0] = b4.x * inv; acc[mi][ni][4 * q + 1] = b4.y * inv;
+                    acc[mi][ni][4 * q + 2] = b4.z * inv; acc[mi][ni][4 * q + 3] = b4.w * inv;
+                }
+            }
+    }
     const int rswz = BK == 64 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
     const int a_row0 = wm * (BM / WM) + l31;     // + mi*32
     const int b_row0 = wn * (BN / WN) + l31;     // + ni*32
@@ -323,6 +345,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
+                    if (REGEPI) {   // weights first: D rows = channels, columns = pixels (same products, same order)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0][ni], af[NPL - 1][mi], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[NPL - 1][ni], af[0][mi], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0][ni], af[0][mi], acc[mi][ni], 0, 0, 0);
+                        continue;
+                    }
                     if (X3) {       // small cross terms first, then hi*hi
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[NPL - 1][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][mi], bf[NPL - 1][ni], acc[mi][ni], 0, 0, 0);
@@ -337,6 +365,79 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     __syncthreads();   // everyone is done reading the staging buffers
     if (SMAP_ABLATE & 8) {
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(a.out)[tid] = acc[0][0][1];   // keep acc live
+        return;
+    }
+
+    if constexpr (REGEPI) {
+        // ---- register epilogue: per (pixel block mi, channel block ni) the half-wave swap turns acc[8j .. 8j+7] into channels
+        //      n_lane + 16j .. +7 of pixel m0 + wm*(BM/WM) + mi*32 + l31; the residual of block (mi, ni) is requested one block ahead.
+        _Float16* const outp = reinterpret_cast<_Float16*>(o_out);
+        unsigned m_dense[MI], m_out[MI];
+        bool m_ok[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wm * (BM / WM) + mi * 32 + l31;
+            m_ok[mi] = m < a.M;
+            const unsigned ms = m_ok[mi] ? (unsigned)m : 0u;
+            m_dense[mi] = ms * (unsigned)(NPL * o_cout8);
+            m_out[mi] = ms * (unsigned)o_stride + (unsigned)o_c_off;
+        }
+        auto n_of = [&](int ni) { return nb + wn * (BN / WN) + ni * 32 + 8 * lhi; };        // + 16 j
+        auto load_rr = [&](int mi, int ni, half8 (&rr)[2][NPL]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n_of(ni) + 16 * j;
+                const unsigned d = n < o_cout8 ? m_dense[mi] + (unsigned)n : 0u;          // (clamped: the load stays in bounds)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) rr[j][pl] = *reinterpret_cast<const half8*>(o_res + d + pl * o_cout8);
+            }
+        };
+        half8 rr[2][2][NPL];
+        if (o_res) load_rr(0, 0, rr[0]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                constexpr int NB = MI * NI;
+                const int blk = mi * NI + ni;
+                if (o_res && blk + 1 < NB) load_rr((blk + 1) / NI, (blk + 1) % NI, rr[(blk + 1) & 1]);
+                f32x16& c = acc[mi][ni];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xf = c[8 * j + e], yf = c[8 * j + 4 + e];
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf), __float_as_uint(yf), false, false);
+                        const unsigned s0 = sw[0], s1 = sw[1];
+                        c[8 * j + e] = o_scale * __uint_as_float(s0);                       // (bias inside)
+                        c[8 * j + 4 + e] = o_scale * __uint_as_float(s1);
+                    }
+                if (o_res) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) c[8 * j + e] += (float)rr[blk & 1][j][0][e] + (float)rr[blk & 1][j][NPL - 1][e];
+                }
+                if (o_relu) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = c[r] < 0.f ? 0.f : c[r];            // NaN stays NaN (torch's ReLU)
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n_of(ni) + 16 * j;
+                    if (!m_ok[mi] || n >= o_cout8 || ((SMAP_ABLATE & 4) && a.M != 7)) continue;
+                    _Float16* op = outp + (m_out[mi] + (unsigned)n);
+                    half8 h, l;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        h[e] = (_Float16)c[8 * j + e];
+                        l[e] = (_Float16)(c[8 * j + e] - (float)h[e]);
+                    }
+                    *reinterpret_cast<half8*>(op) = h;
+                    *reinterpret_cast<half8*>(op + o_lo) = l;
+                }
+            }
+        SMAP_TL_END(a)
         return;
     }
 
@@ -540,6 +641,15 @@ hipError_t launch_x3(const ConvArgs& a, hipStream_t st)
 
 }  // namespace
 
+// the register-epilogue instance (tile 56): split precision, plain epilogue only (plan.hip::validate keeps everything else away)
+template <int BM, int BN, int WM, int WN, int STAGES, int BK>
+hipError_t launch_regepi(const ConvArgs& a, hipStream_t st)
+{
+    if (!a.x3 || a.up || a.add1 || a.add2 || a.out_fp32 || a.ksplit > 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, true, false, true>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+    return hipGetLastError();
+}
+
 // halves per staged K tile (= the packing unit of the weight blob, include/smap_hip.h); mirrors the BK template arguments
 // of smap_launch_conv below and smap_amd/engine.py::tile_bk (tests/test_host_cpu.py compares the two)
 extern "C" int smap_conv_tile_bk(int tile, int precision)
@@ -577,6 +687,7 @@ extern "C" int smap_conv_tile_dims(int tile, int* bm, int* bn)
         case 50: case 51: case 52: *bm = 128; *bn = 128; return 0;   // 50..54: eight-wave workgroups
         case 53: *bm = 256; *bn = 128; return 0;
         case 54: *bm = 128; *bn = 256; return 0;
+        case 56: *bm = 256; *bn = 256; return 0;                    // 56: eight waves of 128 x 64, register epilogue (split precision only)
         case 0: case 5: *bm = 128; *bn = 128; return 0;
         case 1: case 6: *bm = 128; *bn = 64; return 0;
         case 2: case 7: *bm = 64; *bn = 64; return 0;
@@ -592,7 +703,7 @@ int smap_conv_tile_has_splitk(int tile) { return tile == 2 || tile == 7 || tile 
 // tiles that have a split-precision instance (plan.hip::validate asks)
 int smap_conv_tile_has_x3(int tile)
 {
-    return (tile >= 0 && tile <= 4) || tile == 7 || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 45) || (tile >= 50 && tile <= 55) || (tile >= 60 && tile <= 65) ||
+    return (tile >= 0 && tile <= 4) || tile == 7 || (tile >= 20 && tile <= 27) || (tile >= 30 && tile <= 45) || (tile >= 50 && tile <= 56) || (tile >= 60 && tile <= 65) ||
            (tile >= 80 && tile <= 82) || (tile >= 90 && tile <= 94);
 }
 
@@ -635,6 +746,7 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
             case 53: return launch_x3<256, 128, 4, 2, 2, 32>(a, st);  // 96 KiB, 8 waves of 64x64
             case 54: return launch_x3<128, 256, 2, 4, 2, 32>(a, st);  // 96 KiB, 8 waves of 64x64
             case 55: return launch_x3<128, 128, 2, 4, 4, 32>(a, st);  // 128 KiB: 8 waves, 3 K tiles (96 KiB) in flight
+            case 56: return launch_regepi<256, 256, 2, 4, 2, 32>(a, st);   // 128 KiB: 8 waves of 128 x 64, two 64 KiB stages, register epilogue
             default: return hipErrorInvalidValue;
         }
     }

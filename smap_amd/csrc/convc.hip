@@ -30,8 +30,19 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
+
+// Residual chunks (of four) whose values are copied into registers while x streams through LDS in phase 1; the others are read again from
+// L2 / Infinity Cache while their chunk of the tail is multiplied.  Round 6: 2 (64 registers) instead of 3 (96) -- the registers pay for a
+// SECOND fragment set in every phase (the software pipeline below).
+#ifndef SMAP_CONVC_NRS
+#define SMAP_CONVC_NRS 2
+#endif
+#ifndef SMAP_CONVC_PIPE
+#define SMAP_CONVC_PIPE 1          // 0 = round 5's loops (fragments single-buffered, read -> wait -> multiply inside every K step)
+#endif
 
 __device__ __forceinline__ void wait_vm(int n)
 {
@@ -44,9 +55,18 @@ __device__ __forceinline__ void wait_vm(int n)
 }
 
 // every LDS read of this wave has returned, then the workgroup barrier (raw: an LDS-DMA in flight must survive it)
+// all LDS reads of this wave have landed (the builtin: hipcc's wait-count pass sees it and adds no lgkmcnt(0) of its own further down)
+__device__ __forceinline__ void lds_reads_landed() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
 __device__ __forceinline__ void lds_barrier()
 {
+#if SMAP_CONVC_PIPE
+    // the BUILTIN, not inline asm: hipcc's wait-count pass then knows that the fragment set read before the barrier has landed and puts no
+    // lgkmcnt(0) in front of the MFMAs that use it behind the barrier (gfx9 encoding: vmcnt = 63 and expcnt = 7 "don't wait", lgkmcnt = 0)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -145,8 +165,9 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
     // nc*128 + wn*32 + 16*j + 8*lhi .. +7 of pixel (mi, l31) -- the layout the register epilogue of phase 3 ends in
     // Chunks 0 .. NRS-1 only: 128 + the 48 accumulators of phase 1 + fragments and addresses do not fit 256 registers without scratch,
     // the last chunk's residual is read again (from L2 / Infinity Cache) while that chunk is multiplied: 3584 instead of 4096 B/px saved.
-    constexpr int NRS = NCH3 - 1;
-    half8 rs[NRS][MI][2][2];
+    constexpr int NRS = SMAP_CONVC_NRS;
+    static_assert(NRS >= 0 && NRS < NCH3, "residual chunks held in registers");
+    half8 rs[NRS > 0 ? NRS : 1][MI][2][2];
 
     // Biases enter through the ACCUMULATORS (acc = b / 2^-s before the first MFMA; the power-of-two scale makes that exact): an
     // ordinary global load in the middle of the LDS-DMA pipeline would make hipcc drain the whole queue (vmcnt(0)) at its use.
@@ -170,6 +191,68 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
     }
     const int fswz = (l31 >> 1) & 7;                            // (row >> 1) & 7 of every fragment row = multiple of 32 + l31
 
+#if SMAP_CONVC_PIPE
+    // SOFTWARE PIPELINE (round 6).  Round 5's loops read a K step's fragments, waited for them and multiplied, step after step: hipcc
+    // turns that into `ds_read x2-4, s_waitcnt lgkmcnt(0), mfma x1-4` groups -- an LDS round trip exposed five or six times per barrier
+    // interval, in BOTH waves of a SIMD at once (they walk in step), which is where the tile's 105k non-MFMA cycles of 163k came from
+    // (EXPERIMENTS R4.1b, R6.1).  Now every phase keeps TWO fragment sets: the reads of K step u + 1 go out, then step u is multiplied
+    // from registers that landed half a barrier interval ago.  The first reads behind a barrier hide under the previous interval's last
+    // MFMAs.  Same MFMAs in the same order: bit-identical results.  The second set costs 32 / 24 registers; they come from the residual
+    // (SMAP_CONVC_NRS = 2 chunks in registers instead of 3).
+    half8 w1a[2], x1a[NB1][2], w1b[2], x1b[NB1][2];
+    auto rd1 = [&](int ks, int kk, half8 (&wf)[2], half8 (&xf)[NB1][2]) {
+        const char* sX = smem + (ks % NS1) * ST1;
+        const char* sW = sX + XS;
+        const int g = kk * 2 + lhi;
+        const int slot0 = (g ^ fswz) << 4, slot1 = ((g + 4) ^ fswz) << 4;
+        wf[0] = *reinterpret_cast<const half8*>(sW + (wn * 32 + l31) * ROWB + slot0);
+        wf[1] = *reinterpret_cast<const half8*>(sW + (wn * 32 + l31) * ROWB + slot1);
+#pragma unroll
+        for (int j = 0; j < NB1; ++j) {
+            const char* xr = sX + ((wm * NB1 + j) * 32 + l31) * ROWB;
+            xf[j][0] = *reinterpret_cast<const half8*>(xr + slot0);
+            xf[j][1] = *reinterpret_cast<const half8*>(xr + slot1);
+        }
+    };
+    auto mm1 = [&](const half8 (&wf)[2], const half8 (&xf)[NB1][2]) {      // small cross terms first, then hi*hi (conv3.hip's order)
+#pragma unroll
+        for (int j = 0; j < NB1; ++j) {
+            acc1[j] = MFMA_(wf[0], xf[j][1], acc1[j]);
+            acc1[j] = MFMA_(wf[1], xf[j][0], acc1[j]);
+            acc1[j] = MFMA_(wf[0], xf[j][0], acc1[j]);
+        }
+    };
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+        if (ks + NS1 - 1 <= KS1) wait_vm((NS1 - 2) * LPT1);     // stage ks has landed; younger stages stay in flight
+        else wait_vm((KS1 - 1 - ks) * LPT1);
+        lds_barrier();
+        if (ks + NS1 - 1 < KS1) issue1((ks + NS1 - 1) % NS1, ks + NS1 - 1);     // into the buffer stage ks-1 was read from
+        rd1(ks, 0, w1a, x1a);
+        if ((ks >> 2) < NRS && (ks & 3) == wn) {                // this wave's residual channels: nc*128 + wn*32 + .. = stage 4 nc + wn
+            const char* sX = smem + (ks % NS1) * ST1;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                int cr = crow[mi];
+                asm volatile("" : "+v"(cr));                    // addresses computed HERE, four times per wave (registers)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        rs[ks >> 2][mi][j][pl] = *reinterpret_cast<const half8*>(sX + cr * ROWB + (((2 * j + lhi + 4 * pl) ^ ((cr >> 1) & 7)) << 4));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks > 0) mm1(w1b, x1b);                              // K step (ks - 1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        lds_reads_landed();                                     // set a, under the MFMAs above (hipcc would wait for a AND b after the next reads)
+        rd1(ks, 1, w1b, x1b);
+        __builtin_amdgcn_sched_barrier(0);
+        mm1(w1a, x1a);                                          // K step (ks, 0)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mm1(w1b, x1b);
+#else
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
         if (ks + NS1 - 1 <= KS1) wait_vm((NS1 - 2) * LPT1);     // stage ks has landed; younger stages stay in flight
@@ -208,6 +291,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
             }
         }
     }
+#endif
     lds_barrier();                                              // every wave is done with the staging buffers (all DMA has landed)
     // phase 2's accumulators start at b2 / scale: the loads go out now, ahead of the first weight slots
     float4 b2v[4];
@@ -281,6 +365,48 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
     for (int mi = 0; mi < MI; ++mi) prow0[mi] = crow[mi] - PW - 1;
     const int c_row0 = wn * 32 + l31;                           // this wave's 32 output channels: rows of a weight slot
 
+#if SMAP_CONVC_PIPE
+    half8 a2a[2][MI], b2a[2], a2b[2][MI], b2b[2];
+    auto rd2 = [&](int s, int kk, half8 (&af)[2][MI], half8 (&bf)[2]) {
+        const char* sB = ring + (s % NS) * SLOT;
+        const int tap = s / KC, cc = s % KC;
+        const int shift = (tap / 3) * PW + (tap % 3);
+        const int g = kk * 2 + lhi;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int prow = prow0[mi] + shift;
+                af[pl][mi] = *reinterpret_cast<const half8*>(sY1 + (cc * PROWS + prow) * ROWB + (((g + 4 * pl) ^ ((prow >> 1) & 7)) << 4));
+            }
+            bf[pl] = *reinterpret_cast<const half8*>(sB + c_row0 * ROWB + (((g + 4 * pl) ^ fswz) << 4));
+        }
+    };
+    auto mm2 = [&](const half8 (&af)[2][MI], const half8 (&bf)[2]) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            acc2[mi] = MFMA_(bf[0], af[1][mi], acc2[mi]);
+            acc2[mi] = MFMA_(bf[1], af[0][mi], acc2[mi]);
+            acc2[mi] = MFMA_(bf[0], af[0][mi], acc2[mi]);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NS2; ++s) {
+        lds_barrier();                                          // slot s landed for every wave; y1 complete (s = 0); slot s-1's buffer is free
+        if (s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
+        rd2(s, 0, a2a, b2a);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) mm2(a2b, b2b);                               // K step (s - 1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        lds_reads_landed();
+        rd2(s, 1, a2b, b2b);
+        __builtin_amdgcn_sched_barrier(0);
+        mm2(a2a, b2a);                                          // K step (s, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        wait_next(s);
+    }
+    mm2(a2b, b2b);
+#else
 #pragma unroll
     for (int s = 0; s < NS2; ++s) {
         lds_barrier();                                          // slot s landed for every wave; y1 complete (s = 0); slot s-1's buffer is free
@@ -310,6 +436,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
         }
         wait_next(s);
     }
+#endif
     lds_barrier();                                              // every wave is done with y1: y2 may overwrite it
 
     // ---- accumulators -> y2 [KC][BM][128 B] (rows = tile pixels).  acc2[mi][4*q + e] = channel wn*32 + 8*q + 4*lhi + e
@@ -351,6 +478,158 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
     const int p_row0 = wm * 64 + l31;                           // + mi*32: pixel rows of y2
     _Float16* __restrict__ outp = reinterpret_cast<_Float16*>(a.out);
 
+#if SMAP_CONVC_PIPE
+    // Same pipeline; the epilogue of chunk nc runs half a slot late (behind the first reads of chunk nc + 1's first slot), the residual
+    // loads of a chunk that is not held in registers go out behind the previous chunk's epilogue (one register set).
+    f32x16 acc3[MI];                                            // start value b3 / scale: rows = channels nc*128 + wn*32 + 8*q + 4*lhi + e
+    half8 rl[MI][2][2];                                         // residual of a chunk that is not held in registers (nc >= NRS)
+    half8 p3a[2][MI], w3a[2], p3b[2][MI], w3b[2];
+    auto rd3 = [&](int s, int kc, int kk, half8 (&pf)[2][MI], half8 (&wf)[2]) {
+        const char* sW = ring + (s % NS) * SLOT;
+        const int g = kk * 2 + lhi;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                pf[pl][mi] = *reinterpret_cast<const half8*>(sY2 + (kc * BM + p_row0 + mi * 32) * ROWB + (((g + 4 * pl) ^ fswz) << 4));
+            wf[pl] = *reinterpret_cast<const half8*>(sW + c_row0 * ROWB + (((g + 4 * pl) ^ fswz) << 4));
+        }
+    };
+    auto mm3 = [&](const half8 (&pf)[2][MI], const half8 (&wf)[2]) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            acc3[mi] = MFMA_(wf[0], pf[1][mi], acc3[mi]);
+            acc3[mi] = MFMA_(wf[1], pf[0][mi], acc3[mi]);
+            acc3[mi] = MFMA_(wf[0], pf[0][mi], acc3[mi]);
+        }
+    };
+    // The bias table is read with RAW ds_read_b128: behind an ordinary LDS load hipcc puts s_waitcnt vmcnt(0) when LDS-DMA is in flight (it
+    // cannot tell the table from the ring the DMA writes), which drained the three weight slots in flight -- and the residual loads just
+    // issued -- once per chunk.  The raw reads are followed by their own lgkmcnt(0) and a scheduling fence (the compiler does not know
+    // that the outputs of the asm need the wait).
+    const unsigned sB3_lds = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(smem + Y2_BYTES) + (unsigned)((wn * 32 + 4 * lhi) * 4);
+    auto init_acc = [&](int nc) {
+        f32x4 b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b4[q]) : "v"(sB3_lds + (unsigned)((nc * P + 8 * q) * 4)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                acc3[mi][4 * q + 0] = b4[q][0]; acc3[mi][4 * q + 1] = b4[q][1]; acc3[mi][4 * q + 2] = b4[q][2]; acc3[mi][4 * q + 3] = b4[q][3];
+            }
+    };
+    auto load_rl = [&](int nc) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    rl[mi][j][pl] = *reinterpret_cast<const half8*>(a.res + m_dense[mi] + (unsigned)(nc * P + wn * 32 + 8 * lhi + 16 * j) + pl * a.tail_cout8);
+    };
+    auto epilogue = [&](int nc) {
+        // ---- register epilogue (convp.hip): half-wave swap -> acc3[mi][8*j .. 8*j+7] = channels n_lane + 16*j .. +7 of the pixel
+        const int n_lane = nc * P + wn * 32 + 8 * lhi;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xf = acc3[mi][8 * j + e], yf = acc3[mi][8 * j + 4 + e];   // (bit_cast of a vector ELEMENT lvalue reads element 0)
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf), __float_as_uint(yf), false, false);
+                    const unsigned s0 = sw[0], s1 = sw[1];
+                    acc3[mi][8 * j + e] = a.tail_acc_scale * __uint_as_float(s0);       // (bias inside)
+                    acc3[mi][8 * j + 4 + e] = a.tail_acc_scale * __uint_as_float(s1);
+                }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)                          // + x, from the registers filled in phase 1
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    acc3[mi][8 * j + e] += nc < NRS ? (float)rs[nc < NRS ? nc : 0][mi][j][0][e] + (float)rs[nc < NRS ? nc : 0][mi][j][1][e]
+                                                    : (float)rl[mi][j][0][e] + (float)rl[mi][j][1][e];
+        if (a.relu) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[mi][r] = acc3[mi][r] < 0.f ? 0.f : acc3[mi][r];
+        }
+        auto add_tensor = [&](const _Float16* __restrict__ tsr) {       // post-ReLU skip adds of the last block of a layer; one pixel block at
+#pragma unroll                                                          // a time: the residual registers leave room for 16 more, not 32
+            for (int mi = 0; mi < MI; ++mi) {
+                half8 h[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        h[j][pl] = *reinterpret_cast<const half8*>(tsr + m_dense[mi] + (unsigned)(n_lane + 16 * j) + pl * a.tail_cout8);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc3[mi][8 * j + e] += (float)h[j][0][e] + (float)h[j][1][e];
+            }
+        };
+        if (a.add1) add_tensor(a.add1);
+        if (a.add2) add_tensor(a.add2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!m_ok[mi]) continue;
+                _Float16* op = outp + (m_out[mi] + (unsigned)(n_lane + 16 * j));
+                half8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h[e] = (_Float16)acc3[mi][8 * j + e];
+                    l[e] = (_Float16)(acc3[mi][8 * j + e] - (float)h[e]);
+                }
+                if (SMAP_CONVC_ABLATE & 4) { if (h[0] == (_Float16)123.25f && l[1] == (_Float16)77.5f) *reinterpret_cast<half8*>(op) = h; continue; }   // keep the values live
+                *reinterpret_cast<half8*>(op) = h;
+                *reinterpret_cast<half8*>(op + a.out_lo) = l;
+            }
+    };
+    // Counted waits name LOADS only (LDS-DMA and the residual loads; in-order among themselves), never stores: "slot s + 1 has landed" =
+    // at most the loads issued after its request are outstanding.  Those are the requests of slots s + 2 and s + 3 plus the residual loads
+    // of this chunk when they went out in between (they are issued in the chunk's first iteration, behind that iteration's wait).
+    auto wait_next3 = [&](int s, int nc, int kc) {
+        if (s + 1 >= NSLOT) return;
+        const int younger = (s + 2 < NSLOT ? LS : 0) + (s + 3 < NSLOT ? LS : 0) + ((nc >= NRS && (kc == 1 || kc == 2)) ? MI * 4 : 0);
+        wait_vm(younger);
+    };
+#pragma unroll
+    for (int nc = 0; nc < NCH3; ++nc) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int s = NS2 + nc * KC + kc;
+            lds_barrier();                                      // slot s landed for every wave; y2 + bias table complete (first slot); slot s-1's buffer is free
+            if (s + NS - 1 < NSLOT) issue_slot(s + NS - 1);
+            rd3(s, kc, 0, p3a, w3a);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s > NS2) mm3(p3b, w3b);                         // K step (s - 1, 1): the last one of chunk nc - 1 when kc == 0
+            __builtin_amdgcn_sched_barrier(0);
+            if (kc == 0) {
+                wait_next3(s, nc, kc);                          // BEFORE the epilogue's stores and this chunk's residual loads
+                if (nc > 0) epilogue(nc - 1);
+                if (nc >= NRS) load_rl(nc);
+                init_acc(nc);
+            }
+            lds_reads_landed();
+            rd3(s, kc, 1, p3b, w3b);
+            __builtin_amdgcn_sched_barrier(0);
+            mm3(p3a, w3a);                                      // K step (s, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (kc != 0) wait_next3(s, nc, kc);
+        }
+    }
+    mm3(p3b, w3b);
+    epilogue(NCH3 - 1);
+#else
 #pragma unroll
     for (int nc = 0; nc < NCH3; ++nc) {
         f32x16 acc3[MI];                                        // start value b3 / scale: rows = channels nc*128 + wn*32 + 8*q + 4*lhi + e
@@ -466,6 +745,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck128_kernel(const ConvArgs a,
                 *reinterpret_cast<half8*>(op + a.out_lo) = l;
             }
     }
+#endif
     SMAP_TL_END(a)
 }
 

@@ -625,6 +625,8 @@ static int validate(const smap_op& o)
                 if (o.out_stride_c < o.tail_cout) return SMAP_E_ARG;
                 if ((int64_t)o.B * o.Ho * o.Wo * o.tail_cout * (1 + o.precision) >= ((int64_t)1 << 31)) return SMAP_E_ARG;
             }
+            if (o.tile == 56 && (o.precision != 1 || o.out_fp32 || o.aux_off[0] >= 0 || o.add1_off >= 0 || o.add2_off >= 0 || o.Cout % 8 || o.ksplit > 1))
+                return SMAP_E_ARG;                       // register-epilogue tile of conv.hip: split precision, fp16 outputs, residual + ReLU only
             if (o.tile >= 60 && o.tile < 80 && (o.out_fp32 || o.aux_off[0] >= 0 || o.Cout % 8 || o.cout_pad > 2048))
                 return SMAP_E_ARG;                       // persistent kernel: register epilogue, fp16 outputs, no fused bilinear add, bias table of 2048 channels in LDS
             if (o.in_stride_c % 8 || o.in_c_off % 8 || o.out_stride_c % 8 || o.out_c_off % 8) return SMAP_E_ARG;

@@ -52,6 +52,9 @@ TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (128, 32), 4: (64, 128),
          50: (128, 128), 51: (128, 128), 52: (128, 128), 53: (256, 128), 54: (128, 256),
          # 55: 4-stage pipeline (three K tiles in flight per workgroup: bytes in flight, not occupancy, for the streaming layers)
          55: (128, 128),
+         # 56 (round 6): 256 x 256, eight waves of 128 x 64, REGISTER epilogue (two 64 KiB LDS stages leave no room for a staging tile): half the
+         # L2 -> LDS bytes per MFMA of the 128 x 128 tiles.  Split precision, fp16 outputs, residual + ReLU only (no bilinear add / addends)
+         56: (256, 256),
          # 60..62: csrc/convp.hip, persistent workgroups with loader waves and a register epilogue (no fused bilinear add, no fp32 out)
          60: (128, 256), 61: (256, 128), 62: (128, 128), 63: (128, 64), 64: (128, 64), 65: (128, 64),
          # 80..82: csrc/convf.hip, a Bottleneck's 3x3 (BN = all of its planes) with the following 1x1 fused in (TAIL_BN)
@@ -91,7 +94,7 @@ ZERO_PAGE = 16384             # csrc/plan.hip SMAP_ZERO_PAGE
 WINDOW = 1 << 32              # csrc/plan.hip SMAP_WINDOW: bytes [k * WINDOW, k * WINDOW + ZERO_PAGE) of the arena are reserved
 PRECISIONS = ("f16", "x3")
 SPLITK_TILES = (2, 7, 20, 22)     # csrc/conv.hip tiles with a split-K instance (smap_conv_tile_has_splitk)
-X3_TILES = (0, 1, 2, 4, 7, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 60, 61, 62, 63, 64, 65)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
+X3_TILES = (0, 1, 2, 4, 7, 20, 21, 22, 23, 24, 25, 26, 27, 50, 51, 52, 53, 54, 55, 56, 60, 61, 62, 63, 64, 65)   # conv.hip tiles with a split-precision instance (+ 3: Cout <= 32)
 
 
 def split_f16(w, scaled=True):
@@ -117,8 +120,13 @@ def _table_entry(v):
     return [int(t) for t in v] if isinstance(v, (list, tuple)) else [int(v)]
 
 
-def tile_legal(tile, *, cout, cout_pad=None, plain3=True, up=False, out_fp32=False):
+REGEPI_TILES = (56,)               # csrc/conv.hip tiles with the register epilogue
+
+
+def tile_legal(tile, *, cout, cout_pad=None, plain3=True, up=False, out_fp32=False, adds=False, x3=True):
     """Can tile id `tile` run an op with these properties?  Mirrors csrc/plan.hip::validate."""
+    if tile in REGEPI_TILES:
+        return x3 and not up and not out_fp32 and not adds and cout % 8 == 0
     if 30 <= tile < 50:
         return plain3
     if 80 <= tile < 100:
@@ -540,7 +548,8 @@ class Graph:
         M = nfr * Ho * Wo
         key = f"{nfr},{x.H},{x.W},{cin},{cout},{ksize},{stride}"
         plain3 = ksize == 3 and stride == 1 and res is None and add1 is None and add2 is None and up is None
-        legal = lambda t: tile_legal(t, cout=cout, plain3=plain3, up=up is not None, out_fp32=out_fp32)
+        legal = lambda t: tile_legal(t, cout=cout, plain3=plain3, up=up is not None, out_fp32=out_fp32,
+                                     adds=add1 is not None or add2 is not None, x3=self.x3)
         if self.x3:
             # ops with the fused bilinear add have their own entries (the tap loads of the epilogue favour wider tiles)
             cands = pick_tile_x3(M, cout, [key + ",up", key] if up is not None else key)
@@ -610,7 +619,8 @@ class Graph:
         # widest conv alone (same input, same K: the nearest measured relative)
         key = f"{self.B},{x.H},{x.W},{cin},{'+'.join(map(str, couts))},1,1"
         wide = f"{self.B},{x.H},{x.W},{cin},{max(couts)},1,1"
-        legal = lambda t: tile_family(t) == "igemm" and (t in X3_TILES or not self.x3) and t not in (3, 8)
+        legal = lambda t: (tile_family(t) == "igemm" and (t in X3_TILES or not self.x3) and t not in (3, 8)
+                           and (t not in REGEPI_TILES or (self.x3 and up is None)))
         if tile is not None:
             assert legal(tile), tile
         elif self.x3:

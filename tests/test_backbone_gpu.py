@@ -228,6 +228,12 @@ X3_CASES = [
     (1, 16, 26, 64, 320, 3, 1, 54, True, True, True),
     # 4-stage pipelines (tile ids 55..57), incl. K shorter than the pipeline
     (3, 10, 14, 192, 320, 3, 1, 55, True, True, True),
+    # 256 x 256 with the register epilogue (tile id 56): residual + ReLU only
+    (2, 16, 24, 256, 256, 1, 1, 56, True, True, False),      # three M tiles, one N tile
+    (3, 10, 14, 192, 320, 3, 1, 56, True, True, False),      # ragged M, Cout not a tile multiple (two N tiles), 3x3 taps
+    (1, 32, 52, 256, 512, 1, 2, 56, False, False, False),    # strided shortcut, no ReLU, no residual
+    (2, 8, 12, 2048, 1024, 1, 1, 56, True, True, False),     # long K, M < one tile
+    (4, 32, 52, 64, 1024, 1, 1, 56, True, False, False),     # K = two tiles (the pipeline's shortest loop), 26 x 4 tiles
     # persistent wave-specialised kernel (convp.hip)
     (2, 16, 24, 64, 256, 1, 1, 60, False, False, False),
     (3, 10, 14, 192, 320, 3, 1, 60, True, True, True),
@@ -919,6 +925,7 @@ SEG_CASES = [   # B, H, W, Cin, couts, relus, up (low-res size or None), tile
     (2, 9, 11, 128, (128, 256, 8), (0, 1, 1), (5, 6), 2),
     (3, 16, 24, 256, (512, 256), (1, 0), None, 53),
     (1, 32, 52, 64, (256, 64), (1, 1), (16, 26), 50),
+    (3, 16, 24, 256, (512, 256, 264), (1, 0, 1), None, 56),     # register-epilogue tile: every segment on its own 256-row N tile(s)
 ]
 
 
@@ -932,6 +939,8 @@ def test_merged_1x1_launch_matches_torch(case, x3):
     from smap_amd import engine as E
     from smap_amd import lib as L
     B, H, W, cin, couts, relus, up, tile = case
+    if tile in E.REGEPI_TILES and not x3:
+        pytest.skip("the register-epilogue tile has a split-precision instance only")
     gen = torch.Generator().manual_seed(sum(case[:4]) + tile)
     sd, segs = {}, []
     for j, (c, r) in enumerate(zip(couts, relus)):

@@ -1,0 +1,99 @@
+#!/bin/bash
+# Round 6: what each GPU visit ran, one function per visit (the logs under profiles/r6_v<N>_* came from these).
+#     gpurun -- bash tools/gpu_visits/round6.sh <N>
+R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"
+export TMPDIR=/tmp
+line() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); c=d['config']; r=d['roofline']; print('$1', round(d['value'],1),'fps', round(d['ms_per_step'],3),'ms/step', 'lf0', c.get('value_launch_frames_0') and round(c['value_launch_frames_0'],1), 'fpl', c.get('frames_per_launch'), 'mfma', round(r['frac'],4), 'pipe', round(r.get('pipe_frac',0),4), 'assoc_us', c.get('association_lift_us_per_launch',{}).get('network'))
+"; }
+layers() {   # layers <out dir> <tag> <frames per launch> <bench args...>: per-op table of one rocprofv3 kernel trace
+  local O=$1 tag=$2 B=$3; shift 3
+  (cd /tmp; SMAP_PRECISION=x3 SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $R/$O/prof_$tag -o smap -- python $R/bench.py "$@" --no-cpu-baseline > $R/$O/rocprof_$tag.log 2>&1)
+  local db=$(find $R/$O/prof_$tag -name "*.db" | head -1)
+  SMAP_PRECISION=x3 python tools/prof_layers.py $db $B > $O/layers_$tag.txt 2>&1
+  python tools/prof_export.py $db $R/$O/kernel_stats_$tag.csv
+  rm -rf $R/$O/prof_$tag
+  tail -32 $O/layers_$tag.txt
+}
+
+v1() {
+# visit 1: the round-5 tree on this round's box: driver-form line twice, the 100-step line, per-op traces at depth 1 with 16- and 8-frame launches
+O=gpurun_out/r6v1; mkdir -p $O
+python -c "from smap_amd import lib; print(lib.version())" > $O/version.log 2>&1
+for rep in 1 2; do
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 2>>$O/ab.err | line "rep $rep driver form" >> $O/base.log
+done
+SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 2>>$O/ab.err | line "100 steps" >> $O/base.log
+SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 --depth 1 2>>$O/ab.err | line "depth 1, 16 frames per launch" >> $O/base.log
+SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 --depth 1 --launch-frames 0 2>>$O/ab.err | line "depth 1, 8 frames per launch" >> $O/base.log
+cat $O/base.log
+layers $O d1_f16 16 --depth 1 --steps 6 --warmup 2
+layers $O d1_f8 8 --depth 1 --launch-frames 0 --steps 4 --warmup 2
+}
+
+v2() {
+# visit 2: convc.hip with the software pipeline (fragments of K step u + 1 in flight while step u multiplies; 2 residual chunks in registers):
+# parity of tile 94, the launch alone (warm, back to back), in situ against round 5's loops and against 1 / 0 residual chunks in registers
+O=gpurun_out/r6v2; mkdir -p $O
+timeout 600 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "whole_bottleneck and (94 or 128)" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -5 $O/pytest.log
+V=$R/smap_amd/csrc/obj
+for lib in "" $V/libsmap_hip_convc_convc_nrs3_convc_pipe0.so $V/libsmap_hip_convc_convc_nrs1_convc_pipe1.so $V/libsmap_hip_convc_convc_nrs0_convc_pipe1.so; do
+  SMAP_HIP_LIB=$lib timeout 120 python tools/bench_convb.py 94 --n 40 --check 2>&1 | tail -2 >> $O/convc_alone.log
+done
+cat $O/convc_alone.log
+for rep in 1 2; do
+  for lib in "" $V/libsmap_hip_convc_convc_nrs3_convc_pipe0.so $V/libsmap_hip_convc_convc_nrs1_convc_pipe1.so $V/libsmap_hip_convc_convc_nrs0_convc_pipe1.so; do
+    SMAP_HIP_LIB=$lib SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep depth 2 [$(basename ${lib:-shipped})]" >> $O/ab_convc.log
+  done
+done
+for lib in "" $V/libsmap_hip_convc_convc_nrs3_convc_pipe0.so; do
+  SMAP_HIP_LIB=$lib SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 --depth 1 2>>$O/ab.err | line "depth 1 [$(basename ${lib:-shipped})]" >> $O/ab_convc.log
+done
+cat $O/ab_convc.log
+}
+
+v3() {
+# visit 3: the whole-block launches alone (warm, back to back): convc variants; trace of the default
+O=gpurun_out/r6v3; mkdir -p $O
+V=$R/smap_amd/csrc/obj
+for lib in "" $V/libsmap_hip_convc_convc_nrs3_convc_pipe0.so $V/libsmap_hip_convc_convc_nrs1_convc_pipe1.so $V/libsmap_hip_convc_convc_nrs0_convc_pipe1.so; do
+  SMAP_HIP_LIB=$lib timeout 120 python tools/bench_convb.py 94 --check 2>&1 | tail -2 >> $O/convc_alone.log
+  SMAP_HIP_LIB=$lib timeout 120 python tools/bench_convb.py 94 2>&1 | tail -1 >> $O/convc_alone.log
+done
+cat $O/convc_alone.log
+}
+
+v4() {
+# visit 4: the driver's form (20 steps, 5 warm-up) against pipeline depth and frames per launch
+O=gpurun_out/r6v4; mkdir -p $O
+for rep in 1 2; do
+ for cfg in "--depth 2 --launch-frames 16" "--depth 3 --launch-frames 16" "--depth 3 --launch-frames 8" "--depth 4 --launch-frames 8" "--depth 2 --launch-frames 32"; do
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 $cfg 2>>$O/ab.err | line "rep $rep 20 steps [$cfg]" >> $O/sweep.log
+ done
+done
+for cfg in "--depth 2 --launch-frames 16" "--depth 3 --launch-frames 16" "--depth 3 --launch-frames 8"; do
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 $cfg 2>>$O/ab.err | line "100 steps [$cfg]" >> $O/sweep.log
+done
+cat $O/sweep.log
+}
+
+v5() {
+# visit 5: the 256 x 256 register-epilogue tile (conv.hip, tile id 56): parity, then where it beats the table's tile (cold, alone), then in situ
+O=gpurun_out/r6v5; mkdir -p $O
+timeout 900 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "x56 or t56 or x3-" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -8 $O/pytest.log
+timeout 900 python tools/autotune_regepi.py --batch 16 --batch 8 --iters 15 --out $R/$O/tile_table_x3_t56.json > $O/autotune_regepi.log 2>&1; tail -70 $O/autotune_regepi.log
+for rep in 1 2; do
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep shipped table" >> $O/ab_t56.log
+  SMAP_TILE_TABLE_X3=$R/$O/tile_table_x3_t56.json SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep table with tile 56" >> $O/ab_t56.log
+done
+SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 2>>$O/ab.err | line "depth 1 shipped table" >> $O/ab_t56.log
+SMAP_TILE_TABLE_X3=$R/$O/tile_table_x3_t56.json SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 2>>$O/ab.err | line "depth 1 table with tile 56" >> $O/ab_t56.log
+cat $O/ab_t56.log
+}
+
+"v$1"
