@@ -56,6 +56,14 @@ int smap_flip_merge(float* hms, const float* hms_flip, const int* pair43, int B,
  * Requires H*W <= 32768. */
 int smap_nms(const float* hms, int B, int C, int H, int W, float threshold,
              float* peaks, void* stream);
+/* The same result from TWO launches and a caller-provided workspace (the library never allocates): nmsRegisterKernel's mask
+ * (nmsBase.cu:10-41) as one thread per pixel over the whole batch -- B x 15 x H x W / 256 workgroups instead of the B x 15 of the
+ * fused form, whose 120 workgroups at eight frames walk 26 serial chunks each -- into a bit mask per 64 pixels, then the scan and the
+ * 7x7 centroid write-out (nmsBase.cu:43-135, 166) per channel.  workspace: DEVICE memory, 8-byte aligned, at least
+ * smap_nms_workspace_bytes(B, H, W) = B * 15 * ceil(H * W / 64) * 8 bytes; not read or written outside the call's launches. */
+int64_t smap_nms_workspace_bytes(int B, int H, int W);
+int smap_nms_ws(const float* hms, int B, int C, int H, int W, float threshold, float* peaks, void* workspace,
+                int64_t workspace_bytes, void* stream);
 
 /* bodyPartConnectorBase.cu:11-63,104-189 (process + pafScoreKernel).
  * hms: [B,43,H,W]; peaks as above; scores: [B,14,127,127] fp32 out (-1 where no pair). */
@@ -216,7 +224,11 @@ typedef struct smap_op {
                                        the same input, added before the final ReLU.  Weight blocks [n chunk][k chunk][64 rows][128 B] like
                                        the tail's; its bias is folded into the tail's bias by the packer; res_off = -1 */
     float short_acc_scale;          /* 2^-s of the shortcut conv's weights; 0 = the op has no shortcut conv */
-    int32_t reserved0;
+    int32_t scale_hms;              /* HEADSUM: 1 = the maps are written ALREADY SCALED as exps/stage3_root2/test.py:111-112 scales them before the
+                                       association: channels < in_c_off (the key points) / 255, the others (the PAFs) / 127 -- the same fp32
+                                       divisions smap_scale_hms performs, applied to the summed (and, with flip_from, merged) value in the
+                                       head sum's store, so that no separate pass over the maps runs between the backbone and smap_nms.
+                                       0 = raw maps: what model.smap.SMAP.forward returns (smap.py:417-419).  Other kinds: 0. */
     /* N SEGMENTS: several 1x1 convs that read the SAME input as one launch with up to three outputs (Upsample_unit, smap.py:210-241:
        u_skip and skip1 both read x; skip2, cross_conv / res_conv1 and the next unit's up_conv all read `out`).  The weight
        matrix [cout_pad][K] is the concatenation of the convs' rows, every segment starting on a multiple of the tile's N extent
@@ -293,6 +305,7 @@ int smap_workspace_bytes(const smap_plan* plan, int64_t* arena_bytes, int64_t* o
  * section [weights_offset, +weights_bytes) to the device, smap_plan_run.  Little-endian, written by
  * smap_amd/engine.py::BackboneEngine.blob():
  *   smap_blob_header | smap_op[n_ops] at ops_offset | weight section at weights_offset (256-byte aligned) */
+#define SMAP_BLOB_VERSION 2u
 typedef struct smap_blob_info {
     int32_t frames, H, W;               /* input: [frames,3,H,W] fp32 NCHW                                      */
     int32_t out_h, out_w;               /* map size                                                              */
@@ -305,7 +318,9 @@ typedef struct smap_blob_info {
 } smap_blob_info;
 typedef struct smap_blob_header {
     char magic[8];                      /* "SMAPPLN1"                                                            */
-    uint32_t version, sizeof_op, header_bytes;
+    uint32_t version, sizeof_op, header_bytes;   /* version = SMAP_BLOB_VERSION: any other value is refused (a blob written for an older smap_op
+                                           MEANING -- version 1: status_off named ONE status word, no seg_ / ksplit / lane / scale_hms
+                                           fields -- must not load just because the struct sizes happen to agree) */
     int32_t n_ops;
     int64_t ops_offset;
     int64_t weights_offset, weights_bytes, arena_bytes, out_bytes;     /* = info's, kept flat for readers without the struct */

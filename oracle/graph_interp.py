@@ -99,6 +99,10 @@ def run_graph(g, imgs, quantize, keep=False):
             for t in op.aux:
                 u = up(T[t.name][:, :p["Cout"]], size)
                 y = u if y is None else y + u
+            if p.get("scale_hms"):                       # test.py:111-112 fused into the head sum (smap_op.scale_hms)
+                y = y.clone()
+                y[:, :p["n_kpt"]] /= 255
+                y[:, p["n_kpt"]:] /= 127
             outs[p["ext_off"]] = y
     lay = g.out_layout
     r = (outs[lay["hms"][0]], outs[lay["det_d"][0]], outs[lay["root_d"][0]])

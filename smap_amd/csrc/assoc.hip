@@ -79,8 +79,27 @@ __device__ __forceinline__ bool nms_is_peak(const float* __restrict__ s, int p, 
            v > s[p + W - 1] && v > s[p + W] && v > s[p + W + 1];
 }
 
+// Pass 1 alone, one thread per pixel over the WHOLE batch (smap_nms_ws): the single-kernel form below runs B x 15 workgroups -- 120 on 256
+// CUs at eight frames -- through 26 serial chunks of nine loads per pixel each (109 us per launch, the longest kernel of the association);
+// here the masks of a launch are B x 15 x H x W / 256 workgroups (12 480) of one chunk each.  ballots[(b * 15 + c) * nq + q] = the wave
+// ballot of pixels 64 q .. 64 q + 63 of channel c: the same predicate on the same pixels as pass 1 below, hence the same peaks.
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ hms, int C, int H, int W, float thr, int nq,
+                                                       unsigned long long* __restrict__ ballots)
+{
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int HW = H * W;
+    const float* s = hms + ((size_t)b * C + c) * HW;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool f = p < HW && nms_is_peak(s, p, H, W, thr);
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0 && (p >> 6) < nq) ballots[((size_t)b * NJ + c) * nq + (p >> 6)] = m;
+}
+
+// PRE = true: passes 2 and 3 only, the ballots of pass 1 come from nms_mask_kernel's workspace.
+template <bool PRE>
 __global__ __launch_bounds__(NMS_NT) void nms_kernel(const float* __restrict__ hms, int C, int H, int W,
-                                                      float thr, float* __restrict__ peaks)
+                                                      float thr, float* __restrict__ peaks,
+                                                      const unsigned long long* __restrict__ ballots)
 {
     __shared__ unsigned long long s_ballot[NMS_MAXCHUNK * NMS_NW];
     __shared__ int s_off[NMS_MAXCHUNK * NMS_NW + 1];
@@ -91,11 +110,16 @@ __global__ __launch_bounds__(NMS_NT) void nms_kernel(const float* __restrict__ h
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nchunk = (HW + NMS_NT - 1) / NMS_NT;
 
-    for (int i = 0; i < nchunk; ++i) {
-        const int p = i * NMS_NT + tid;
-        const bool f = p < HW && nms_is_peak(s, p, H, W, thr);
-        const unsigned long long m = __ballot(f);
-        if (lane == 0) s_ballot[i * NMS_NW + wave] = m;
+    if (PRE) {          // chunk i, wave w of the single-kernel form = pixels 64 (i * 16 + w) .. +63 = ballot i * 16 + w
+        const int nq_in = (HW + 63) / 64;
+        for (int q = tid; q < nchunk * NMS_NW; q += NMS_NT) s_ballot[q] = q < nq_in ? ballots[((size_t)b * NJ + c) * nq_in + q] : 0ull;
+    } else {
+        for (int i = 0; i < nchunk; ++i) {
+            const int p = i * NMS_NT + tid;
+            const bool f = p < HW && nms_is_peak(s, p, H, W, thr);
+            const unsigned long long m = __ballot(f);
+            if (lane == 0) s_ballot[i * NMS_NW + wave] = m;
+        }
     }
     __syncthreads();
     const int nq = nchunk * NMS_NW;
@@ -857,8 +881,29 @@ int smap_nms(const float* hms, int B, int C, int H, int W, float threshold, floa
 {
     if (!hms || !peaks || B <= 0 || C < NJ || H < 3 || W < 3) return SMAP_E_ARG;
     if ((long long)H * W > (long long)NMS_MAXCHUNK * NMS_NT) return SMAP_E_ARG;
-    hipLaunchKernelGGL(nms_kernel, dim3(B * NJ), dim3(NMS_NT), 0, (hipStream_t)stream, hms, C, H, W,
-                       threshold, peaks);
+    hipLaunchKernelGGL(nms_kernel<false>, dim3(B * NJ), dim3(NMS_NT), 0, (hipStream_t)stream, hms, C, H, W,
+                       threshold, peaks, (const unsigned long long*)nullptr);
+    return hip_rc(hipGetLastError());
+}
+
+int64_t smap_nms_workspace_bytes(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (int64_t)B * NJ * (((int64_t)H * W + 63) / 64) * 8;
+}
+
+int smap_nms_ws(const float* hms, int B, int C, int H, int W, float threshold, float* peaks, void* workspace,
+                int64_t workspace_bytes, void* stream)
+{
+    if (!hms || !peaks || !workspace || B <= 0 || C < NJ || H < 3 || W < 3 || ((uintptr_t)workspace & 7)) return SMAP_E_ARG;
+    if ((long long)H * W > (long long)NMS_MAXCHUNK * NMS_NT || B > 65535) return SMAP_E_ARG;
+    if (workspace_bytes < smap_nms_workspace_bytes(B, H, W)) return SMAP_E_ARG;
+    const int nq = (H * W + 63) / 64;
+    unsigned long long* bal = reinterpret_cast<unsigned long long*>(workspace);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((H * W + 255) / 256, NJ, B), dim3(256), 0, (hipStream_t)stream, hms, C, H, W, threshold, nq, bal);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_rc(e);
+    hipLaunchKernelGGL(nms_kernel<true>, dim3(B * NJ), dim3(NMS_NT), 0, (hipStream_t)stream, hms, C, H, W,
+                       threshold, peaks, (const unsigned long long*)bal);
     return hip_rc(hipGetLastError());
 }
 

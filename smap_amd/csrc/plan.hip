@@ -485,10 +485,12 @@ __device__ __forceinline__ float4 head_value4(const HeadSrc& s, const Lerp& ly0,
 // maps of the mirrored frame b + flip_from at the mirrored pixels W-1-x and writes
 //     out[b,c] = v[b,c] + s_c * v_mirror[pair[c]]   (s_c = -1 on PAF-x channels), halved for c >= n_kpt,
 // the same fp32 operations, in the same order, as the reference's channel loop (and as smap_flip_merge).
+// scale (smap_op.scale_hms): the value is stored as v / 255 (channels < n_kpt) or v / 127 -- test.py:111-112's in-place division of the maps
+// before the association, the same fp32 IEEE division as smap_scale_hms (csrc/assoc.hip), fused into this store.
 template <bool FLIP>
 __global__ __launch_bounds__(256) void headsum_kernel(HeadSrc s, float* __restrict__ out, int Ho, int Wo, int C,
                                                       int Cs, int flip_from, const int* __restrict__ pair, int n_kpt,
-                                                      int* __restrict__ status)
+                                                      int* __restrict__ status, int scale)
 {
     __shared__ float tile[(FLIP ? 2 : 1) * 48 * (HS_PX + 1)];
     float* tile2 = tile + 48 * (HS_PX + 1);
@@ -526,6 +528,7 @@ __global__ __launch_bounds__(256) void headsum_kernel(HeadSrc s, float* __restri
             v = v + (neg ? f * -1.f : f);
             if (c >= n_kpt) v = v * 0.5f;
         }
+        if (scale) v = v / (c < n_kpt ? 255.f : 127.f);
         out[(((size_t)b * C + c) * Ho + y) * Wo + x] = v;
         // inf / NaN: an activation left the fp16 range upstream.  Status word b / 31: bit 0 = some frame of the word, bit 1 + b % 31 =
         // output frame b; word 0's bit 0 = some frame of the launch (include/smap_hip.h)
@@ -703,6 +706,7 @@ static int validate(const smap_op& o)
             if (o.n_aux < 1 || o.n_aux > 3 || o.Cout > 48 || o.Cin < o.Cout || o.ext_off < 0) return SMAP_E_ARG;
             if (o.flip_from < 0 || (o.flip_from > 0 && (o.w_off < 0 || o.in_c_off < 0 || o.in_c_off > o.Cout))) return SMAP_E_ARG;
             if (o.status_off < 0 || o.status_off % 4) return SMAP_E_ARG;
+            if ((o.scale_hms != 0 && o.scale_hms != 1) || (o.scale_hms && (o.in_c_off < 0 || o.in_c_off > o.Cout))) return SMAP_E_ARG;
             return 0;
         default:
             return SMAP_E_ARG;
@@ -977,10 +981,10 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
                 int* status = o.status_off > 0 ? reinterpret_cast<int*>(reinterpret_cast<char*>(out) + o.status_off) : nullptr;
                 if (o.flip_from > 0)
                     hipLaunchKernelGGL(headsum_kernel<true>, grid, dim3(256), 0, st, s, dst, o.Ho, o.Wo, o.Cout, o.Cin,
-                                       o.flip_from, reinterpret_cast<const int*>(wb + o.w_off), o.in_c_off, status);
+                                       o.flip_from, reinterpret_cast<const int*>(wb + o.w_off), o.in_c_off, status, o.scale_hms);
                 else
                     hipLaunchKernelGGL(headsum_kernel<false>, grid, dim3(256), 0, st, s, dst, o.Ho, o.Wo, o.Cout, o.Cin,
-                                       0, nullptr, 0, status);
+                                       0, nullptr, o.in_c_off, status, o.scale_hms);
                 e = hipGetLastError();
                 break;
             }
@@ -1052,7 +1056,7 @@ int smap_plan_create_from_blob(const void* blob, size_t blob_bytes, smap_plan** 
     if (!blob || !plan || blob_bytes < sizeof(smap_blob_header)) return SMAP_E_ARG;
     smap_blob_header h;
     memcpy(&h, blob, sizeof(h));
-    if (memcmp(h.magic, "SMAPPLN1", 8) || h.version != 1 || h.sizeof_op != sizeof(smap_op) || h.header_bytes != sizeof(smap_blob_header))
+    if (memcmp(h.magic, "SMAPPLN1", 8) || h.version != SMAP_BLOB_VERSION || h.sizeof_op != sizeof(smap_op) || h.header_bytes != sizeof(smap_blob_header))
         return SMAP_E_ARG;
     // every (offset, size) pair is checked as `off <= total - size` with total - size >= 0: no sum that could wrap
     const int64_t total = (int64_t)blob_bytes;

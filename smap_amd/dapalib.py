@@ -75,20 +75,27 @@ def flip_merge_(hms, hms_flip, pair):
     return hms
 
 
-def extract_batch(hms):
-    """hms [B,43,H,W] -> (peaks [B,15,128,3], scores [B,14,127,127]) on the device."""
+def extract_batch(hms, fused_nms=False):
+    """hms [B,43,H,W] -> (peaks [B,15,128,3], scores [B,14,127,127]) on the device.  The peak search runs as smap_nms_ws (mask of the
+    whole batch with one thread per pixel, then scan + centroids per channel; workspace from torch's caching allocator); fused_nms=True:
+    the single-launch smap_nms (same peaks bit for bit, tests/test_ref_gpu.py)."""
     H, W = _check_hms(hms, True)
     B = hms.shape[0]
     lib = _L.load()
     peaks = torch.empty((B, NJ, MAXP + 1, 3), dtype=torch.float32, device=hms.device)
     scores = torch.empty((B, NL, MAXP, MAXP), dtype=torch.float32, device=hms.device)
     with torch.cuda.device(hms.device):
-        _L.check(lib.smap_nms(_p(hms), B, HMS_C, H, W, 0.2, _p(peaks), _stream()), "smap_nms")
+        if fused_nms:
+            _L.check(lib.smap_nms(_p(hms), B, HMS_C, H, W, 0.2, _p(peaks), _stream()), "smap_nms")
+        else:
+            nb = lib.smap_nms_workspace_bytes(B, H, W)
+            ws = torch.empty((nb // 8,), dtype=torch.int64, device=hms.device)
+            _L.check(lib.smap_nms_ws(_p(hms), B, HMS_C, H, W, 0.2, _p(peaks), _p(ws), nb, _stream()), "smap_nms_ws")
         _L.check(lib.smap_paf_score(_p(hms), _p(peaks), B, H, W, _p(scores), _stream()), "smap_paf_score")
     return peaks, scores
 
 
-def connect_batch(hms, rdepth, rootIdx=2, distFlag=True, return_intermediate=False):
+def connect_batch(hms, rdepth, rootIdx=2, distFlag=True, return_intermediate=False, fused_nms=False, counts=None):
     """Batched connect: hms [B,43,H,W], rdepth [B,H,W] (or [B,1,H,W]) ->
     (bodys [B,127,15,4] fp32, counts [B] int32), both on the device."""
     H, W = _check_hms(hms, True)
@@ -100,9 +107,12 @@ def connect_batch(hms, rdepth, rootIdx=2, distFlag=True, return_intermediate=Fal
     if not 0 <= int(rootIdx) < NJ:
         raise ValueError("rootIdx out of range")
     rdepth = rdepth.to(device=hms.device, dtype=torch.float32).contiguous()
-    peaks, scores = extract_batch(hms)
+    peaks, scores = extract_batch(hms, fused_nms=fused_nms)
     bodys = torch.empty((B, MAXP, NJ, 4), dtype=torch.float32, device=hms.device)
-    counts = torch.empty((B,), dtype=torch.int32, device=hms.device)
+    if counts is None:
+        counts = torch.empty((B,), dtype=torch.int32, device=hms.device)
+    elif tuple(counts.shape) != (B,) or counts.dtype != torch.int32 or counts.device != hms.device or not counts.is_contiguous():
+        raise ValueError("connect_batch(counts=...): a contiguous int32 [B] tensor on the maps' device")
     with torch.cuda.device(hms.device):
         _L.check(_L.load().smap_group(_p(peaks), _p(scores), _p(rdepth), B, H, W, int(rootIdx),
                                       int(bool(distFlag)), _p(bodys), _p(counts), _stream()), "smap_group")
@@ -133,7 +143,7 @@ def register_gt_batch(bodys, counts, gt_roots, gt_counts):
     return matched, mcounts
 
 
-def lift_batch(bodys, counts, det_d, root_d, cams, gt_mode=False):
+def lift_batch(bodys, counts, det_d, root_d, cams, gt_mode=False, out=None):
     """Batched 3D lifting (test.py:116-134, test_util.py:45-99, post_3d.py).
     det_d [B,14,H,W], root_d [B,H,W] or [B,1,H,W], cams [B,9] float64
     (scale,img_w,img_h,net_w,net_h,f_x,f_y,cx,cy).
@@ -151,9 +161,16 @@ def lift_batch(bodys, counts, det_d, root_d, cams, gt_mode=False):
     cams = torch.as_tensor(cams, dtype=torch.float64).to(dev).contiguous()
     if tuple(cams.shape) != (B, 9):
         raise ValueError("cams must be [B,9]")
-    p2 = torch.empty((B, MAXP, NJ, 4), dtype=torch.float64 if gt_mode else torch.float32, device=dev)
-    p3 = torch.empty((B, MAXP, NJ, 4), dtype=torch.float64, device=dev)
-    rz = torch.empty((B, MAXP), dtype=torch.float64, device=dev)
+    if out is not None:            # (p2, p3, rz) to write into: views of one result buffer that goes to the host in ONE copy (pipeline.py)
+        p2, p3, rz = out
+        want = ((B, MAXP, NJ, 4), torch.float64 if gt_mode else torch.float32), ((B, MAXP, NJ, 4), torch.float64), ((B, MAXP), torch.float64)
+        for t, (shp, dt) in zip(out, want):
+            if tuple(t.shape) != shp or t.dtype != dt or t.device != dev or not t.is_contiguous():
+                raise ValueError("lift_batch(out=...): p2 / p3 / rz tensors of the documented shapes and dtypes on the maps' device")
+    else:
+        p2 = torch.empty((B, MAXP, NJ, 4), dtype=torch.float64 if gt_mode else torch.float32, device=dev)
+        p3 = torch.empty((B, MAXP, NJ, 4), dtype=torch.float64, device=dev)
+        rz = torch.empty((B, MAXP), dtype=torch.float64, device=dev)
     fn = _L.load().smap_lift_gt if gt_mode else _L.load().smap_lift
     with torch.cuda.device(dev):
         _L.check(fn(_p(bodys), _p(counts), _p(det_d), _p(root_d), _p(cams), B, H, W, _p(p2), _p(p3), _p(rz), _stream()),
@@ -161,12 +178,15 @@ def lift_batch(bodys, counts, det_d, root_d, cams, gt_mode=False):
     return p2, p3, rz
 
 
-def refine_batch(pred_2d, pred_3d, counts, wt, bs):
+def refine_batch(pred_2d, pred_3d, counts, wt, bs, out=None):
     """RefineNet post-refinement (test_util.py:102-131).  wt/bs: 5 folded, transposed
-    [in][out] fp32 weight tensors and 5 bias tensors on the device."""
+    [in][out] fp32 weight tensors and 5 bias tensors on the device.  out: the [B,127,15,4] f64 tensor to write into."""
     B = pred_2d.shape[0]
     dev = pred_2d.device
-    out = torch.empty((B, MAXP, NJ, 4), dtype=torch.float64, device=dev)
+    if out is None:
+        out = torch.empty((B, MAXP, NJ, 4), dtype=torch.float64, device=dev)
+    elif tuple(out.shape) != (B, MAXP, NJ, 4) or out.dtype != torch.float64 or out.device != dev or not out.is_contiguous():
+        raise ValueError("refine_batch(out=...): a contiguous [B,127,15,4] float64 tensor on the inputs' device")
     wp = (C.c_void_p * 5)(*[w.data_ptr() for w in wt])
     bp = (C.c_void_p * 5)(*[b.data_ptr() for b in bs])
     gt_mode = pred_2d.dtype == torch.float64       # the f64 pred_2d of lift_batch(gt_mode=True)

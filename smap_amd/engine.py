@@ -418,7 +418,7 @@ def arena_budget(device):
 
 class Graph:
     def __init__(self, sd, B, H, W, stage_num=3, chl=256, kpt_paf=43, paf=14, keep_ref=False, precision="f16",
-                 flip_pair=None, build=True):
+                 flip_pair=None, build=True, scaled_hms=False):
         """build=False: an EMPTY schedule with all the book-keeping in place (single-op harnesses of tests / tools append to it with
         Graph.tensor / conv / conv_seg and then allocate() / emit()).
         flip_pair (43 ints: KEYPOINT.FLIP_ORDER + [15 + c for c in PAF.FLIP_CHANNEL]) switches the flip-TTA of
@@ -429,6 +429,9 @@ class Graph:
         self.precision, self.x3 = precision, precision == "x3"
         self.keep_ref = keep_ref
         self.flip_pair = list(flip_pair) if flip_pair is not None else None
+        # scaled_hms: the head sum stores hms / 255 (key points) and / 127 (PAFs), i.e. the maps as test.py:111-112 hands them to the
+        # association (smap_op.scale_hms) -- what the pipelines ask for; SMAP.forward keeps the raw maps of smap.py:417-419
+        self.scaled_hms = bool(scaled_hms)
         self.frames = B                       # frames of the input / output
         if self.flip_pair is not None:
             assert len(self.flip_pair) == kpt_paf
@@ -994,7 +997,8 @@ class Graph:
             self.status_words = (B + 30) // 31               # SMAP_STATUS_WORDS: frame f = word f // 31, bit 1 + f % 31
             # outputs_2d = res4 + res3 + res2 (smap.py:417)
             self.ops.append(Op(OP_HEADSUM, aux=[head_t["res4"], head_t["res3"], head_t["res2"]],
-                               p=dict(Cout=n_hms, ext_off=self.out_layout["hms"][0], **flip_p)))
+                               p={**dict(Cout=n_hms, ext_off=self.out_layout["hms"][0], n_kpt=n_hms - 2 * n_d, scale_hms=int(self.scaled_hms)),
+                                  **flip_p}))
             with self.on_lane(1):
                 self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_d"]], p=dict(Cout=n_d, ext_off=self.out_layout["det_d"][0])))
             with self.on_lane(2):
@@ -1177,6 +1181,8 @@ class Graph:
                 o.status_off = self.status_off
                 if p.get("flip_from"):
                     o.flip_from, o.in_c_off, o.w_off = p["flip_from"], p["n_kpt"], p["w_off"]
+                if p.get("scale_hms"):
+                    o.scale_hms, o.in_c_off = 1, p["n_kpt"]
         return arr
 
     def blob(self):
@@ -1190,7 +1196,7 @@ class Graph:
         ops_bytes = C.sizeof(_L.SmapOp) * n_ops
         w_off = _rup(ops_off + ops_bytes, ALIGN)
         wblob = self.weight_blob().numpy().tobytes()
-        hdr.magic, hdr.version, hdr.sizeof_op, hdr.header_bytes = b"SMAPPLN1", 1, C.sizeof(_L.SmapOp), C.sizeof(hdr)
+        hdr.magic, hdr.version, hdr.sizeof_op, hdr.header_bytes = b"SMAPPLN1", _L.BLOB_VERSION, C.sizeof(_L.SmapOp), C.sizeof(hdr)
         hdr.n_ops, hdr.ops_offset = n_ops, ops_off
         hdr.weights_offset, hdr.weights_bytes = w_off, len(wblob)
         hdr.arena_bytes, hdr.out_bytes = self.arena_bytes, self.out_bytes + 4 * self.status_words
@@ -1218,14 +1224,14 @@ class BackboneEngine:
     """Device-resident schedule for one (B, H, W): weights, arena, output buffer, plan."""
 
     def __init__(self, state_dict, B, H, W, device, stage_num=3, chl=256, kpt_paf=43, paf=14, reuse=True,
-                 precision="f16", flip_pair=None):
+                 precision="f16", flip_pair=None, scaled_hms=False):
         self.lib = _L.load()          # fails loudly when libsmap_hip.so is missing
         self.precision = precision
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("BackboneEngine needs a ROCm GPU device (no CPU path in smap_amd)")
         sd = {k: v.detach().cpu() for k, v in state_dict.items()}
-        g = Graph(sd, B, H, W, stage_num, chl, kpt_paf, paf, precision=precision, flip_pair=flip_pair)
+        g = Graph(sd, B, H, W, stage_num, chl, kpt_paf, paf, precision=precision, flip_pair=flip_pair, scaled_hms=scaled_hms)
         g.allocate(reuse=reuse)
         budget = arena_budget(self.device)
         if g.arena_bytes > budget:

@@ -19,6 +19,7 @@ SYMBOLS = [
     "smap_version", "smap_scale_hms", "smap_flip_merge", "smap_nms", "smap_paf_score", "smap_group", "smap_lift",
     "smap_refine", "smap_register_gt", "smap_lift_gt", "smap_refine_gt", "smap_refine_mlp", "smap_preprocess", "smap_sizeof_op", "smap_conv_tile_dims", "smap_conv_tile_bk", "smap_conv_tile_tail_bn", "smap_plan_create", "smap_plan_destroy", "smap_plan_run", "smap_plan_run_range",
     "smap_plan_run_inputs", "smap_workspace_bytes", "smap_plan_create_from_blob", "smap_plan_set_lanes",
+    "smap_nms_workspace_bytes", "smap_nms_ws",
 ]
 MAX_INPUTS = 8                         # SMAP_MAX_INPUTS
 
@@ -43,7 +44,7 @@ class SmapOp(C.Structure):
         ("tail_cout", C.c_int32), ("tail_cout_pad", C.c_int32), ("tail_acc_scale", C.c_float),
         ("tail_w_off", C.c_int64), ("tail_bias_off", C.c_int64),
         ("head_cin", C.c_int32), ("head_acc_scale", C.c_float), ("head_w_off", C.c_int64), ("head_bias_off", C.c_int64),
-        ("short_w_off", C.c_int64), ("short_acc_scale", C.c_float), ("reserved0", C.c_int32),
+        ("short_w_off", C.c_int64), ("short_acc_scale", C.c_float), ("scale_hms", C.c_int32),
         ("seg_n", C.c_int32 * 2), ("seg_cout", C.c_int32 * 2), ("seg_relu", C.c_int32 * 2), ("seg_out_stride_c", C.c_int32 * 2),
         ("seg_acc_scale", C.c_float * 2), ("seg_out_off", C.c_int64 * 2),
         ("ksplit", C.c_int32), ("reserved1", C.c_int32), ("kpart_off", C.c_int64), ("kcount_off", C.c_int64),
@@ -57,6 +58,9 @@ class BlobInfo(C.Structure):
                 ("n_hms", C.c_int32), ("n_det", C.c_int32), ("n_root", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32),
                 ("arena_bytes", C.c_int64), ("out_bytes", C.c_int64), ("weights_offset", C.c_int64), ("weights_bytes", C.c_int64),
                 ("hms_off", C.c_int64), ("det_off", C.c_int64), ("root_off", C.c_int64), ("status_off", C.c_int64)]
+
+
+BLOB_VERSION = 2          # include/smap_hip.h SMAP_BLOB_VERSION
 
 
 class BlobHeader(C.Structure):
@@ -90,6 +94,8 @@ def load():
     lib.smap_scale_hms.argtypes = [vp, ip, ip, ip, vp]
     lib.smap_flip_merge.argtypes = [vp, vp, C.POINTER(C.c_int), ip, ip, ip, vp]
     lib.smap_nms.argtypes = [vp, ip, ip, ip, ip, fp, vp, vp]
+    lib.smap_nms_workspace_bytes.argtypes = [ip, ip, ip]
+    lib.smap_nms_ws.argtypes = [vp, ip, ip, ip, ip, fp, vp, vp, C.c_int64, vp]
     lib.smap_paf_score.argtypes = [vp, vp, ip, ip, ip, vp, vp]
     lib.smap_group.argtypes = [vp, vp, vp, ip, ip, ip, ip, ip, vp, vp, vp]
     lib.smap_lift.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp, vp, vp, vp]
@@ -112,8 +118,9 @@ def load():
     lib.smap_workspace_bytes.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.smap_plan_create_from_blob.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(BlobInfo)]
     for s in SYMBOLS:
-        if s not in ("smap_version", "smap_plan_destroy"):  # everything else returns int
+        if s not in ("smap_version", "smap_plan_destroy", "smap_nms_workspace_bytes"):  # everything else returns int
             getattr(lib, s).restype = ip
+    lib.smap_nms_workspace_bytes.restype = C.c_int64
     if lib.smap_sizeof_op() != C.sizeof(SmapOp):
         raise ImportError(f"smap_op layout mismatch: C {lib.smap_sizeof_op()} vs ctypes {C.sizeof(SmapOp)}")
     _lib = lib

@@ -138,16 +138,17 @@ class SMAP(nn.Module):
         self.invalidate_engine()
         return super()._apply(fn, *a, **k)
 
-    def engine(self, B, H, W, device, flip_pair=None):
+    def engine(self, B, H, W, device, flip_pair=None, scaled_hms=False):
         """flip_pair: 43 channel indices (FLIP_ORDER + 15 + PAF FLIP_CHANNEL) -> an engine that runs the flip-TTA of
-        test.py:55-70 inside its schedule (B frames in, merged maps of B frames out)."""
-        key = (B, H, W, str(device), self.precision, tuple(flip_pair) if flip_pair is not None else None)
+        test.py:55-70 inside its schedule (B frames in, merged maps of B frames out).  scaled_hms: the engine writes hms / 255 | / 127,
+        the maps as test.py:111-112 hands them to dapalib (the pipelines); forward() keeps the raw maps the reference returns."""
+        key = (B, H, W, str(device), self.precision, tuple(flip_pair) if flip_pair is not None else None, bool(scaled_hms))
         if key not in self._engines:
             if (H // 4, W // 4) != self.output_shape:
                 raise ValueError(f"input {H}x{W} does not match cfg.OUTPUT_SHAPE {self.output_shape} (stride 4)")
             self._engines[key] = BackboneEngine(self.state_dict(), B, H, W, device, self.stage_num,
                                                 self.upsample_chl_num, self.kpt_paf_num, self.paf_num,
-                                                precision=self.precision, flip_pair=flip_pair)
+                                                precision=self.precision, flip_pair=flip_pair, scaled_hms=scaled_hms)
         return self._engines[key]
 
     def forward(self, imgs, valids=None, labels=None, rdepth=None):

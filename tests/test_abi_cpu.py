@@ -69,6 +69,11 @@ def test_plan_blob_round_trip_and_workspace_bytes():
         assert lib.smap_plan_create_from_blob(bytes(bad), len(bad), C.byref(plan), None) == -1      # magic
         assert lib.smap_plan_create_from_blob(blob, len(blob) // 2, C.byref(plan), None) == -1      # truncated
         hdr = L.BlobHeader.from_buffer_copy(blob[:C.sizeof(L.BlobHeader)])
+        assert hdr.version == L.BLOB_VERSION == 2
+        hdr.version = 1                                                                              # a blob of an older smap_op meaning, same struct size
+        old = bytes(hdr) + blob[C.sizeof(hdr):]
+        assert lib.smap_plan_create_from_blob(old, len(old), C.byref(plan), None) == -1
+        hdr = L.BlobHeader.from_buffer_copy(blob[:C.sizeof(L.BlobHeader)])
         hdr.arena_bytes = 4096                                                                       # header smaller than what the ops touch
         lied = bytes(hdr) + blob[C.sizeof(hdr):]
         assert lib.smap_plan_create_from_blob(lied, len(lied), C.byref(plan), None) == -1

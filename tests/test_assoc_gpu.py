@@ -89,6 +89,41 @@ def test_reference_api_connect_extract(batch):
             assert tuple(cands[j].shape) == (n, 3) and np.array_equal(bits(cands[j].numpy()), bits(opk[j, 1:1 + n]))
 
 
+def test_two_launch_peak_search_equals_the_fused_kernel_bit_for_bit(batch):
+    """smap_nms_ws (mask of the whole batch with one thread per pixel, then scan + centroids: what extract_batch runs) against the
+    single-launch smap_nms: the same [B,15,128,3] peak table bit for bit -- on the synthetic scenes (0..20 persons, the 127-peak cap in
+    the noise scenes), on map sizes that are no multiple of a wave / of the mask kernel's workgroup, and through the raw C ABI incl. its
+    argument checks (workspace too small / misaligned / missing)."""
+    import ctypes as C
+    import dapalib
+    from smap_amd import lib as L
+    _, hms, rd = batch
+    pk_ws, sc_ws = dapalib.extract_batch(hms)
+    pk_f, sc_f = dapalib.extract_batch(hms, fused_nms=True)
+    assert torch.equal(pk_ws.view(torch.int32), pk_f.view(torch.int32)) and torch.equal(sc_ws.view(torch.int32), sc_f.view(torch.int32))
+    assert pk_ws[:, :, 0, 0].max() >= 20
+    for (H, W), seed in (((13, 21), 1), ((40, 52), 2), ((3, 3), 3), ((100, 300), 4), ((128, 208), 5)):
+        rng = np.random.default_rng(seed)
+        x = torch.from_numpy(rng.uniform(0, 1, (3, 43, H, W)).astype(np.float32)).to(DEV)
+        a, _ = dapalib.extract_batch(x)
+        b, _ = dapalib.extract_batch(x, fused_nms=True)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (H, W)
+    lib = L.load()
+    x = hms[:2].contiguous()
+    nb = lib.smap_nms_workspace_bytes(2, 128, 208)
+    assert nb == 2 * 15 * 416 * 8 and lib.smap_nms_workspace_bytes(0, 128, 208) == 0
+    ws = torch.zeros(nb // 8 + 1, dtype=torch.int64, device=DEV)
+    pk = torch.empty((2, 15, 128, 3), dtype=torch.float32, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.smap_nms_ws(p(x), 2, 43, 128, 208, 0.2, p(pk), p(ws), nb, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(pk.view(torch.int32), pk_f[:2].view(torch.int32))
+    assert lib.smap_nms_ws(p(x), 2, 43, 128, 208, 0.2, p(pk), p(ws), nb - 8, st) == -1                      # too small
+    assert lib.smap_nms_ws(p(x), 2, 43, 128, 208, 0.2, p(pk), C.c_void_p(ws.data_ptr() + 4), nb, st) == -1   # misaligned
+    assert lib.smap_nms_ws(p(x), 2, 43, 128, 208, 0.2, p(pk), None, nb, st) == -1
+
+
 def test_other_map_sizes():
     import dapalib
     for (H, W), seed in (((16, 24), 1), ((32, 52), 2), ((64, 104), 3), ((100, 300), 4)):
@@ -103,6 +138,37 @@ def test_other_map_sizes():
             assert np.array_equal(bits(pk[i].cpu().numpy()), bits(opk))
             assert np.array_equal(bits(sc[i].cpu().numpy()), bits(osc))
             assert np.array_equal(bits(b[i, :len(ob)].cpu().numpy()), bits(ob))
+
+
+@pytest.mark.parametrize("flip", [False, True], ids=["plain", "flip-tta"])
+@pytest.mark.parametrize("precision", ["x3", "f16"])
+def test_head_sum_writes_the_scaled_maps_bit_for_bit(flip, precision):
+    """smap_op.scale_hms: the schedule's head sum stores hms / 255 | / 127 itself (test.py:111-112 fused into the backbone) -- bit for bit
+    what the in-place division of the raw maps gives, with and without the in-schedule flip-TTA merge; the depth maps are untouched."""
+    from benchkit.recipe import recipe_state_dict
+    from benchkit.workload import make_cfg
+    from model.smap import SMAP
+    torch.manual_seed(0)
+    cfg = make_cfg((16, 24))
+    net = SMAP(cfg).eval()
+    net.load_state_dict(recipe_state_dict(net.state_dict()))
+    net = net.to(DEV)
+    net.precision = precision
+    from exps.stage3_root2.config import cfg as ds
+    pair = (list(ds.DATASET.KEYPOINT.FLIP_ORDER) + [15 + c for c in ds.DATASET.PAF.FLIP_CHANNEL]) if flip else None
+    x = torch.randn(3, 3, 64, 96, generator=torch.Generator().manual_seed(5)).to(DEV)
+    raw = [t.clone() for t in net.engine(3, 64, 96, torch.device(DEV), flip_pair=pair).run(x)]
+    eng = net.engine(3, 64, 96, torch.device(DEV), flip_pair=pair, scaled_hms=True)
+    assert eng is not net.engine(3, 64, 96, torch.device(DEV), flip_pair=pair)
+    assert sum(int(op.p.get("scale_hms", 0)) for op in eng.graph.ops) == 1
+    got = [t.clone() for t in eng.run(x)]
+    want = raw[0].cpu()            # on the HOST, as test_scale_hms_matches_reference_division: IEEE fp32 division (torch's GPU kernel multiplies
+    want[:, :15] /= 255            # by the reciprocal of a scalar divisor, one ulp off in places); test.py:111-112
+    want[:, 15:] /= 127
+    assert raw[0].abs().max() > 0 and torch.equal(got[0].cpu(), want)
+    import dapalib
+    assert torch.equal(dapalib.scale_hms_(raw[0].clone()), got[0])        # = the stand-alone kernel the round-5 pipeline ran
+    assert torch.equal(got[1], raw[1]) and torch.equal(got[2], raw[2])
 
 
 def test_scale_hms_matches_reference_division():

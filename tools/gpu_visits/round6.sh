@@ -96,4 +96,23 @@ SMAP_TILE_TABLE_X3=$R/$O/tile_table_x3_t56.json SMAP_BENCH_NO_LF0=1 timeout 300 
 cat $O/ab_t56.log
 }
 
+v6() {
+# visit 6: /255,/127 inside the head sum (smap_op.scale_hms), the peak search as two launches (smap_nms_ws), one result copy per association pass:
+# association / entry / e2e tests, the bench line (association_lift_us_per_launch), the batch-1 full path
+O=gpurun_out/r6v6; mkdir -p $O
+timeout 1500 python -m pytest tests/test_assoc_gpu.py tests/test_ref_gpu.py tests/test_entry_gpu.py tests/test_e2e_parity_gpu.py tests/test_abi_gpu.py -m gpu -q --tb=short -p no:cacheprovider -x > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -12 $O/pytest.log
+for rep in 1 2; do
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 2>>$O/ab.err | line "rep $rep driver form" >> $O/bench.log
+done
+SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 2>>$O/ab.err | line "100 steps" >> $O/bench.log
+timeout 300 python bench.py --no-cpu-baseline --batch 1 --depth 1 --launch-frames 0 --steps 200 --warmup 20 > $O/bench_b1_full_path.json 2>>$O/ab.err
+python - <<'PY' >> gpurun_out/r6v6/bench.log
+import json
+d = json.load(open("gpurun_out/r6v6/bench_b1_full_path.json")); c = d["config"]
+print("batch 1 full path, depth 1:", round(d["value"], 1), "fps", round(d["ms_per_step"], 3), "ms/frame", "assoc_us", c.get("association_lift_us_per_launch"))
+PY
+cat $O/bench.log
+}
+
 "v$1"
