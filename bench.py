@@ -243,7 +243,11 @@ def dry_run(args):
     dt = time.perf_counter() - t0
     cpu_ms = (time.process_time() - cpu0) / args.steps * 1e3
     per_rank_cpu = [cpu_ms]
+    per_rank_dt = [dt]
     if world > 1:
+        dts = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]      # every rank's own clock (the GPU run reports the same block)
+        dist.all_gather(dts, torch.tensor([dt], dtype=torch.float64))
+        per_rank_dt = [float(x.item()) for x in dts]
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -259,6 +263,9 @@ def dry_run(args):
                                      "host_ms_per_step": {"process_cpu_per_rank": per_rank_cpu},
                                      "host_cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                                      "records_per_rank": [len(g) for g in got],
+                                     "per_rank": {"frames_per_sec": [args.batch * args.steps / x for x in per_rank_dt],
+                                                  "ms_per_step_max": max(per_rank_dt) / args.steps * 1e3,
+                                                  "ms_per_step_min": min(per_rank_dt) / args.steps * 1e3},
                                      "first_paths": [g[0]["image_path"] for g in got],
                                      "last_paths": [g[-1]["image_path"] for g in got]}}), flush=True)
     if world > 1:
@@ -328,6 +335,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU reference pass (no cpu_baseline, no config.e2e_parity): kernel experiments only")
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="distinct resident 8-frame batches the timed steps rotate over (1 = the same frames every step, as rounds 1-5 ran)")
     ap.add_argument("--launch-frames", type=int, default=16,
                     help="frames per backbone launch the pipeline aims for: consecutive steps' batches are coalesced up to it "
                          "(0 = one launch per step)")
@@ -401,10 +410,17 @@ def main():
         from model.refinenet import RefineNet
         torch.manual_seed(1)
         refine_w = RefineNet().eval().folded(dev)
-    SEED = 1234                      # frame 0 of this batch is the frame the heads were calibrated on; every rank
-    imgs_cpu = torch.randn(8, 3, H, W, generator=torch.Generator().manual_seed(SEED))   # runs the same 8 frames
-    imgs_cpu = imgs_cpu[:B] if B <= 8 else imgs_cpu.repeat((B + 7) // 8, 1, 1, 1)[:B]
-    imgs = imgs_cpu.to(dev)
+    SEED = 1234                      # frame 0 of batch 0 on rank 0 is the frame the heads were calibrated on
+    # The timed steps ROTATE over `--rotate` (default 4) distinct resident batches (round 5 ran the same 8 frames every step: 40 MB of input
+    # that never left the 256 MB Infinity Cache); with outputs and arenas > 256 MB are in play per step.  Rank r draws its own frames
+    # (seed + 104729 r): the gathered records then prove rank order by CONTENT.  Batch 0 of rank 0 = the frames the CPU reference runs.
+    NB = max(1, args.rotate)
+
+    def batch_images(j):
+        x = torch.randn(8, 3, H, W, generator=torch.Generator().manual_seed(SEED + 7919 * j + 104729 * rank))
+        return (x[:B] if B <= 8 else x.repeat((B + 7) // 8, 1, 1, 1)[:B]).to(dev)
+    img_batches = [batch_images(j) for j in range(NB)]
+    imgs = img_batches[0]
     cams = np.tile(np.asarray(PEOPLE_CAM, np.float64), (B, 1))
 
     # ---- end-to-end parity of THIS configuration (outside the timed region; rank 0, N = 1 reports it).  The CPU child
@@ -428,8 +444,11 @@ def main():
     for K in KS:
         sc = [synth_scene(K, seed=1000 * rank + 10 * K + i)[:2] for i in range(B)]
         synth[K] = (torch.from_numpy(np.stack([s_[0] for s_ in sc])).to(dev), torch.from_numpy(np.stack([s_[1] for s_ in sc])).to(dev))
-    tags = [f"r{rank}/f{i}" for i in range(B)]
+    batch_tags = [[f"r{rank}/b{j}/f{i}" for i in range(B)] for j in range(NB)]
     collected = []                   # this rank's records of the timed steps (gathered once, at the end of the run)
+    # the LAST timed launch (whose maps the parity block reads back) starts with batch 0: step k runs batch (k - first) mod NB
+    group = max(1, pipe.frames_per_launch // (B * (2 if args.flip else 1)))
+    first = (args.steps - group) % NB if args.steps >= group else 0
 
     host = {"submit": 0.0}
     step_no = [0]
@@ -437,9 +456,10 @@ def main():
     def step(timed):
         # backbone(k) on one stream; association+lift+D2H of batch k on another; records of earlier batches on the host
         K = KS[step_no[0] % len(KS)]
+        j = (step_no[0] - first) % NB
         step_no[0] += 1
         t0 = time.perf_counter()
-        recs = pipe.submit(imgs, cams, tags, extra=[(f"synthK{K}", synth[K][0], synth[K][1], None)], time_backbone=timed)
+        recs = pipe.submit(img_batches[j], cams, batch_tags[j], extra=[(f"synthK{K}", synth[K][0], synth[K][1], None)], time_backbone=timed)
         if timed:
             dt = time.perf_counter() - t0
             host["submit"] += dt
@@ -506,8 +526,9 @@ def main():
     if world == 1 and small is not None and not os.environ.get("SMAP_BENCH_NO_LF0"):
         def step0():
             K = KS[step_no[0] % len(KS)]
+            j = step_no[0] % NB
             step_no[0] += 1
-            small.submit(imgs, cams, tags, extra=[(f"synthK{K}", synth[K][0], synth[K][1], None)])
+            small.submit(img_batches[j], cams, batch_tags[j], extra=[(f"synthK{K}", synth[K][0], synth[K][1], None)])
         for _ in range(args.warmup):
             step0()
         small.flush()
@@ -519,7 +540,11 @@ def main():
         torch.cuda.synchronize()
         fps_lf0 = B * args.steps / (time.perf_counter() - t1)
     per_rank_host = [cpu_ms_per_step]
+    per_rank_dt = [dt]
     if world > 1:
+        dts = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]      # every rank's own clock, for the line's diagnostics
+        dist.all_gather(dts, torch.tensor([dt], dtype=torch.float64, device=cdev))
+        per_rank_dt = [float(x.item()) for x in dts]
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -539,23 +564,25 @@ def main():
         step_s = dt / args.steps if args.depth > 1 else bb * B / pipe.frames_per_launch
         fpl = pipe.frames_per_launch                                             # input frames per backbone launch
         alg_bytes = pipe.engine.alg_bytes_per_batch * B / fpl                    # bytes per launch schedule x launches per step
-        traffic, traffic_src = None, None                        # HBM bytes per batch from committed PMC passes
-        tj = os.path.join(ROOT, "profiles", "hbm_traffic_x3.json" if x3 else "hbm_traffic.json")
-        if os.path.exists(tj) and B == 8:
-            t = json.load(open(tj))
+        # Counters come from committed PMC passes (their own rocprofv3 runs).  They are quoted ONLY while the sources that decide the kernels
+        # (csrc/*, the header, the tile tables, the schedule builder: benchkit/buildhash.py) hash to what the passes were measured on;
+        # otherwise the fields are null and `counters` says which build the files belong to.
+        from benchkit.buildhash import counters_for_build
+        traffic, traffic_src = None, None                        # HBM bytes per batch
+        t, traffic_info = counters_for_build(os.path.join(ROOT, "profiles", "hbm_traffic_x3.json" if x3 else "hbm_traffic.json"))
+        if t is not None and B == 8:
             traffic = t["hbm_read_bytes_per_batch"] + t["hbm_write_bytes_per_batch"]
             traffic_src = t["source"]
         mfma_ctr, mfma_src = None, None                         # MFMA pipe utilisation by counters (separate PMC pass, depth 1)
-        mj = os.path.join(ROOT, "profiles", "mfma_utilisation_x3.json" if x3 else "mfma_utilisation.json")
-        if os.path.exists(mj) and B == 8:
-            t = json.load(open(mj))
+        t, mfma_info = counters_for_build(os.path.join(ROOT, "profiles", "mfma_utilisation_x3.json" if x3 else "mfma_utilisation.json"))
+        if t is not None and B == 8:
             mfma_ctr, mfma_src = t["pipe_utilisation"], t["source"]
 
         def hbm_view(nbytes):                                   # bytes per step -> GB/s over the timed region and its share of the HBM peak
             g = nbytes / step_s / 1e9
             return {"bytes_per_step": nbytes, "achieved": g, "frac": g / PEAK_HBM_GBPS}
         n_rec = len(collected) if gathered is None else sum(len(pickle.loads(b)) for b in gathered)
-        # every timed step runs the SAME frames (and one of four synthetic scenes): records with one image_path must be identical, bit
+        # the timed steps rotate over NB resident batches (and four synthetic scenes): records with one image_path must be identical, bit
         # for bit, whatever ran next to them on the GPU -- a guard the overlapped pipeline lacked until round 3 (EXPERIMENTS R3.6)
         n_rem = getattr(pipe, "remainder_records", 0)            # an odd step count leaves one batch to the batch-sized schedule, whose
         groups = {}                                              # kernels sum in other orders: compared with itself only
@@ -572,6 +599,11 @@ def main():
                                    f"+ lifting{' + RefineNet (configs[4])' if args.refine else ''}{' + flip-TTA' if args.flip else ''} "
                                    f"(BASELINE configs[2]; configs[3] when n_gpus=8)",
                        "frames_per_step": B * world, "records_in_run": n_rec,
+                       "resident_batches_in_rotation": NB, "input_bytes_in_rotation": NB * B * 3 * H * W * 4,
+                       # N > 1: every rank's own timed region (the headline divides by the MAX), so that a slow rank shows in ONE record
+                       "per_rank": {"frames_per_sec": [B * args.steps / x for x in per_rank_dt],
+                                    "ms_per_step_max": max(per_rank_dt) / args.steps * 1e3, "ms_per_step_min": min(per_rank_dt) / args.steps * 1e3,
+                                    "frame_seeds": [SEED + 104729 * r for r in range(world)]},
                        "timed_steps_reproduce": {"identical_records_per_frame_across_steps": identical, "frames_checked": len(groups),
                                                  "records_checked": len(collected) - n_rem,
                                                  "frames_with_variants": sorted(k for k, v in groups.items() if len(v) > 1)[:8]},
@@ -623,6 +655,9 @@ def main():
                          "pipe_frac": (3 if x3 else 1) * achieved / PEAK_F16_TFLOPS,
                          "pipe_frac_counters": mfma_ctr, "pipe_frac_counters_source": mfma_src,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_commit": traffic_info.get("measured_on_commit"),
+                         "counters_match_build": bool(traffic_info["counters_match_build"] and mfma_info["counters_match_build"]),
+                         "counters": {"traffic": traffic_info, "pipe_frac_counters": mfma_info},
                          "kernel": "conv_igemm_kernel / conv3x3_halo_kernel / convp_kernel / bottleneck_kernel / bottleneck128_kernel (all backbone launches; HIP "
                                    "events: per-schedule span below, rate = algorithmic work of the timed region / its duration when depth > 1)",
                          "hbm": {"peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -646,13 +681,13 @@ def main():
                 ms = parity.compare(hip_frames, cpu_ref["ref"])
                 m = parity.compare(timed_frames, cpu_ref["ref"]) if timed_frames is not None else None
                 if m is not None:
-                    # ... and the timed RECORDS are these very frames' results (bit for bit): frame i of the batch <-> image_path r0/f{i}
+                    # ... and the timed RECORDS are these very frames' results (bit for bit): frame i of batch 0 <-> image_path r0/b0/f{i}
                     by_path = {}
                     for r in collected:
                         by_path.setdefault(r["image_path"], r)
                     same = True
                     for i, fr in enumerate(timed_frames):
-                        r = by_path.get(f"r{rank}/f{i}")
+                        r = by_path.get(f"r{rank}/b0/f{i}")
                         if r is None:
                             same = same and len(fr["p3"]) == 0
                         else:

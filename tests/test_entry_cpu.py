@@ -305,6 +305,10 @@ def test_bench_control_flow_eight_ranks_gloo():
     assert d["config"]["first_paths"] == [f"r{k}/b2/f0" for k in range(8)]
     assert d["config"]["last_paths"] == [f"r{k}/b6/f7" for k in range(8)]
     assert len(d["config"]["host_ms_per_step"]["process_cpu_per_rank"]) == 8
+    # one record is enough to diagnose a scaling run: every rank's own rate and the slowest / fastest step time (the headline uses the MAX)
+    pr = d["config"]["per_rank"]
+    assert len(pr["frames_per_sec"]) == 8 and all(f > 0 for f in pr["frames_per_sec"])
+    assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] <= d["ms_per_step"] * 1.0001
 
 
 def test_test_py_dry_run_eight_ranks(tmp_path):

@@ -2,6 +2,8 @@
 amount the split-precision backbone differs from the fp32 reference (3e-6 of the map scale).  What is pinned here is the checker's
 own arithmetic: the DERIVED centroid-noise bound holds on every peak, joints moved by a straddled rounding step are classified as
 lifter ties within their cap, and a genuinely wrong coordinate is not."""
+import os
+
 import numpy as np
 import pytest
 
@@ -63,3 +65,34 @@ def test_a_wrong_coordinate_is_not_a_tie():
     assert m["joints_over_0.1cm_unexplained"] >= 1 or m["max_joint_err_cm"] <= 0.1, m
     if m["max_joint_err_cm"] > 0.1:
         assert m["joints_over_0.1cm_unexplained"] >= 1
+
+
+def test_counter_files_are_quoted_only_for_the_build_they_were_measured_on(tmp_path):
+    """bench.py's roofline.traffic / pipe_frac_counters come from committed PMC passes; benchkit/buildhash.py ties them to a hash of the
+    kernel sources, the header, the tile tables and the schedule builder: one flipped byte in a .hip file and the figures are withheld."""
+    import json
+    import shutil
+    from benchkit import buildhash as H
+    root = tmp_path / "tree"
+    for f in H.hashed_files():
+        dst = root / os.path.relpath(f, H.ROOT)
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        shutil.copy(f, dst)
+    assert len(H.hashed_files(str(root))) == len(H.hashed_files()) >= 12
+    h0 = H.source_hash(str(root))
+    assert h0 == H.source_hash()                                       # same bytes, same hash, wherever the tree lies
+    cj = tmp_path / "hbm_traffic_x3.json"
+    json.dump({"hbm_read_bytes_per_batch": 1.0, "hbm_write_bytes_per_batch": 2.0, "source": "test", "build_hash": h0, "commit": "abc"}, open(cj, "w"))
+    t, info = H.counters_for_build(str(cj), str(root))
+    assert t is not None and info["counters_match_build"] and info["measured_on_commit"] == "abc"
+    victim = root / "smap_amd" / "csrc" / "conv.hip"
+    raw = bytearray(victim.read_bytes())
+    raw[len(raw) // 2] ^= 1
+    victim.write_bytes(bytes(raw))
+    t, info = H.counters_for_build(str(cj), str(root))
+    assert t is None and not info["counters_match_build"] and info["measured_on_build"] == h0 != info["this_build"]
+    t, info = H.counters_for_build(str(tmp_path / "missing.json"), str(root))
+    assert t is None and not info["present"]
+    # a counter file from before the stamp existed (no build_hash) is never quoted
+    json.dump({"hbm_read_bytes_per_batch": 1.0, "hbm_write_bytes_per_batch": 2.0, "source": "old"}, open(cj, "w"))
+    assert H.counters_for_build(str(cj))[0] is None

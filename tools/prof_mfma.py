@@ -7,7 +7,11 @@ Over the conv launches of the LAST complete forward: SQ_VALU_MFMA_BUSY_CYCLES (s
 XCDs x 1024 SIMDs).  depth 1 so that kernels do not overlap."""
 import collections
 import csv
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from benchkit.buildhash import stamp  # noqa: E402
 
 CONV = ("conv_igemm", "conv3x3_halo", "convp_kernel", "conv3_tail_kernel", "bottleneck_kernel", "bottleneck_first_kernel", "bottleneck128_kernel")
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -40,4 +44,4 @@ if len(sys.argv) > 2:          # the figure bench.py quotes next to its arithmet
                          "--depth 1 --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline`: MFMA busy cycles / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) over the "
                          f"{len(conv)} conv launches of one 8-frame forward (tools/prof_mfma.py)",
                "pipe_utilisation": mf / (ga / 8 * 1024), "conv_launches": len(conv), "serial_conv_ms_at_2.4GHz": ga / 8 / 2.4e6,
-               "whole_block_launches_pipe_utilisation": (mfb / (gab / 8 * 1024)) if blk else None}, open(sys.argv[2], "w"), indent=1)
+               "whole_block_launches_pipe_utilisation": (mfb / (gab / 8 * 1024)) if blk else None, **stamp()}, open(sys.argv[2], "w"), indent=1)

@@ -7,7 +7,11 @@ complete forward in each trace.  FETCH_SIZE is doubled: gfx950 reports half of w
 (MI355X_MICROARCH.md; calibrated in round 1 on a 1x1 layer: 2 x FETCH_SIZE = input + residual + weights within 1 %)."""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from benchkit.buildhash import stamp  # noqa: E402
 
 CONV = ("conv_igemm", "conv3x3_halo", "conv1x1_ws", "convp_kernel", "conv3_tail_kernel", "bottleneck_kernel", "bottleneck_first_kernel", "bottleneck128_kernel")
 
@@ -38,6 +42,7 @@ def main():
            "hbm_read_bytes_per_batch": 2.0 * f_kb * 1024, "hbm_write_bytes_per_batch": w_kb * 1024,
            "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads; calibrated in "
                    "round 1 on a 1x1 layer: 2 x FETCH_SIZE = input + residual + weights bytes within 1 %)"}
+    out.update(stamp())          # build_hash / commit: bench.py quotes the figures only for the tree they were measured on
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
