@@ -231,6 +231,9 @@ def generate_3d_point_pairs(model, refine_model, data_loader, cfg, logger, devic
 
 
 def main():
+    # the schedule of a (checkpoint, shape, arithmetic) is built once and kept on disk (smap_amd/engine.py plan cache): the second start of
+    # this command loads it through smap_plan_create_from_blob instead of re-packing the weights (SMAP_PLAN_CACHE=0 switches it off)
+    os.environ.setdefault("SMAP_PLAN_CACHE", os.path.join(os.environ.get("XDG_CACHE_HOME", os.path.expanduser("~/.cache")), "smap_amd"))
     parser = argparse.ArgumentParser()
     parser.add_argument("--test_mode", "-t", type=str, default="run_inference",
                         choices=["generate_train", "generate_result", "run_inference"])

@@ -293,8 +293,11 @@ int smap_plan_run(const smap_plan* plan, const float* input, void* arena, const 
 #define SMAP_MAX_INPUTS 8
 int smap_plan_run_inputs(const smap_plan* plan, const float* const* inputs, int n_inputs, void* arena,
                          const void* weights, float* out, void* stream);
-/* Lanes on (1) / off (0, the default): see smap_op.lane.  Side streams and events are created on the device that is current at the first
- * run after switching them on, and destroyed with the plan. */
+/* Lanes on (1) / off (0, the default): see smap_op.lane.  Switching them on creates the side streams and events IN THIS CALL, on the current
+ * device (all or nothing: a failure is this call's return code and leaves nothing behind); they are destroyed with the plan.  smap_plan_run
+ * never creates anything (a first run inside a stream capture is fine) and joins the side lanes into the caller's stream on error returns
+ * too.  A plan with lanes ON has one caller at a time -- its side streams are shared by whoever runs it; with lanes off a plan is immutable
+ * and may be run from several host threads / executors at once. */
 int smap_plan_set_lanes(smap_plan* plan, int on);
 /* Bytes of arena and of output buffer the schedule touches, computed from the ops (either pointer may be NULL). */
 int smap_workspace_bytes(const smap_plan* plan, int64_t* arena_bytes, int64_t* out_bytes);

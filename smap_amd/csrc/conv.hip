@@ -465,13 +465,30 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         // atomic accesses (sc1: written through / read around the non-coherent caches), the writers wait for their stores to be
         // acknowledged (vmcnt counts stores on gfx9) before the barrier that precedes the ticket, and the ticket is an agent-scope
         // atomic: when the last arriver sees S - 1, every part is in memory.
+        // This hand-off is OUTSIDE the HIP / LLVM memory model (relaxed accesses, no release / acquire): it rests on gfx942 / gfx950 facts --
+        // an agent-scope atomic store is an sc1 write-THROUGH to memory, an agent-scope atomic load an sc1 read that misses the XCD's L2,
+        // vmcnt counts a store until memory has acknowledged it -- and on hipcc lowering relaxed agent-scope atomics to exactly those
+        // accesses.  So: only for the architectures it was verified on (the #error below), with the stress test of tests/test_backbone_gpu.py
+        // (::test_split_k_batch_1_full_size_many_runs_bit_for_bit: two streams, 40 runs, bit for bit) in the default GPU suite, and with
+        // -DSMAP_SPLITK_ACQREL=1 as the model-conforming form (release on the ticket of every writer, acquire on the last arriver's: an
+        // agent-scope release writes the XCD's L2 back; measured in EXPERIMENTS R6.5).
+#if !defined(__gfx942__) && !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "split K: the fence-free partial-tile hand-off is verified for gfx942 / gfx950 only; build with -DSMAP_SPLITK_ACQREL=1 elsewhere"
+#endif
+#ifndef SMAP_SPLITK_ACQREL
+#define SMAP_SPLITK_ACQREL 0
+#endif
         float* part = a.kpart + (size_t)tile_id * S * (BM * BN);
         for (int i = tid; i < BM * BN; i += NT) __hip_atomic_store(part + (size_t)ks * (BM * BN) + i, Cs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         volatile int* s_last = reinterpret_cast<volatile int*>(smem + LDS_BYTES - 16);     // behind the epilogue tile
         if (tid == 0) {
+#if SMAP_SPLITK_ACQREL
+            const unsigned t = __hip_atomic_fetch_add(a.kcount + tile_id, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
             const unsigned t = atomicAdd(a.kcount + tile_id, 1u);
+#endif
             *s_last = t == (unsigned)(S - 1);
             if (t == (unsigned)(S - 1)) atomicExch(a.kcount + tile_id, 0u);      // ready for the next launch
         }

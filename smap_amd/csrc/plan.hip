@@ -550,7 +550,8 @@ inline int grid_for(long long total, int block)
 struct smap_plan {
     std::vector<smap_op> ops;
     std::vector<int64_t> windows;          // arena offsets of the zero pages this schedule's conv launches address through
-    int64_t kcount_lo = 0, kcount_hi = 0;  // arena byte range that holds the split-K tickets of every op (one contiguous region)
+    struct Ticket { int64_t off, bytes; int op; };
+    std::vector<Ticket> tickets;           // arena byte range of every split-K op's ticket slice (zeroed per op by smap_plan_run)
     // lanes (smap_op.lane): side streams 1 .. SMAP_MAX_LANES - 1 and one event per op some other lane waits for; created on first use
     bool lanes_on = false, lanes_ready = false;
     int n_lanes = 1;
@@ -759,47 +760,89 @@ int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan)
                 int bm = 0, bn = 1;
                 smap_conv_tile_dims(ops[i].tile, &bm, &bn);
                 const int64_t tiles = (((int64_t)ops[i].B * ops[i].Ho * ops[i].Wo + bm - 1) / bm) * (ops[i].cout_pad / bn);
-                const int64_t lo = ops[i].kcount_off, hi = lo + tiles * 4;
-                if (p->kcount_hi == p->kcount_lo) { p->kcount_lo = lo; p->kcount_hi = hi; }
-                else { if (lo < p->kcount_lo) p->kcount_lo = lo; if (hi > p->kcount_hi) p->kcount_hi = hi; }
+                p->tickets.push_back({ops[i].kcount_off, tiles * 4, i});
             }
         }
-        if (p->kcount_hi - p->kcount_lo > (1 << 22)) { delete p; return SMAP_E_ARG; }      // tickets of one schedule live in ONE small region (the packer's contract)
+    // Split-K tickets: smap_plan_run zeroes EACH op's own slice (not a span from the lowest to the highest ticket: a foreign blob may put
+    // tensors in between), and a slice overlaps neither another op's slice nor any tensor / scratch range an op of the schedule touches --
+    // the tickets live for the whole schedule, whatever the packer reuses around them.
+    for (size_t t = 0; t < p->tickets.size(); ++t) {
+        const int64_t lo = p->tickets[t].off, hi = lo + p->tickets[t].bytes;
+        for (size_t u = 0; u < t; ++u)
+            if (lo < p->tickets[u].off + p->tickets[u].bytes && p->tickets[u].off < hi) { delete p; return SMAP_E_ARG; }
+        for (int i = 0; i < n_ops; ++i) {
+            const smap_op& o = ops[i];
+            if (o.kind != SMAP_OP_CONV && o.kind != SMAP_OP_STEM && o.kind != SMAP_OP_MAXPOOL && o.kind != SMAP_OP_UPADD && o.kind != SMAP_OP_STEMPOOL) continue;
+            const int64_t M = (int64_t)o.B * o.Ho * o.Wo, pl = 1 + o.precision;
+            const int64_t c8 = o.tail_cout > 0 ? o.tail_cout : ((o.Cout + 7) & ~7);
+            auto hit = [&](int64_t off, int64_t bytes) { return off >= 0 && bytes > 0 && off < hi && lo < off + bytes; };
+            bool bad = hit(o.out_off, M * (o.kind == SMAP_OP_CONV ? (int64_t)o.out_stride_c * (o.out_fp32 ? 4 : 2) : c8 * 2 * pl));
+            if (o.kind == SMAP_OP_CONV || o.kind == SMAP_OP_MAXPOOL || o.kind == SMAP_OP_UPADD)
+                bad = bad || hit(o.in_off, (int64_t)o.B * o.H * o.W * (o.kind == SMAP_OP_CONV ? (int64_t)o.in_stride_c * 2 : (int64_t)o.Cin * 2 * pl));
+            if (o.kind == SMAP_OP_CONV) {
+                bad = bad || hit(o.res_off, M * c8 * 2 * pl) || hit(o.add1_off, M * c8 * 2 * pl) || hit(o.add2_off, M * c8 * 2 * pl);
+                bad = bad || hit(o.aux_off[0], (int64_t)o.B * o.aux_h[0] * o.aux_w[0] * c8 * 2 * pl);
+                for (int j = 0; j < 2; ++j)
+                    if (o.seg_n[j] > 0) bad = bad || hit(o.seg_out_off[j], M * o.seg_out_stride_c[j] * 2);
+                if (o.ksplit > 1) {
+                    int bm = 0, bn = 1;
+                    smap_conv_tile_dims(o.tile, &bm, &bn);
+                    const int64_t tiles = ((M + bm - 1) / bm) * (o.cout_pad / bn);
+                    bad = bad || hit(o.kpart_off, tiles * o.ksplit * bm * bn * 4);
+                }
+            }
+            if (bad) { delete p; return SMAP_E_ARG; }
+        }
+    }
     *plan = p;
     return 0;
 }
 
+static void lanes_release(smap_plan* p);
+
 void smap_plan_destroy(smap_plan* plan)
 {
     if (!plan) return;
-    for (hipEvent_t e : plan->ev) if (e) hipEventDestroy(e);
-    for (int l = 0; l < SMAP_MAX_LANES; ++l) {
-        if (plan->join_ev[l]) hipEventDestroy(plan->join_ev[l]);
-        if (plan->side[l]) hipStreamDestroy(plan->side[l]);
-    }
+    lanes_release(plan);
     delete plan;
 }
 
-int smap_plan_set_lanes(smap_plan* plan, int on)
+static void lanes_release(smap_plan* p)
 {
-    if (!plan) return SMAP_E_ARG;
-    plan->lanes_on = on != 0;
-    return 0;
+    for (hipEvent_t& e : p->ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (int l = 0; l < SMAP_MAX_LANES; ++l) {
+        if (p->join_ev[l]) { (void)hipEventDestroy(p->join_ev[l]); p->join_ev[l] = nullptr; }
+        if (p->side[l]) { (void)hipStreamDestroy(p->side[l]); p->side[l] = nullptr; }
+    }
+    p->lanes_ready = false;
 }
 
-// side streams + events of a plan whose lanes were switched on (device = the current one)
+// side streams + events of a plan whose lanes are switched on (device = the current one).  All or nothing: a failure half way releases
+// what was created, so that the next attempt starts clean (round 5 created them lazily inside the const run and leaked on failure).
 static int lanes_setup(smap_plan* p)
 {
     if (p->lanes_ready) return 0;
-    for (int l = 1; l < p->n_lanes; ++l)
-        if (hipError_t e = hipStreamCreateWithFlags(&p->side[l], hipStreamNonBlocking); e != hipSuccess) return hip_rc(e);
-    for (int l = 0; l < p->n_lanes; ++l)
-        if (hipError_t e = hipEventCreateWithFlags(&p->join_ev[l], hipEventDisableTiming); e != hipSuccess) return hip_rc(e);
+    hipError_t e = hipSuccess;
+    for (int l = 1; l < p->n_lanes && e == hipSuccess; ++l) e = hipStreamCreateWithFlags(&p->side[l], hipStreamNonBlocking);
+    for (int l = 0; l < p->n_lanes && e == hipSuccess; ++l) e = hipEventCreateWithFlags(&p->join_ev[l], hipEventDisableTiming);
     p->ev.assign(p->ops.size(), nullptr);
-    for (size_t i = 0; i < p->ops.size(); ++i)
-        if (p->signalled[i])
-            if (hipError_t e = hipEventCreateWithFlags(&p->ev[i], hipEventDisableTiming); e != hipSuccess) return hip_rc(e);
+    for (size_t i = 0; i < p->ops.size() && e == hipSuccess; ++i)
+        if (p->signalled[i]) e = hipEventCreateWithFlags(&p->ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) { lanes_release(p); return hip_rc(e); }
     p->lanes_ready = true;
+    return 0;
+}
+
+// Lanes on / off.  Switching them ON creates the side streams and events HERE (on the current device), not inside a run: a first run inside
+// a stream capture must not create streams, smap_plan_run stays const, and a failure is this call's return code.  A plan with lanes on has
+// ONE caller at a time (its side streams and events are shared by whoever runs it: executors of one plan on several host threads are not
+// supported with lanes; without lanes a plan is immutable and may be run concurrently).
+int smap_plan_set_lanes(smap_plan* plan, int on)
+{
+    if (!plan) return SMAP_E_ARG;
+    if (on && plan->n_lanes > 1)
+        if (int rc = lanes_setup(plan)) return rc;
+    plan->lanes_on = on != 0;
     return 0;
 }
 
@@ -819,18 +862,35 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
     const bool have_input = n_inputs > 0 && inputs[0];
     for (int64_t w : plan->windows)
         if (hipError_t e = hipMemsetAsync(ar + w, 0, SMAP_ZERO_PAGE, st); e != hipSuccess) return hip_rc(e);
-    if (plan->kcount_hi > plan->kcount_lo)               // split-K tickets: zero before the first op (the kernels leave them at zero; an aborted run may not)
-        if (hipError_t e = hipMemsetAsync(ar + plan->kcount_lo, 0, (size_t)(plan->kcount_hi - plan->kcount_lo), st); e != hipSuccess) return hip_rc(e);
+    // split-K tickets: zero before the first op (the kernels leave them at zero; an aborted run may not) -- the slices of the ops THIS run
+    // launches, one memset each when they are apart, one for the lot when the packer laid them end to end (engine.py does)
+    for (size_t t = 0; t < plan->tickets.size();) {
+        if (plan->tickets[t].op < first || plan->tickets[t].op >= first + count) { ++t; continue; }
+        int64_t lo = plan->tickets[t].off, hi = lo + plan->tickets[t].bytes;
+        size_t u = t + 1;
+        while (u < plan->tickets.size() && plan->tickets[u].off == hi && plan->tickets[u].op < first + count) hi += plan->tickets[u++].bytes;
+        if (hipError_t e = hipMemsetAsync(ar + lo, 0, (size_t)(hi - lo), st); e != hipSuccess) return hip_rc(e);
+        t = u;
+    }
     for (int i = first; i < first + count; ++i)          // the status word (one per schedule) starts every run at 0
         if (plan->ops[i].kind == SMAP_OP_HEADSUM && plan->ops[i].status_off > 0 && out) {
             if (hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(out) + plan->ops[i].status_off, 0, 4 * (size_t)SMAP_STATUS_WORDS(plan->ops[i].B), st); e != hipSuccess) return hip_rc(e);
             break;
         }
     // lanes: only for whole-schedule runs (a partial range may start behind a fork)
-    const bool lanes = plan->lanes_on && plan->n_lanes > 1 && first == 0 && count == (int)plan->ops.size();
+    const bool lanes = plan->lanes_on && plan->lanes_ready && plan->n_lanes > 1 && first == 0 && count == (int)plan->ops.size();
     hipStream_t const st0 = st;
+    // (error returns behind the fork go through `fail`: the side lanes are joined into the caller's stream first, so that nothing of this run
+    //  is still in flight on a stream the caller does not know about)
+    auto join = [&]() -> int {
+        for (int l = 1; l < plan->n_lanes; ++l) {
+            if (hipError_t e = hipEventRecord(plan->join_ev[l], plan->side[l]); e != hipSuccess) return hip_rc(e);
+            if (hipError_t e = hipStreamWaitEvent(st0, plan->join_ev[l], 0); e != hipSuccess) return hip_rc(e);
+        }
+        return 0;
+    };
+    auto fail = [&](int rc) -> int { if (lanes) (void)join(); return rc; };
     if (lanes) {
-        if (int rc = lanes_setup(const_cast<smap_plan*>(plan))) return rc;
         // the side lanes start behind what the caller's stream holds so far (its earlier work, the memsets above)
         if (hipError_t e = hipEventRecord(plan->join_ev[0], st0); e != hipSuccess) return hip_rc(e);
         for (int l = 1; l < plan->n_lanes; ++l)
@@ -842,7 +902,7 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
         if (lanes) {
             st = o.lane > 0 ? plan->side[o.lane] : st0;
             for (int k = 0; k < o.n_wait; ++k)
-                if (hipError_t e2 = hipStreamWaitEvent(st, plan->ev[o.wait_op[k]], 0); e2 != hipSuccess) return hip_rc(e2);
+                if (hipError_t e2 = hipStreamWaitEvent(st, plan->ev[o.wait_op[k]], 0); e2 != hipSuccess) return fail(hip_rc(e2));
         }
         switch (o.kind) {
             case SMAP_OP_CONV: {
@@ -911,8 +971,8 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
             }
             case SMAP_OP_STEM: {
                 const int frames = o.flip_from > 0 ? o.flip_from : o.B;       // frames the input holds
-                if (!have_input || frames % n_inputs) return SMAP_E_ARG;
-                for (int j = 0; j < n_inputs; ++j) if (!inputs[j]) return SMAP_E_ARG;
+                if (!have_input || frames % n_inputs) return fail(SMAP_E_ARG);
+                for (int j = 0; j < n_inputs; ++j) if (!inputs[j]) return fail(SMAP_E_ARG);
                 sin.frames_per = frames / n_inputs;
                 dim3 grid((o.Wo + ST_T - 1) / ST_T, (o.Ho + ST_T - 1) / ST_T, o.B);
                 if (o.precision)
@@ -930,8 +990,8 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
             }
             case SMAP_OP_STEMPOOL: {
                 const int frames = o.flip_from > 0 ? o.flip_from : o.B;
-                if (!have_input || frames % n_inputs) return SMAP_E_ARG;
-                for (int j = 0; j < n_inputs; ++j) if (!inputs[j]) return SMAP_E_ARG;
+                if (!have_input || frames % n_inputs) return fail(SMAP_E_ARG);
+                for (int j = 0; j < n_inputs; ++j) if (!inputs[j]) return fail(SMAP_E_ARG);
                 sin.frames_per = frames / n_inputs;
                 const int hs = (o.H + 6 - 7) / 2 + 1, ws = (o.W + 6 - 7) / 2 + 1;
                 dim3 grid((o.Wo + SP_PX - 1) / SP_PX, (o.Ho + SP_PY - 1) / SP_PY, o.B);
@@ -968,7 +1028,7 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
                 break;
             }
             case SMAP_OP_HEADSUM: {
-                if (!out) return SMAP_E_ARG;
+                if (!out) return fail(SMAP_E_ARG);
                 HeadSrc s;
                 s.n = o.n_aux;
                 for (int k = 0; k < 3; ++k) {
@@ -989,17 +1049,13 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
                 break;
             }
             default:
-                return SMAP_E_ARG;
+                return fail(SMAP_E_ARG);
         }
-        if (e != hipSuccess) return hip_rc(e);
+        if (e != hipSuccess) return fail(hip_rc(e));
         if (lanes && plan->signalled[i])
-            if (hipError_t e2 = hipEventRecord(plan->ev[i], st); e2 != hipSuccess) return hip_rc(e2);
+            if (hipError_t e2 = hipEventRecord(plan->ev[i], st); e2 != hipSuccess) return fail(hip_rc(e2));
     }
-    if (lanes)                                           // join: the caller's stream continues when every lane is done
-        for (int l = 1; l < plan->n_lanes; ++l) {
-            if (hipError_t e = hipEventRecord(plan->join_ev[l], plan->side[l]); e != hipSuccess) return hip_rc(e);
-            if (hipError_t e = hipStreamWaitEvent(st0, plan->join_ev[l], 0); e != hipSuccess) return hip_rc(e);
-        }
+    if (lanes) return join();                            // the caller's stream continues when every lane is done
     return 0;
 }
 

@@ -402,18 +402,23 @@ DEFAULT_REMAP = {}
 class ArenaTooLarge(ValueError):
     """The schedule does not fit: ONE activation tensor exceeds a 4 GiB window (the conv kernels address their input with 32-bit
     byte offsets from a 4 GiB-aligned base, csrc/plan.hip: 52 frames of the widest split-precision tensor), or the whole arena
-    exceeds the memory budget (BackboneEngine: SMAP_MAX_ARENA_BYTES, default 45 % of the device memory that is free when the engine
-    is built -- a pipeline keeps one arena per backbone in flight).  Either way: run the frames in smaller launches
+    exceeds the memory budget (BackboneEngine: SMAP_MAX_ARENA_BYTES, default 90 % of the device's memory / 4 arenas -- a pipeline keeps
+    one arena per backbone in flight and per schedule size).  Either way: run the frames in smaller launches
     (PosePipeline splits by itself)."""
 
 
+ARENAS_PER_DEVICE = 4       # what a pipeline keeps: `depth` (2) backbones in flight x (the coalesced schedule + the batch-sized one for trailing groups)
+
+
 def arena_budget(device):
-    """Bytes one activation arena may take on `device`: SMAP_MAX_ARENA_BYTES, else 45 % of what is free right now."""
+    """Bytes ONE activation arena may take on `device`: SMAP_MAX_ARENA_BYTES, else 90 % of the device's TOTAL memory shared out over the
+    arenas a pipeline keeps (SMAP_ARENAS_PER_DEVICE, default 4).  (Round 5 took 45 % of what happened to be FREE when the engine was built:
+    the chunking of a pipeline -- hence its throughput -- then depended on the allocator's state and on which engine was built first.)"""
     env = os.environ.get("SMAP_MAX_ARENA_BYTES", "")
     if env:
         return int(float(env))
-    free, _ = torch.cuda.mem_get_info(device)
-    return int(0.45 * free)
+    _, total = torch.cuda.mem_get_info(device)
+    return int(0.9 * total / max(1, int(os.environ.get("SMAP_ARENAS_PER_DEVICE", ARENAS_PER_DEVICE))))
 
 
 class Graph:
@@ -1219,6 +1224,55 @@ class Graph:
         return blob
 
 
+# ----------------------------------------------------------------------------- plan cache
+# Building a schedule is 2.5-10 s of Python (BN folding in f64, hi/lo splits, weight packing for ~150 launches); its result -- Graph.blob():
+# ops + packed weights -- depends only on the checkpoint, the shape, the arithmetic, the tile tables and this file.  With SMAP_PLAN_CACHE=<dir>
+# (exps/stage3_root2/test.py defaults it to ~/.cache/smap_amd) BackboneEngine stores the blob there and the next process loads it through
+# smap_plan_create_from_blob: < 1 s from the page cache instead of the build.  At most PLAN_CACHE_KEEP blobs are kept (oldest out).
+PLAN_CACHE_KEEP = 6
+
+
+def plan_cache_dir():
+    d = os.environ.get("SMAP_PLAN_CACHE", "")
+    return None if d in ("", "0") else os.path.expanduser(d)
+
+
+def state_hash(sd):
+    """Content hash of a state dict (keys, shapes, dtypes, bytes): xxh3 when the module is there (~10 GB/s), else blake2b."""
+    try:
+        import xxhash
+        h = xxhash.xxh3_128()
+    except ImportError:                                     # pragma: no cover
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+    for k in sorted(sd):
+        t = sd[k].detach().cpu().contiguous()
+        h.update(f"{k}|{tuple(t.shape)}|{t.dtype}|".encode())
+        h.update(t.reshape(-1).view(torch.uint8).numpy().data if t.numel() else b"")
+    return h.hexdigest()
+
+
+def _schedule_env():
+    """The SMAP_* switches that change what Graph builds (tile overrides, merge policy, split K ...): part of the cache key."""
+    skip = ("SMAP_PLAN_CACHE", "SMAP_HIP_LIB", "SMAP_BENCH", "SMAP_CLI", "SMAP_DECODE", "SMAP_STRICT", "SMAP_CHECK", "SMAP_FORCE", "SMAP_GIT",
+            "SMAP_MAX_ARENA", "SMAP_MAX_FRAMES", "SMAP_BB_STREAM")
+    return sorted((k, v) for k, v in os.environ.items() if k.startswith("SMAP_") and not k.startswith(skip))
+
+
+def plan_cache_key(sd, B, H, W, stage_num, chl, kpt_paf, paf, precision, flip_pair, scaled_hms):
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.blake2b(digest_size=16)
+    h.update(repr((state_hash(sd), B, H, W, stage_num, chl, kpt_paf, paf, precision, tuple(flip_pair) if flip_pair is not None else None,
+                   bool(scaled_hms), _L.BLOB_VERSION, C.sizeof(_L.SmapOp), _L.version(), _schedule_env())).encode())
+    for f in ("engine.py", "tile_table.json", "tile_table_x3.json"):      # the schedule builder and its tables
+        h.update(open(os.path.join(here, f), "rb").read())
+    tt = os.environ.get("SMAP_TILE_TABLE_X3") or os.environ.get("SMAP_TILE_TABLE")
+    if tt and os.path.exists(tt):
+        h.update(open(tt, "rb").read())
+    return h.hexdigest()
+
+
 # ----------------------------------------------------------------------------- engine
 class BackboneEngine:
     """Device-resident schedule for one (B, H, W): weights, arena, output buffer, plan."""
@@ -1231,38 +1285,102 @@ class BackboneEngine:
         if self.device.type != "cuda":
             raise RuntimeError("BackboneEngine needs a ROCm GPU device (no CPU path in smap_amd)")
         sd = {k: v.detach().cpu() for k, v in state_dict.items()}
-        g = Graph(sd, B, H, W, stage_num, chl, kpt_paf, paf, precision=precision, flip_pair=flip_pair, scaled_hms=scaled_hms)
-        g.allocate(reuse=reuse)
-        budget = arena_budget(self.device)
-        if g.arena_bytes > budget:
-            raise ArenaTooLarge(f"the activation arena of a {B}-frame schedule ({precision}{', flip-TTA' if flip_pair is not None else ''}) takes "
-                                f"{g.arena_bytes / 2 ** 30:.2f} GiB, the budget is {budget / 2 ** 30:.2f} GiB (SMAP_MAX_ARENA_BYTES / 45 % of the "
-                                "free device memory): use smaller launches")
-        self.graph, self.B, self.H, self.W = g, B, H, W
-        self.h, self.w = g.out_h, g.out_w
-        self.ops = g.emit()
-        self.n_ops = len(g.ops)
-        self.weights = g.weight_blob().to(self.device)
-        self.arena = torch.zeros((g.arena_bytes,), dtype=torch.uint8, device=self.device)
-        handle = C.c_void_p()
-        with torch.cuda.device(self.device):
-            _L.check(self.lib.smap_plan_create(self.ops, self.n_ops, C.byref(handle)), "smap_plan_create")
-        self.handle = handle
-        if g.lanes:
-            _L.check(self.lib.smap_plan_set_lanes(handle, 1), "smap_plan_set_lanes")
+        self._graph_args = (sd, B, H, W, stage_num, chl, kpt_paf, paf, precision, flip_pair, scaled_hms, reuse)
+        self._graph = None
+        self.B, self.H, self.W = B, H, W
         self.kpt_paf, self.paf = kpt_paf, paf
-        self.out_floats = g.out_bytes // 4
-        self.status_words = g.status_words
+        self.from_cache = False
+        cdir = plan_cache_dir() if reuse else None         # (reuse=False: debugging layouts, never cached)
+        meta = None
+        if cdir is not None:
+            self.cache_key = plan_cache_key(sd, B, H, W, stage_num, chl, kpt_paf, paf, precision, flip_pair, scaled_hms)
+            meta = self._load_cached(cdir)
+        if meta is None:
+            g = self.graph                                 # builds and allocates the schedule
+            meta = dict(arena_bytes=g.arena_bytes, out_h=g.out_h, out_w=g.out_w, out_bytes=g.out_bytes, status_words=g.status_words,
+                        lanes=int(g.lanes), flops=g.flops, alg_bytes=g.alg_bytes, n_ops=len(g.ops))
+        budget = arena_budget(self.device)
+        if meta["arena_bytes"] > budget:
+            raise ArenaTooLarge(f"the activation arena of a {B}-frame schedule ({precision}{', flip-TTA' if flip_pair is not None else ''}) takes "
+                                f"{meta['arena_bytes'] / 2 ** 30:.2f} GiB, the budget is {budget / 2 ** 30:.2f} GiB (SMAP_MAX_ARENA_BYTES / 90 % of the "
+                                "device memory shared by 4 arenas): use smaller launches")
+        self.h, self.w = meta["out_h"], meta["out_w"]
+        self.n_ops = meta["n_ops"]
+        if not self.from_cache:
+            g = self.graph
+            self.ops = g.emit()
+            self.weights = g.weight_blob().to(self.device)
+            handle = C.c_void_p()
+            with torch.cuda.device(self.device):
+                _L.check(self.lib.smap_plan_create(self.ops, self.n_ops, C.byref(handle)), "smap_plan_create")
+            self.handle = handle
+            if cdir is not None:
+                self._store_cached(cdir, meta)
+        self.arena = torch.zeros((meta["arena_bytes"],), dtype=torch.uint8, device=self.device)
+        if meta["lanes"]:
+            _L.check(self.lib.smap_plan_set_lanes(self.handle, 1), "smap_plan_set_lanes")
+        self.out_floats = meta["out_bytes"] // 4
+        self.status_words = meta["status_words"]
         self.out = self.new_output()                      # default output buffer
         self.hms, self.det_d, self.root_d = self.views(self.out)
-        self.flops_per_batch = g.flops
-        self.alg_bytes_per_batch = g.alg_bytes            # conv launches only (stem / pool / head sums are < 3 % more)
+        self.flops_per_batch = meta["flops"]
+        self.alg_bytes_per_batch = meta["alg_bytes"]      # conv launches only (stem / pool / head sums are < 3 % more)
+
+    @property
+    def graph(self):
+        """The schedule as Python objects (ops, tensors, weight chunks).  An engine loaded from the plan cache builds it only when somebody
+        asks (profiling tools, tests, blob()): the launches themselves need the plan handle alone."""
+        if self._graph is None:
+            sd, B, H, W, stage_num, chl, kpt_paf, paf, precision, flip_pair, scaled_hms, reuse = self._graph_args
+            g = Graph(sd, B, H, W, stage_num, chl, kpt_paf, paf, precision=precision, flip_pair=flip_pair, scaled_hms=scaled_hms)
+            g.allocate(reuse=reuse)
+            self._graph = g
+        return self._graph
+
+    def _load_cached(self, cdir):
+        """Plan + weights from <cdir>/<key>.smapplan through smap_plan_create_from_blob, or None (absent / refused: rebuilt and rewritten)."""
+        import json
+        path = os.path.join(cdir, self.cache_key + ".smapplan")
+        if not (os.path.exists(path) and os.path.exists(path + ".json")):
+            return None
+        try:
+            meta = json.load(open(path + ".json"))
+            raw = torch.from_file(path, shared=False, size=os.path.getsize(path), dtype=torch.uint8)
+            handle, info = C.c_void_p(), _L.BlobInfo()
+            with torch.cuda.device(self.device):
+                rc = self.lib.smap_plan_create_from_blob(C.c_void_p(raw.data_ptr()), raw.numel(), C.byref(handle), C.byref(info))
+            if rc != 0 or info.arena_bytes != meta["arena_bytes"] or info.frames != self.B:
+                return None
+            self.weights = raw[info.weights_offset:info.weights_offset + info.weights_bytes].to(self.device)
+            self.handle, self.ops, self.from_cache = handle, None, True
+            os.utime(path)                                  # most recently used
+            return meta
+        except Exception:                                   # a damaged cache entry is not an error: build the schedule
+            return None
+
+    def _store_cached(self, cdir, meta):
+        import json
+        try:
+            os.makedirs(cdir, exist_ok=True)
+            path = os.path.join(cdir, self.cache_key + ".smapplan")
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as f:
+                f.write(self.graph.blob())
+            os.replace(tmp, path)
+            json.dump(meta, open(path + ".json", "w"))
+            old = sorted((p for p in (os.path.join(cdir, n) for n in os.listdir(cdir)) if p.endswith(".smapplan")), key=os.path.getmtime)
+            for p_ in old[:-PLAN_CACHE_KEEP]:
+                for q in (p_, p_ + ".json"):
+                    if os.path.exists(q):
+                        os.remove(q)
+        except OSError:                                     # read-only home, full disk: the cache is an optimisation
+            pass
 
     def sibling(self):
         """A second executor of the same schedule with its own arena (weights and plan shared), so that
         two batches can be in flight on two streams."""
         import copy
-        e = copy.copy(self)
+        e = copy.copy(self)                # (shares _graph / _graph_args too)
         e.arena = torch.zeros_like(self.arena)
         e.out = e.new_output()
         e.hms, e.det_d, e.root_d = e.views(e.out)

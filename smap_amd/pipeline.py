@@ -95,7 +95,7 @@ class PosePipeline:
         self.flip_pair = list(cfg.DATASET.KEYPOINT.FLIP_ORDER) + [kpt + c for c in cfg.DATASET.PAF.FLIP_CHANNEL]
         # frames per backbone launch: the whole batch, or the largest divisor of it that the engine accepts (ArenaTooLarge: one tensor
         # beyond a 4 GiB addressing window -- 53+ frames in split precision -- or an arena beyond the memory budget, SMAP_MAX_ARENA_BYTES /
-        # 45 % of the free device memory: every backbone in flight has its own arena)
+        # 90 % of the device memory shared by 4 arenas: every backbone in flight has its own)
         from .engine import ArenaTooLarge
         limit = max_frames_per_launch or int(os.environ.get("SMAP_MAX_FRAMES_PER_LAUNCH", "0")) or batch
         self.chunk = None
@@ -107,9 +107,12 @@ class PosePipeline:
                 self.engine = model.engine(batch // parts, H, W, self.device, flip_pair=self.flip_pair if do_flip else None, scaled_hms=True)
                 self.chunk = batch // parts
                 break
-            except ArenaTooLarge:
+            except ArenaTooLarge as exc:
                 if parts == batch:
                     raise
+                import logging                          # not silently: the chunking decides the throughput
+                logging.getLogger("smap_amd").warning("PosePipeline: %d frames do not run as one backbone launch (%s); trying %d launches per batch",
+                                                      batch // parts, exc, parts + 1)
         self._model, self._generation = model, model.weights_generation      # a reload / .to() after this point makes the
                                                                              # pipeline stale: submit() refuses to run on old weights
         self.refine = refine_weights

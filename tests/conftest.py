@@ -9,6 +9,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
         sys.path.insert(0, p)
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("SMAP_PLAN_CACHE", "0")      # tests build hundreds of schedules of throw-away weights: no blobs in $HOME (the cache has its own test)
 
 
 def pytest_configure(config):

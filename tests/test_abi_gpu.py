@@ -59,6 +59,53 @@ def test_c_host_runs_the_forward_from_a_plan_blob(tmp_path, golden_dir, precisio
     assert int(got[-1:].view(np.int32)[0]) == 0                                                          # status word
 
 
+def test_plan_cache_second_start_loads_the_blob(tmp_path, monkeypatch):
+    """SMAP_PLAN_CACHE=<dir>: the first engine of a (checkpoint, shape, arithmetic) builds the schedule and leaves Graph.blob() on disk; the next
+    process -- here: a fresh model object -- gets plan and weights back through smap_plan_create_from_blob without packing anything, runs the
+    same launches (outputs bit for bit) and starts in a fraction of the time.  Other weights, another batch or a damaged file miss the cache."""
+    import time
+    from smap_amd import engine as E
+    monkeypatch.setenv("SMAP_PLAN_CACHE", str(tmp_path))
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(4)).to(DEV)
+
+    def start(scale=None, B=2):
+        net = _small_net()
+        if scale is not None:
+            sd = net.state_dict()
+            sd["top.conv.conv.weight"] = sd["top.conv.conv.weight"] * scale
+            net.load_state_dict(sd)
+        net = net.to(DEV)
+        net.precision = "x3"
+        t0 = time.perf_counter()
+        eng = net.engine(B, 64, 96, torch.device(DEV), scaled_hms=True)
+        return eng, time.perf_counter() - t0
+    e1, t1 = start()
+    blobs = sorted(p.name for p in tmp_path.iterdir())
+    assert not e1.from_cache and len(blobs) == 2 and blobs[0].endswith(".smapplan") and blobs[1].endswith(".smapplan.json")
+    want = [t.clone() for t in e1.run(x)]
+    e2, t2 = start()
+    assert e2.from_cache and e2._graph is None and e2.cache_key == e1.cache_key
+    got = e2.run(x)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    assert t2 < 0.5 * t1, (t1, t2)
+    assert len(e2.graph.ops) == e2.n_ops == e1.n_ops           # the Python view is still there for whoever asks (built lazily)
+    print(f"engine start: {t1:.2f} s built, {t2:.2f} s from the plan cache")
+    e3, _ = start(scale=1.0001)                                 # other weights -> other key
+    assert not e3.from_cache and e3.cache_key != e1.cache_key
+    e4, _ = start(B=1)
+    assert not e4.from_cache
+    path = tmp_path / (e1.cache_key + ".smapplan")
+    raw = bytearray(path.read_bytes())
+    raw[0:4] = b"XXXX"                                          # damaged: refused by smap_plan_create_from_blob, rebuilt, rewritten
+    path.write_bytes(bytes(raw))
+    e5, _ = start()
+    assert not e5.from_cache and all(torch.equal(a, b) for a, b in zip(e5.run(x), want))
+    e6, _ = start()
+    assert e6.from_cache
+    assert len([p for p in tmp_path.iterdir() if p.name.endswith(".smapplan")]) <= E.PLAN_CACHE_KEEP
+
+
 @pytest.mark.parametrize("flip", [False, True])
 def test_several_input_buffers_equal_one(flip):
     """smap_plan_run_inputs: the frames of a launch in 2 / 4 separate buffers give the bits of one gathered buffer (the stem only

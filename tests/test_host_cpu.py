@@ -470,7 +470,10 @@ def test_batch_1_schedule_rules_and_arena(monkeypatch):
             assert all(o.lane == 0 and o.n_wait == 0 for o in ops)
         h = C.c_void_p()
         assert L.load().smap_plan_create(ops, n, C.byref(h)) == 0
-        assert L.load().smap_plan_set_lanes(h, int(lanes)) == 0
+        rc = L.load().smap_plan_set_lanes(h, int(lanes))          # lanes on: creates the side streams IN this call (include/smap_hip.h) --
+        assert rc == 0 or (lanes == "1" and not torch.cuda.is_available() and rc <= -1000), rc     # a hipError_t on a host without a GPU
+        if rc == 0:
+            assert L.load().smap_plan_set_lanes(h, 0) == 0
         L.load().smap_plan_destroy(h)
 
 

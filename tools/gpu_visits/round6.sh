@@ -115,4 +115,42 @@ PY
 cat $O/bench.log
 }
 
+v7() {
+# visit 7: the whole GPU suite on the round's changes so far (plan cache, eager lanes, per-op ticket memsets, scale_hms, nms_ws, rotation);
+# split K with release / acquire on the ticket (-DSMAP_SPLITK_ACQREL=1) against the fence-free hand-off at batch 1; the bench line with 4 batches in rotation vs 1
+O=gpurun_out/r6v7; mkdir -p $O
+timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -8 $O/pytest.log
+b1() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$1', round(d['value'],1),'fps', round(d['ms_per_step'],3),'ms/frame', d['config']['launch'], 'split-K launches', d['config'].get('split_k_launches'))
+"; }
+B1="--forward-only --batch 1 --steps 300 --warmup 30"
+V=$R/smap_amd/csrc/obj/libsmap_hip_conv_splitk_acqrel1.so
+for rep in 1 2; do
+  timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "rep $rep b1 fence-free hand-off (shipped)" >> $O/ab_splitk.log
+  SMAP_HIP_LIB=$V timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "rep $rep b1 release/acquire ticket" >> $O/ab_splitk.log
+  SMAP_SPLITK=0 timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "rep $rep b1 no split K" >> $O/ab_splitk.log
+done
+SMAP_HIP_LIB=$V timeout 600 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "split_k" > $O/pytest_acqrel.log 2>&1; echo "pytest rc $?" >> $O/pytest_acqrel.log
+tail -3 $O/pytest_acqrel.log >> $O/ab_splitk.log
+cat $O/ab_splitk.log
+for rep in 1 2; do
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 --rotate 4 2>>$O/ab.err | line "rep $rep 100 steps, 4 batches in rotation" >> $O/rotate.log
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 --rotate 1 2>>$O/ab.err | line "rep $rep 100 steps, the same batch every step" >> $O/rotate.log
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 --rotate 4 2>>$O/ab.err | line "rep $rep 20 steps, 4 batches in rotation" >> $O/rotate.log
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 --rotate 1 2>>$O/ab.err | line "rep $rep 20 steps, the same batch every step" >> $O/rotate.log
+done
+cat $O/rotate.log
+}
+
+v8() {
+# visit 8: the whole GPU suite
+O=gpurun_out/r6v8; mkdir -p $O
+timeout 3000 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -15 $O/pytest.log
+}
+
 "v$1"
