@@ -257,6 +257,17 @@ typedef struct smap_op {
        guarantees that buffers touched by an op on a side lane are not reused before the end of the schedule. */
     int32_t lane, n_wait;
     int32_t wait_op[4];
+    /* SECOND INPUT, concatenated along K (round 6; csrc/conv.hip tiles 20, 50, 51; ksize 1): the op computes
+           out = act( W [x | x2_sampled] + bias (+ res) )
+       -- ONE accumulator over K = Cin + in2_C, the weight matrix [cout_pad][Cin + in2_C] being the two convs' matrices side by side.  This is
+       the last 1x1 of a stride-2 / widening Bottleneck TOGETHER with its 1x1 shortcut conv (model/smap.py:60-77, 124-129:
+       out = relu(bn3(conv3(y)) + downsample(x)), no activation between the two sums): the shortcut's output is never written or read back and
+       its launch disappears.  x2 = fp16 NHWC tensor [B, in2_H, in2_W] of in2_C channels (channel stride in2_stride_c, hi | lo planes in split
+       precision like every tensor) at in2_off, sampled at pixel (oy * in2_stride, ox * in2_stride) for output pixel (oy, ox):
+       Ho = (in2_H - 1) / in2_stride + 1, likewise Wo.  in2_C = 0: no second input.  x2 lies in the same 4 GiB window as the first input
+       (one 64-bit base per launch, include/smap_hip.h "windows").  Not with split K, N segments, the fused bilinear add or a 3x3. */
+    int64_t in2_off;
+    int32_t in2_H, in2_W, in2_C, in2_stride_c, in2_stride, reserved2;
 } smap_op;
 
 #define SMAP_STATUS_WORDS(frames) (((frames) + 30) / 31)      /* int32 status words of a schedule with `frames` output frames */

@@ -45,16 +45,23 @@ def run_graph(g, imgs, quantize, keep=False):
                 x = _q(F.relu(F.conv2d(T[op.inp.name], hd["w_ref"].to(dt).to(dev), hd["b_ref"].to(dt).to(dev))), quantize)
             else:
                 x = T[op.inp.name][:, p["in_c_off"]:p["in_c_off"] + cin]
+            cin2 = p["cat"]["cin"] if "cat" in p else 0       # a second input concatenated along K (Graph.conv_cat): the block's shortcut conv
             if quantize:
-                K = k * k * cin
+                K = k * k * cin + cin2
                 from smap_amd.engine import unpack_conv_weights      # the blob holds pre-tiled weight blocks
                 wk = unpack_conv_weights(blob[p["w_off"]:p["w_off"] + p["cout_pad"] * K * 2].view(torch.float16), p["tile"], False,
-                                         k, cin, p["cout_pad"], pairs=p["w_pairs"])[0]
-                w = wk[:cout].float().view(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()
-                b = blob[p["bias_off"]:p["bias_off"] + p["cout_pad"] * 4].view(torch.float32)[:cout].clone()
+                                         k, cin + cin2 if cin2 else cin, p["cout_pad"], pairs=p["w_pairs"])[0]
+                w = wk[:cout, :k * k * cin].float().reshape(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()
+                w2 = wk[:cout, k * k * cin:].float().reshape(cout, cin2, 1, 1) if cin2 else None
+                b = blob[p["bias_off"]:p["bias_off"] + p["cout_pad"] * 4].view(torch.float32)[:cout].clone()      # (cat: b1 + b2)
+                b2 = None
             else:
                 w, b = p["w_ref"].to(dt), p["b_ref"].to(dt)
+                w2, b2 = (p["cat"]["w_ref"].to(dt), p["cat"]["b_ref"].to(dt)) if cin2 else (None, None)
             y = F.conv2d(x, w.to(dev), b.to(dev), stride=p["stride"], padding=p["pad"])
+            if cin2:
+                st2 = p["cat"]["stride"]
+                y = y + F.conv2d(T[op.aux2.name][:, :cin2, ::st2, ::st2], w2.to(dev), b2.to(dev) if b2 is not None else None)
             if "tail" in p:                              # fused Bottleneck tail (csrc/convf.hip): relu(3x3) -> 1x1; the 3x3's
                 tl = p["tail"]                           # output is rounded like a stored activation (hi|lo split = exact here)
                 y = _q(F.relu(y), quantize)

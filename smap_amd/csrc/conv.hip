@@ -63,10 +63,15 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // accumulators' start value, b / 2^-s: exact), residual, ReLU and the hi | lo split happen in registers: 16-byte loads and stores
 // straight from / to the NHWC tensors (convp.hip's and convc.hip's epilogue).  Split precision, fp16 outputs, no fused bilinear add
 // or post-ReLU addends, no split K; N segments as everywhere.
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3, bool SPLITK = false, bool REGEPI = false>
+// DUAL = true (round 6, smap_op.in2_*): a SECOND input concatenated along K -- the K loop walks the first input's Cin / BK tiles, then the
+// second input's Cin2 / BK tiles (other tensor, other pixel stride: the staging offsets are switched once), into the SAME accumulators; the
+// packed weight matrix is the two convs' matrices side by side.  A stride-2 Bottleneck's last 1x1 and its shortcut 1x1 as one launch
+// (model/smap.py:60-77).  1x1 only, plain epilogue, no split K.
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3, bool SPLITK = false, bool REGEPI = false, bool DUAL = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a)
 {
     static_assert(!REGEPI || (X3 && !FULL && !SPLITK), "register epilogue: split precision, plain epilogue, no split K");
+    static_assert(!DUAL || (!FULL && !SPLITK && !REGEPI), "second input: plain epilogue, no split K");
     constexpr int NPL = X3 ? 2 : 1;                    // fp16 planes per operand
     constexpr int NW = WM * WN, NT = NW * 64;          // waves, threads
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
@@ -202,13 +207,33 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             while (oy >= a.Ho) { oy -= a.Ho; ++b; }
         }
     }
+    unsigned a_off2[DUAL ? LA : 1];                            // second input: byte offset of the sampled pixel's granule (0 = zero page: rows past M)
+    if (DUAL) {
+        int m = m0 + srow;
+        int b = m / HoWo, rem = m - b * HoWo;
+        int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            a_off2[i] = 0;
+            if (m < a.M) {
+                const long long e = ((long long)(b * a.H2 + oy * a.stride2) * a.W2 + ox * a.stride2) * a.in2_stride_c + gch * 8;
+                a_off2[i] = (unsigned)(a.in2_off + e * 2);
+            }
+            m += RPR;
+            ox += RPR;
+            while (ox >= a.Wo) { ox -= a.Wo; ++oy; }
+            while (oy >= a.Ho) { oy -= a.Ho; ++b; }
+        }
+    }
     const int cchunks = a.Cin / BK;
-    const int n_all = a.ksize * a.ksize * cchunks;             // K tiles of the op
+    const int cchunks2 = DUAL ? a.Cin2 / BK : 0;
+    const int n_all = a.ksize * a.ksize * cchunks + cchunks2;  // K tiles of the op
     const int it_lo = S > 1 ? ks * n_all / S : 0;              // this workgroup's share (all of them without split K)
     const int n_iter = (S > 1 ? (ks + 1) * n_all / S : n_all) - it_lo;
 
     // staging cursor (all wave-uniform -> SGPRs): tap (s_kh, s_kw), channel chunk s_cc
     int s_kh = 0, s_kw = 0, s_cc = 0;
+    int s_in2 = 0;                                             // DUAL: the cursor is in the second input's K tiles
     int s_it = it_lo;                                          // K tile the cursor stands on
     if (S > 1) {
         const int tap = it_lo / cchunks;
@@ -229,7 +254,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         for (int pl = 0; pl < NPL; ++pl) {
             char* sA = smem + buf * STAGE + pl * BM * ROWB;
             // invalid taps: a_cur = 0 -> zero page + s_cc*ROWB (+ the lo-plane offset: the zero page covers both)
-            const char* gA = arena + (unsigned)(s_cc * ROWB + (X3 ? pl * a.in_lo * 2 : 0));
+            const char* gA = arena + (unsigned)(s_cc * ROWB + (X3 ? pl * ((DUAL && s_in2) ? a.in2_lo : a.in_lo) * 2 : 0));
 #pragma unroll
             for (int i = 0; i < LA; ++i)
                 __builtin_amdgcn_global_load_lds((gbl_void*)(gA + a_cur[i]), (lds_void*)(sA + (i * RPR + wave * RPW) * ROWB), 16, 0, 0);
@@ -237,8 +262,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     };
     auto advance = [&]() {
         ++s_it;
+        if (DUAL && s_in2) { ++s_cc; return; }                 // (past the last tile nothing is issued)
         if (++s_cc == cchunks) {
             s_cc = 0;
+            if (DUAL) {                // 1x1: the first input is through -> the second input's pixels from here on
+                s_in2 = 1;
+#pragma unroll
+                for (int i = 0; i < LA; ++i) a_cur[i] = a_off2[i];
+                return;
+            }
             if (++s_kw == a.ksize) { s_kw = 0; ++s_kh; }
             set_tap();                 // past the last tap the mask bit is 0 -> offsets 0, never issued anyway
         }
@@ -667,6 +699,17 @@ hipError_t launch_regepi(const ConvArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
+// the second-input instances (smap_op.in2_C > 0; tiles 20, 50, 51: plan.hip::validate keeps the rest away)
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool X3>
+hipError_t launch_dual(const ConvArgs& a, hipStream_t st)
+{
+    if (a.up || a.add1 || a.add2 || a.ksplit > 1 || a.ksize != 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, X3, false, false, true>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+    return hipGetLastError();
+}
+
+int smap_conv_tile_has_dual(int tile) { return tile == 20 || tile == 50 || tile == 51; }
+
 // halves per staged K tile (= the packing unit of the weight blob, include/smap_hip.h); mirrors the BK template arguments
 // of smap_launch_conv below and smap_amd/engine.py::tile_bk (tests/test_host_cpu.py compares the two)
 extern "C" int smap_conv_tile_bk(int tile, int precision)
@@ -729,6 +772,14 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
     if (tile >= 60 && tile < 80) return smap_launch_convp(a, tile, st);      // persistent wave-specialised kernel, both precisions
     if (tile >= 80 && tile < 90) return smap_launch_convf(a, tile, st);      // 3x3 + fused 1x1 tail, both precisions
     if (tile >= 90 && tile < 100) return smap_launch_convb(a, tile, st);     // whole identity Bottleneck, split precision
+    if (a.Cin2 > 0) {                                       // second input along K: its own instances of three tiles (smap_conv_tile_has_dual)
+        switch (tile) {
+            case 20: return a.x3 ? launch_dual<128, 128, 2, 2, 2, 32, true>(a, st) : launch_dual<128, 128, 2, 2, 2, 32, false>(a, st);
+            case 50: return a.x3 ? launch_dual<128, 128, 2, 4, 2, 32, true>(a, st) : launch_dual<128, 128, 2, 4, 2, 32, false>(a, st);
+            case 51: return a.x3 ? launch_dual<128, 128, 4, 2, 2, 32, true>(a, st) : launch_dual<128, 128, 4, 2, 2, 32, false>(a, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     if (a.ksplit > 1) {                                     // split K: its own instances of three tiles (plan.hip::validate asked smap_conv_tile_has_splitk)
         switch (tile) {
             case 2: return a.x3 ? launch_splitk<64, 64, 2, 2, 2, 64, true>(a, st) : launch_splitk<64, 64, 2, 2, 2, 64, false>(a, st);

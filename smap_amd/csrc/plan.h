@@ -43,6 +43,9 @@ struct ConvArgs {
     int ksplit;
     float* kpart;
     unsigned* kcount;
+    // second input, concatenated along K (smap_op.in2_*, conv.hip template DUAL): K = Cin + Cin2, 1x1; x2 sampled with spatial stride stride2
+    long long in2_off;       // byte offset from the launch's base (the first input's window)
+    int H2, W2, Cin2, in2_stride_c, stride2, in2_lo;
     // N segments (smap_op.seg_*): rows >= seg_n1 / seg_n2 of the weight matrix belong to outputs 1 / 2 (INT_MAX = no such segment)
     int seg_n1, seg_n2;
     void* seg_out1; void* seg_out2;
@@ -77,6 +80,7 @@ __device__ __forceinline__ Lerp lerp_index(int dst, int in_size, int out_size)
 }
 
 int smap_conv_tile_has_splitk(int tile);                                    // conv.hip: tile ids with a split-K instance
+int smap_conv_tile_has_dual(int tile);                                      // conv.hip: tile ids with a second-input (K-concatenated) instance
 int smap_conv_tile_has_x3(int tile);                                        // conv.hip: tile ids with a split-precision instance
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st);
 int smap_conv3_tile_dims(int tile, int* bm, int* bn);                       // conv3.hip (tile ids 30..33, halo-tiled 3x3)

@@ -660,6 +660,20 @@ static int validate(const smap_op& o)
                 if (o.kpart_off < SMAP_ZERO_PAGE || o.kcount_off < SMAP_ZERO_PAGE || o.kpart_off % 16 || o.kcount_off % 4) return SMAP_E_ARG;
                 if (hits_zero_page(o.kpart_off, pbytes) || hits_zero_page(o.kcount_off, cbytes)) return SMAP_E_ARG;
             }
+            if (o.in2_C < 0) return SMAP_E_ARG;
+            if (o.in2_C > 0) {                           // second input along K: conv.hip's tiles 20 / 50 / 51, 1x1 stride 1 on the first input, plain epilogue
+                if (!smap_conv_tile_has_dual(o.tile) || o.ksize != 1 || o.stride != 1 || o.pad != 0 || o.ksplit > 1 || o.seg_n[0] != 0 || o.aux_off[0] >= 0 ||
+                    o.add1_off >= 0 || o.add2_off >= 0 || o.out_fp32 || o.in_c_off != 0)
+                    return SMAP_E_ARG;
+                if (o.in2_C % 64 || o.in2_stride < 1 || o.in2_stride > 2 || o.in2_H <= 0 || o.in2_W <= 0 || o.in2_off < SMAP_ZERO_PAGE) return SMAP_E_ARG;
+                if (o.Ho != (o.in2_H - 1) / o.in2_stride + 1 || o.Wo != (o.in2_W - 1) / o.in2_stride + 1) return SMAP_E_ARG;
+                if (o.in2_stride_c % 8 || o.in2_stride_c < o.in2_C * (1 + o.precision) || (o.precision == 1 && o.in2_stride_c % 16)) return SMAP_E_ARG;
+                if (o.in2_C * 2 + (o.precision ? o.in2_stride_c : 0) + 16 > SMAP_ZERO_PAGE) return SMAP_E_ARG;      // padding rows read the zero page (both planes)
+                const int64_t b2 = (int64_t)o.B * o.in2_H * o.in2_W * o.in2_stride_c * 2;
+                if (window_of(o.in2_off) != window_of(o.in_off) || o.in2_off - window_of(o.in_off) + b2 > ((int64_t)1 << 32) || hits_zero_page(o.in2_off, b2))
+                    return SMAP_E_ARG;
+                if ((int64_t)o.cout_pad * (o.Cin + o.in2_C) * 2 * (1 + o.precision) > ((int64_t)1 << 32)) return SMAP_E_ARG;
+            }
             if (o.seg_n[0] == 0 && o.seg_n[1] != 0) return SMAP_E_ARG;
             if (o.seg_n[0] != 0) {                       // N segments: conv.hip's tiles, 1x1, fp16 outputs; every segment starts on an N tile
                 const bool igemm = (o.tile >= 0 && o.tile < 30) || (o.tile >= 50 && o.tile < 60);
@@ -781,6 +795,7 @@ int smap_plan_create(const smap_op* ops, int n_ops, smap_plan** plan)
                 bad = bad || hit(o.in_off, (int64_t)o.B * o.H * o.W * (o.kind == SMAP_OP_CONV ? (int64_t)o.in_stride_c * 2 : (int64_t)o.Cin * 2 * pl));
             if (o.kind == SMAP_OP_CONV) {
                 bad = bad || hit(o.res_off, M * c8 * 2 * pl) || hit(o.add1_off, M * c8 * 2 * pl) || hit(o.add2_off, M * c8 * 2 * pl);
+                if (o.in2_C > 0) bad = bad || hit(o.in2_off, (int64_t)o.B * o.in2_H * o.in2_W * o.in2_stride_c * 2);
                 bad = bad || hit(o.aux_off[0], (int64_t)o.B * o.aux_h[0] * o.aux_w[0] * c8 * 2 * pl);
                 for (int j = 0; j < 2; ++j)
                     if (o.seg_n[j] > 0) bad = bad || hit(o.seg_out_off[j], M * o.seg_out_stride_c[j] * 2);
@@ -933,7 +948,10 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
                 a.ksize = o.ksize; a.stride = o.stride; a.pad = o.pad; a.relu = o.relu;
                 a.out_stride_c = o.out_stride_c; a.out_c_off = o.out_c_off; a.out_fp32 = o.out_fp32;
                 a.M = o.B * o.Ho * o.Wo;
-                a.K = o.ksize * o.ksize * o.Cin;
+                a.K = o.ksize * o.ksize * o.Cin + (o.in2_C > 0 ? o.in2_C : 0);      // (a second input extends K)
+                a.Cin2 = o.in2_C > 0 ? o.in2_C : 0;
+                a.in2_off = o.in2_C > 0 ? o.in2_off - window_of(o.in_off) : 0;       // same base as the first input (validate: same window)
+                a.H2 = o.in2_H; a.W2 = o.in2_W; a.in2_stride_c = o.in2_stride_c; a.stride2 = o.in2_stride; a.in2_lo = o.in2_stride_c / 2;
                 a.x3 = o.precision;
                 a.in_lo = o.in_stride_c / 2;
                 a.out_lo = o.out_stride_c / 2;
@@ -1071,6 +1089,7 @@ int smap_workspace_bytes(const smap_plan* plan, int64_t* arena_bytes, int64_t* o
             case SMAP_OP_CONV: {
                 const int64_t c8 = o.tail_cout > 0 ? o.tail_cout : ((o.Cout + 7) & ~7);
                 up(ar, o.in_off, (int64_t)o.B * o.H * o.W * o.in_stride_c * 2);
+                if (o.in2_C > 0) up(ar, o.in2_off, (int64_t)o.B * o.in2_H * o.in2_W * o.in2_stride_c * 2);
                 up(ar, o.out_off, M * o.out_stride_c * (o.out_fp32 ? 4 : 2));
                 up(ar, o.res_off, M * c8 * 2 * pl); up(ar, o.add1_off, M * c8 * 2 * pl); up(ar, o.add2_off, M * c8 * 2 * pl);
                 up(ar, o.aux_off[0], (int64_t)o.B * o.aux_h[0] * o.aux_w[0] * c8 * 2 * pl);
@@ -1126,7 +1145,8 @@ int smap_plan_create_from_blob(const void* blob, size_t blob_bytes, smap_plan** 
         bool ok = true;
         if (o.kind == SMAP_OP_CONV) {
             if (o.cout_pad <= 0 || o.Cin <= 0 || o.ksize <= 0 || o.ksize > 7) return SMAP_E_ARG;
-            ok = inside(o.w_off, (int64_t)o.cout_pad * o.ksize * o.ksize * o.Cin * 2 * pl, wb) && inside(o.bias_off, (int64_t)o.cout_pad * 4, wb);
+            if (o.in2_C < 0 || o.in2_C > (1 << 20)) return SMAP_E_ARG;
+            ok = inside(o.w_off, (int64_t)o.cout_pad * (o.ksize * o.ksize * o.Cin + o.in2_C) * 2 * pl, wb) && inside(o.bias_off, (int64_t)o.cout_pad * 4, wb);
             if (o.tail_cout > 0)
                 ok = ok && o.tail_cout_pad > 0 && o.Cout > 0 && inside(o.tail_w_off, (int64_t)o.tail_cout_pad * o.Cout * 2 * pl, wb) &&
                      inside(o.tail_bias_off, (int64_t)o.tail_cout_pad * 4, wb);

@@ -121,6 +121,7 @@ def _table_entry(v):
 
 
 REGEPI_TILES = (56,)               # csrc/conv.hip tiles with the register epilogue
+DUAL_TILES = (20, 50, 51)          # csrc/conv.hip tiles with a second-input (K-concatenated) instance (smap_conv_tile_has_dual)
 
 
 def tile_legal(tile, *, cout, cout_pad=None, plain3=True, up=False, out_fp32=False, adds=False, x3=True):
@@ -342,6 +343,7 @@ class Op:
     p: dict = field(default_factory=dict)
     lane: int = 0                                 # stream lane (smap_op.lane): 0 = the caller's stream
     outs: list = field(default_factory=list)      # further output tensors (N segments 1, 2 of a merged 1x1 launch)
+    aux2: Tensor = None                           # second input, concatenated along K (Graph.conv_cat)
     scratch: list = field(default_factory=list)   # arena scratch that lives for this op only (split K: the partial tiles)
 
 
@@ -610,6 +612,54 @@ class Graph:
             w_ref=w if self.keep_ref else None, b_ref=b if self.keep_ref else None)))
         return out
 
+    def conv_cat(self, name, pre1, x, pre2, x2, stride2, relu=True, tile=None):
+        """The last 1x1 of a Bottleneck (prefix pre1, on x) TOGETHER with the block's 1x1 shortcut conv (prefix pre2, on x2 sampled with spatial
+        stride `stride2`) as ONE launch: out = act(W1 x + W2 x2 + b1 + b2) -- smap.py:60-77 adds the shortcut's output before the ReLU, no
+        activation in between, so the two GEMMs share their accumulators when K is the concatenation of both inputs' channels
+        (include/smap_hip.h smap_op.in2_*).  The shortcut tensor is never written or read back and its launch disappears."""
+        (w1, b1), (w2, b2) = fold_conv_bn(self.sd, pre1), fold_conv_bn(self.sd, pre2)
+        cout, c1, c2 = w1.shape[0], w1.shape[1], w2.shape[1]
+        assert w2.shape[0] == cout and w1.shape[2] == 1 == w2.shape[2] and c1 == x.C and c2 == x2.C and cout % 8 == 0
+        Ho, Wo = x.H, x.W
+        assert (x2.H - 1) // stride2 + 1 == Ho and (x2.W - 1) // stride2 + 1 == Wo
+        M, K = self.B * Ho * Wo, c1 + c2
+        if tile is None:
+            key = f"{self.B},{Ho},{Wo},{c1}+{c2}cat,{cout},1,1"
+            cands = (pick_tile_x3(M, cout, key) if self.x3 else []) + [50, 51, 20]
+            forced = os.environ.get("SMAP_CAT_TILE", "")                         # A/B hook
+            tile = int(forced) if forced else next(t for t in cands if t in DUAL_TILES)
+        assert tile in DUAL_TILES, tile
+        bn = TILES[tile][1]
+        cout_pad = _rup(cout, bn)
+        w = torch.cat([w1.reshape(cout, c1), w2.reshape(cout, c2)], 1)           # [cout][K = (x channels | x2 channels)]
+        b = b1 + b2
+        acc_scale = 1.0
+        if self.x3:
+            hi, lo, acc_scale = split_f16(w)                                       # ONE power-of-two scale: the two matrices share the accumulators
+            wk = torch.zeros((2, cout_pad, K), dtype=torch.float16)
+            wk[0, :cout], wk[1, :cout] = hi, lo
+        else:
+            wk = torch.zeros((1, cout_pad, K), dtype=torch.float16)
+            wk[0, :cout] = w.to(torch.float16)
+            if not torch.isfinite(wk).all():
+                raise ValueError(f"{name}: folded weights exceed the fp16 range")
+        wk = pack_conv_weights(wk, tile, self.x3, 1, K, pairs=self.w_pairs)
+        bk = torch.zeros((cout_pad,), dtype=torch.float32)
+        bk[:cout] = b.to(torch.float32)
+        out = self.tensor(name, Ho, Wo, cout)
+        fl = 2 * M * cout * K
+        by = x.nbytes + self.B * Ho * Wo * c2 * 2 * x2.planes + out.nbytes + wk.numel() * 2      # (the strided shortcut touches the sampled pixels only)
+        self.flops += fl
+        self.alg_bytes += by
+        keep = self.keep_ref
+        self.ops.append(Op(OP_CONV, out=out, inp=x, aux2=x2, p=dict(
+            flops=fl, alg_bytes=by, kinds="1x1",
+            Cin=c1, in_c_off=0, Cout=cout, ksize=1, stride=1, pad=0, relu=int(relu), cout_pad=cout_pad, tile=tile, out_fp32=0,
+            w_off=self._add_w(wk), bias_off=self._add_w(bk), acc_scale=acc_scale, frames=self.B, w_pairs=self.w_pairs,
+            cat=dict(cin=c2, stride=stride2, w_ref=w2 if keep else None, b_ref=b2 if keep else None),
+            w_ref=w1 if keep else None, b_ref=b1 if keep else None)))
+        return out
+
     def conv_seg(self, segs, x, up=None, tile=None):
         """Several 1x1 stride-1 convs that read the SAME input as ONE launch with one output tensor per conv (include/smap_hip.h
         smap_op.seg_*; Upsample_unit, smap.py:210-241: u_skip | skip1 on x; skip2 | cross_conv | the next unit's up_conv on
@@ -865,8 +915,16 @@ class Graph:
             first = 92                   # small schedules: the 4 x 16 tiles here too
         if first is not None and self.x3 and has_ds and stride == 1 and x.C == 64 and planes == 64 and add1 is None and add2 is None:
             return self.conv_block_first(pre + ".c3", pre, x, first)
-        idn = self.conv(pre + ".downsample", [pre + ".downsample"], x, 1, stride, relu=False) if has_ds else x
+        # A block with a shortcut conv (the first of layer2 / 3 / 4; layer1's runs as a whole-block launch above): its last 1x1 and the shortcut
+        # as ONE GEMM over K = (planes | in_planes) -- the shortcut tensor is never stored (conv_cat).  SMAP_CAT=0: two launches, as round 5 ran.
+        # (Not for arenas beyond one 4 GiB window: both inputs are addressed from one base.)
+        cat = (has_ds and add1 is None and add2 is None and os.environ.get("SMAP_CAT", "1") != "0" and self.tail_tile(planes, stride) is None
+               and self.B * self.H * self.W <= 20 * 512 * 832)
+        idn = x if (not has_ds or cat) else self.conv(pre + ".downsample", [pre + ".downsample"], x, 1, stride, relu=False)
         y = self.conv(pre + ".c1", [pre + ".conv_bn_relu1"], x, 1, 1, relu=True)
+        if cat:
+            y = self.conv(pre + ".c2", [pre + ".conv_bn_relu2"], y, 3, stride, relu=True)
+            return self.conv_cat(pre + ".c3", pre + ".conv_bn_relu3", y, pre + ".downsample", x, stride, relu=True)
         tail = self.tail_tile(planes, stride)
         if tail is not None:        # c2 + c3 in one launch (csrc/convf.hip)
             return self.conv_tail(pre + ".c3", pre + ".conv_bn_relu2", pre + ".conv_bn_relu3", y, tail, res=idn, add1=add1, add2=add2)
@@ -1013,7 +1071,7 @@ class Graph:
     # -- arena: liveness-based first-fit allocation
     def allocate(self, reuse=True):
         for i, op in enumerate(self.ops):
-            for t in [op.inp, op.res, op.add1, op.add2] + list(op.aux):
+            for t in [op.inp, op.res, op.add1, op.add2, op.aux2] + list(op.aux):
                 if t is not None:
                     t.last = i
             for t in ([op.out] if op.out is not None else []) + list(op.outs):
@@ -1031,7 +1089,7 @@ class Graph:
         for i, op in enumerate(self.ops):
             if not op.lane:
                 continue
-            reads = [t for t in [op.inp, op.res, op.add1, op.add2] + list(op.aux) if t is not None]
+            reads = [t for t in [op.inp, op.res, op.add1, op.add2, op.aux2] + list(op.aux) if t is not None]
             start = 1 + max([producer.get(id(t), -1) for t in reads] + [-1])
             for t in ([op.out] if op.out is not None else []) + list(op.outs) + list(op.scratch):
                 t.first = min(t.first, start)
@@ -1103,7 +1161,7 @@ class Graph:
             # lanes: wait for the latest producer on every OTHER lane (ops of one lane are ordered by their stream)
             o.lane = op.lane
             waits = {}
-            for t in [op.inp, op.res, op.add1, op.add2] + list(op.aux):
+            for t in [op.inp, op.res, op.add1, op.add2, op.aux2] + list(op.aux):
                 pi = producer.get(id(t)) if t is not None else None
                 if pi is not None and self.ops[pi].lane != op.lane:
                     ln = self.ops[pi].lane
@@ -1150,6 +1208,10 @@ class Graph:
                     t = op.aux[0]
                     assert t.C == y.C and t.esize == 2
                     o.aux_off[0], o.aux_h[0], o.aux_w[0] = t.off, t.H, t.W
+                if "cat" in p:
+                    t = op.aux2
+                    assert t.off // WINDOW == x.off // WINDOW, (y.name, "both inputs of a conv_cat launch must lie in one 4 GiB window")
+                    o.in2_off, o.in2_H, o.in2_W, o.in2_C, o.in2_stride_c, o.in2_stride = t.off, t.H, t.W, p["cat"]["cin"], t.C * t.planes, p["cat"]["stride"]
                 if p.get("ksplit", 1) > 1:
                     o.ksplit, o.kpart_off, o.kcount_off = p["ksplit"], op.scratch[0].off, self.kcount.off + 4 * p["kcount_first"]
                 for j, (sg, t) in enumerate(zip(p.get("segs", []), op.outs)):

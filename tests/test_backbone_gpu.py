@@ -1000,6 +1000,83 @@ def test_merged_1x1_launch_matches_torch(case, x3):
         assert torch.isfinite(got).all() and err < ((3e-6 * mx + 1e-6) if x3 else 2e-3 * mx), (j, err, mx)
 
 
+CAT_CASES = [   # B, H (out), W (out), planes (c3's K), in_planes (the shortcut's K), cout, spatial stride of the shortcut, tile
+    (2, 8, 13, 128, 256, 512, 2, 50),          # layer2's first block in small: ragged M tile, stride 2 (odd input width 25 -> 13)
+    (1, 16, 26, 256, 512, 1024, 2, 51),        # layer3's
+    (3, 5, 7, 512, 1024, 2048, 2, 20),         # layer4's: M < one tile
+    (2, 16, 24, 64, 64, 256, 1, 50),           # layer1's first block (stride 1: the shortcut reads the block's own input)
+    (1, 9, 11, 128, 192, 320, 1, 20),          # Cout not a tile multiple
+]
+
+
+@pytest.mark.parametrize("x3", [True, False], ids=["x3", "f16"])
+@pytest.mark.parametrize("case", CAT_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_last_1x1_with_the_shortcut_conv_as_one_gemm(case, x3):
+    """Graph.conv_cat / smap_op.in2_*: relu(W3 y + Wd x[::s, ::s] + b3 + bd) -- a Bottleneck's last 1x1 and its 1x1 shortcut conv
+    (smap.py:60-77, 124-129) as ONE launch over K = (planes | in_planes) -- against the f64 evaluation of the two convs on the same (rounded)
+    operands."""
+    import torch.nn.functional as F
+    from smap_amd import engine as E
+    from smap_amd import lib as L
+    B, H, W, c1, c2, cout, st2, tile = case
+    gen = torch.Generator().manual_seed(sum(case))
+    sd = {}
+    for pre, c, sc in (("c3", c1, 0.06), ("ds", c2, 0.21)):           # different weight scales: ONE power-of-two scale serves both halves of K
+        sd[pre + ".conv.weight"] = torch.randn(cout, c, 1, 1, generator=gen) * sc
+        sd[pre + ".conv.bias"] = torch.randn(cout, generator=gen) * 0.1
+        sd[pre + ".bn.weight"] = torch.rand(cout, generator=gen) + 0.5
+        sd[pre + ".bn.bias"] = torch.randn(cout, generator=gen) * 0.1
+        sd[pre + ".bn.running_mean"] = torch.randn(cout, generator=gen) * 0.1
+        sd[pre + ".bn.running_var"] = torch.rand(cout, generator=gen) + 0.5
+    H2, W2 = (H - 1) * st2 + 1 + (st2 - 1) * (W % 2), (W - 1) * st2 + 1          # (H2 - 1) // s + 1 == H either way
+    g = E.Graph(sd, B, 4 * H, 4 * W, keep_ref=True, precision="x3" if x3 else "f16", build=False)
+    g.w_pairs = int(B == 1)
+    yt, xt = g.tensor("y", H, W, c1), g.tensor("x", H2, W2, c2)
+    out = g.conv_cat("out", "c3", yt, "ds", xt, st2, relu=True, tile=tile)
+    yt.first = xt.first = 0
+    g.allocate(reuse=False)
+    ops = g.emit()
+    lib = L.load()
+    h = C.c_void_p()
+    L.check(lib.smap_plan_create(ops, 1, C.byref(h)), "smap_plan_create")
+    arena = torch.zeros(g.arena_bytes, dtype=torch.uint8, device=DEV)
+
+    def put(t, v):
+        v = v.permute(0, 2, 3, 1).contiguous()
+        hi = v.to(torch.float16)
+        if t.planes == 2:
+            lo = (v - hi.float()).to(torch.float16)
+            raw, val = torch.stack([hi, lo], 3).reshape(-1), hi.double() + lo.double()
+        else:
+            raw, val = hi.reshape(-1), hi.double()
+        arena[t.off:t.off + t.nbytes].view(torch.float16).copy_(raw.to(DEV))
+        return val.permute(0, 3, 1, 2)
+    yv = put(yt, torch.randn(B, c1, H, W, generator=gen))
+    xv = put(xt, torch.randn(B, c2, H2, W2, generator=gen))
+    blob = g.weight_blob().to(DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()), None, st), "run")
+    torch.cuda.synchronize()
+    lib.smap_plan_destroy(h)
+    p = g.ops[0].p
+    q = (lambda w: w.double()) if x3 else (lambda w: w.to(torch.float16).double())
+    want = F.relu(F.conv2d(yv, q(p["w_ref"]), p["b_ref"].double()) + F.conv2d(xv[:, :, ::st2, ::st2], q(p["cat"]["w_ref"]), p["cat"]["b_ref"].double()))
+    raw = arena[out.off:out.off + out.nbytes].view(torch.float16).cpu()
+    got = (raw.view(B, H, W, 2, out.C).double().sum(3) if out.planes == 2 else raw.view(B, H, W, out.C).double()).permute(0, 3, 1, 2)
+    err, mx = (got - want).abs().max().item(), want.abs().max().item()
+    assert torch.isfinite(got).all() and err < ((3e-6 * mx + 1e-6) if x3 else 2e-3 * mx), (err, mx)
+    # and the plan refuses what the kernel cannot do: a second input on a tile without the instance, with split K, beyond the first input's window
+    bad = (L.SmapOp * 1)(ops[0])
+    bad[0].tile = 21
+    assert lib.smap_plan_create(bad, 1, C.byref(h)) == -1
+    bad = (L.SmapOp * 1)(ops[0])
+    bad[0].in2_off = ops[0].in2_off + (1 << 32)
+    assert lib.smap_plan_create(bad, 1, C.byref(h)) == -1
+    bad = (L.SmapOp * 1)(ops[0])
+    bad[0].in2_stride = 3
+    assert lib.smap_plan_create(bad, 1, C.byref(h)) == -1
+
+
 @pytest.mark.parametrize("env", [{"SMAP_HALO3": "16"}, {"SMAP_HALO3": "32", "SMAP_HALO3_DEEP": "1"}], ids=["halo16", "halo32deep"])
 def test_small_schedule_split_precision_with_halo_kernel(golden_dir, small, monkeypatch, env):
     """precision "x3" with every plain 3x3 conv on the halo-tiled kernel's split-precision instances."""

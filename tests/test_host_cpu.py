@@ -53,7 +53,10 @@ def test_x3_graph_emits_split_strides_and_weights(small_sd, monkeypatch, blocks)
     ops = g.emit()
     n_blk = sum(1 for op in g.ops if "head" in op.p)
     assert n_blk == (18 if blocks else 0)                 # 3 stages x (first block + two identity blocks of layer1 + three identity blocks of layer2)
-    assert len(g.ops) == len(g16.ops) - (3 * 3 + 2 * 6 + 2 * 9 if blocks else 0) and g.flops == g16.flops
+    # (a first block is 3 launches layer by layer since round 6 -- c1, c2, c3 with the shortcut conv inside, Graph.conv_cat -- and 1 as a whole block)
+    assert len(g.ops) == len(g16.ops) - (3 * 2 + 2 * 6 + 2 * 9 if blocks else 0) and g.flops == g16.flops
+    assert sum(1 for op in g.ops if "cat" in op.p) == (9 if blocks else 12) and sum(1 for op in g16.ops if "cat" in op.p) == 12
+    assert not any(op.out is not None and op.out.name.endswith(".downsample") for op in g.ops)
     assert g.weight_blob().numel() > 1.9 * g16.weight_blob().numel()
     for op, o in zip(g.ops, ops):
         assert o.precision == 1
@@ -241,6 +244,7 @@ def test_fused_bottleneck_tail_schedule_on_cpu(small_sd, monkeypatch):
     from smap_amd import lib as L
     from smap_amd.engine import Graph, OP_CONV, TAIL_BN, pack_halo_rows, unpack_halo_rows
     x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(3))
+    monkeypatch.setenv("SMAP_CAT", "0")                  # (this test compares ROUNDINGS op for op: the shortcut tensors stay stored on both sides)
     g0 = Graph(small_sd, 2, 64, 96, keep_ref=True)
     want, want_q = run_graph(g0, x.double(), quantize=False), run_graph(g0, x, quantize=True)
     monkeypatch.setenv("SMAP_TAIL", "64:80,128:82")

@@ -206,7 +206,8 @@ def test_schedule_wiring_matches_reference_golden(golden_dir, small_model, monke
     # 203 convs + stem + maxpool + 3 head sums; "2" (every shared-input pair): 2 launches fewer per Upsample_unit of stages 0 / 1, 1 fewer
     # for up2 / up3 of stage 2; "1" (default: the merges that measured faster) keeps u_skip | skip1 apart where u_skip has the bilinear add
     saved = {"2": 18, "1": 12, "0": 0}[merge]
-    assert len(g.ops) == 208 - saved and sum(len(op.outs) for op in g.ops) == saved
+    # ... and (round 6) the 12 shortcut convs -- first block of every layer, 3 stages -- inside their blocks' last 1x1 (Graph.conv_cat): 203 -> 191 convs
+    assert len(g.ops) == 208 - 12 - saved and sum(len(op.outs) for op in g.ops) == saved and sum(1 for op in g.ops if "cat" in op.p) == 12
     with torch.no_grad():
         outs = run_graph(g, torch.from_numpy(z["x"]), quantize=False)
         outs_q = run_graph(g, torch.from_numpy(z["x"]), quantize=True)

@@ -153,4 +153,21 @@ timeout 3000 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $
 tail -15 $O/pytest.log
 }
 
+v9() {
+# visit 9: a stride-2 Bottleneck's last 1x1 + its shortcut conv as one K-concatenated GEMM (Graph.conv_cat, smap_op.in2_*): parity, then in situ
+O=gpurun_out/r6v9; mkdir -p $O
+timeout 1500 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "shortcut_conv_as_one_gemm or small_schedule or full_size or smap_module" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -6 $O/pytest.log
+for rep in 1 2; do
+  for v in "SMAP_CAT=0" "SMAP_CAT_TILE=50" "SMAP_CAT_TILE=51" "SMAP_CAT_TILE=20"; do
+    env $v SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep depth 2 [$v]" >> $O/ab_cat.log
+  done
+done
+for v in "SMAP_CAT=0" "SMAP_CAT_TILE=50" "SMAP_CAT_TILE=51" "SMAP_CAT_TILE=20"; do
+  env $v SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 2>>$O/ab.err | line "depth 1 [$v]" >> $O/ab_cat.log
+done
+cat $O/ab_cat.log
+layers $O d1_f16_cat 16 --depth 1 --steps 6 --warmup 2
+}
+
 "v$1"
