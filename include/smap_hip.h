@@ -139,6 +139,10 @@ enum smap_op_kind {
     SMAP_OP_HEADSUM = 4,    /* fp32 NCHW out = sum of bilinear-upsampled heads (smap.py:221-229,417-419) */
     SMAP_OP_STEMPOOL = 5,   /* ResNet_top whole (smap.py:83-86): STEM followed by MAXPOOL in one kernel; H,W = image,
                                Ho,Wo = pooled size, same weight format as STEM                                  */
+    SMAP_OP_TAPSUM = 6,     /* the second half of a 3x3 conv with ONE output channel whose first half ran inside the producing launch
+                               (CONV with tap_n = 9): out[b,0,y,x] = bias + sum over (dy,dx) in {-1,0,1}^2 of t[b, y+dy, x+dx][3 (dy+1) + dx+1]
+                               (zero outside the map) -- fp32 NCHW map at ext_off of the output buffer, like HEADSUM (same status words).
+                               aux_off[0] = t, fp32 [B,H,W,Cin] (Cin = 16: nine used); Ho,Wo = H,W; Cout = 1; bias: one fp32 at bias_off */
 };
 
 typedef struct smap_op {
@@ -267,7 +271,17 @@ typedef struct smap_op {
        Ho = (in2_H - 1) / in2_stride + 1, likewise Wo.  in2_C = 0: no second input.  x2 lies in the same 4 GiB window as the first input
        (one 64-bit base per launch, include/smap_hip.h "windows").  Not with split K, N segments, the fused bilinear add or a 3x3. */
     int64_t in2_off;
-    int32_t in2_H, in2_W, in2_C, in2_stride_c, in2_stride, reserved2;
+    int32_t in2_H, in2_W, in2_C, in2_stride_c, in2_stride;
+    /* TAP-DOT EPILOGUE (round 6; csrc/conv.hip tile 54 = 128 x 256, cout_pad = 256 = ONE N tile, ksize 1): tap_n = 9 -- the launch's
+       activation y = act(W x + b) is NOT stored; its only consumer is a 3x3 conv with one output channel (smap.py:227-229, res_rd_conv2 on
+       res_rd_conv1), whose per-pixel half the epilogue computes instead, on the matrix cores: t[m][k] = < tapw[k], y[m] >, k = 0..8.
+       tapw at tap_w_off in the weight blob: the folded 3x3 weights [kh*3+kw][channel] * 2^s as fp16 hi | lo in the B-fragment order of
+       v_mfma_f32_16x16x32_f16 -- [K step 0..7][plane hi, lo][lane 0..63][8 halves], lane l holding tap l % 16 (taps 9..15: zeros), channels
+       32 step + 8 (l / 16) .. +7 -- and tap_scale = 2^-s.  `out` is then the fp32 tensor t, pixel stride out_stride_c = 16 (out_fp32 = 1,
+       entries 9..15 written as zeros), and a TAPSUM op finishes the conv.  0 = off.  Not with res / adds / segments / split K / in2. */
+    int32_t tap_n;
+    float tap_scale;
+    int64_t tap_w_off;
 } smap_op;
 
 #define SMAP_STATUS_WORDS(frames) (((frames) + 30) / 31)      /* int32 status words of a schedule with `frames` output frames */

@@ -10,7 +10,7 @@ TEST INFRASTRUCTURE ONLY.  Two uses:
 import torch
 import torch.nn.functional as F
 
-from smap_amd.engine import OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM, OP_STEMPOOL
+from smap_amd.engine import OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM, OP_STEMPOOL, OP_TAPSUM
 
 
 def _q(x, on):
@@ -87,6 +87,9 @@ def run_graph(g, imgs, quantize, keep=False):
                 y = y + T[op.add1.name]
             if op.add2 is not None:
                 y = y + T[op.add2.name]
+            if "tap" in p:                               # tap-dot epilogue: nine per-pixel dot products of the (never stored) activation
+                w3 = p["tap"]["w_ref"].to(dt).to(dev)    # [1, C, 3, 3] -> nine 1x1 convs, channel k = tap 3 kh + kw
+                y = F.conv2d(y, w3[0].permute(1, 2, 0).reshape(9, -1, 1, 1))
             T[op.out.name] = y if p["out_fp32"] else _q(y, quantize)
             for sg, t in zip(p.get("segs", []), op.outs):        # N segments: further 1x1 convs on the same input, one output tensor each
                 if quantize:
@@ -100,6 +103,12 @@ def run_graph(g, imgs, quantize, keep=False):
             a, t = T[op.inp.name], T[op.aux[0].name]
             y = a + up(t, a.shape[-2:])
             T[op.out.name] = _q(F.relu(y) if p["relu"] else y, quantize)
+        elif op.kind == OP_TAPSUM:                       # out[y, x] = b + sum over taps of t[y + kh - 1, x + kw - 1][3 kh + kw]
+            t = T[op.aux[0].name][:g.frames]
+            tp = F.pad(t, (1, 1, 1, 1))
+            H_, W_ = t.shape[-2:]
+            y = p["b_ref"].to(dt).to(dev).reshape(1, 1, 1, 1) + sum(tp[:, kh * 3 + kw:kh * 3 + kw + 1, kh:kh + H_, kw:kw + W_] for kh in range(3) for kw in range(3))
+            outs[p["ext_off"]] = y
         elif op.kind == OP_HEADSUM:
             size = (g.out_h, g.out_w)
             y = None

@@ -67,9 +67,15 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // second input's Cin2 / BK tiles (other tensor, other pixel stride: the staging offsets are switched once), into the SAME accumulators; the
 // packed weight matrix is the two convs' matrices side by side.  A stride-2 Bottleneck's last 1x1 and its shortcut 1x1 as one launch
 // (model/smap.py:60-77).  1x1 only, plain epilogue, no split K.
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3, bool SPLITK = false, bool REGEPI = false, bool DUAL = false>
+// TAPDOT = true (round 6, smap_op.tap_n; tile 54 = 128 x 256, ONE N tile): the launch's activation y = act(W x + b) [pixel][256] never reaches
+// memory.  Its only consumer is a 3x3 conv with ONE output channel (model/smap.py:227-229: res_rd_conv2 on res_rd_conv1's output), and
+//     conv3x3(y)[p] = sum over taps of  < w[tap], y[p + offset(tap)] >
+// so the epilogue stores t[p][tap] = < w[tap], y[p] > -- nine fp32 numbers per pixel instead of 256 hi | lo pairs -- and a nine-term stencil
+// over t (plan.hip::tapsum_kernel) finishes the conv.  Dot products in fp32 on the fp32 accumulators (nothing is rounded to fp16 in between).
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3, bool SPLITK = false, bool REGEPI = false, bool DUAL = false, bool TAPDOT = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a)
 {
+    static_assert(!TAPDOT || (!FULL && !SPLITK && !REGEPI && !DUAL), "tap-dot epilogue: plain instance only");
     static_assert(!REGEPI || (X3 && !FULL && !SPLITK), "register epilogue: split precision, plain epilogue, no split K");
     static_assert(!DUAL || (!FULL && !SPLITK && !REGEPI), "second input: plain epilogue, no split K");
     constexpr int NPL = X3 ? 2 : 1;                    // fp16 planes per operand
@@ -88,7 +94,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     constexpr int STAGE = NPL * (BM + BN) * ROWB;      // [A planes][B planes]
     constexpr int LPT = NPL * (LA + LB);               // LDS-DMA loads per thread per K tile
     static_assert((STAGES - 2) * LPT <= 63, "vmcnt is 6 bits");
-    constexpr int LDS_BYTES = REGEPI ? STAGES * STAGE : (STAGES * STAGE > BM * BN * 4 ? STAGES * STAGE : BM * BN * 4) + (SPLITK ? 16 : 0);   // pipeline | fp32 epilogue tile (+ the split-K flag)
+    constexpr int CSS = TAPDOT ? BN + 8 : BN;                 // row stride (floats) of the fp32 epilogue tile (tap-dot: padded, its rows are read as MFMA fragments)
+    constexpr int LDS_BYTES = REGEPI ? STAGES * STAGE : (STAGES * STAGE > BM * CSS * 4 ? STAGES * STAGE : BM * CSS * 4) + (SPLITK ? 16 : 0);   // pipeline | fp32 epilogue tile (+ the split-K flag)
     static_assert(LDS_BYTES <= 160 * 1024, "LDS is 160 KiB per CU");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * (BM / WM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                Cs[row * BN + col] = S > 1 ? acc[mi][ni][r] : (X3 ? acc[mi][ni][r] * o_scale + bias : acc[mi][ni][r] + bias);
+                Cs[row * CSS + col] = S > 1 ? acc[mi][ni][r] : (X3 ? acc[mi][ni][r] * o_scale + bias : acc[mi][ni][r] + bias);
             }
     }
     __syncthreads();
@@ -534,6 +541,45 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
             Cs[i] = X3 ? v * o_scale + bias : v + bias;
         }
         __syncthreads();
+    }
+
+    if constexpr (TAPDOT) {
+        // ---- tap-dot epilogue ON THE MATRIX CORES: T[128 pixels][16 taps] = act(Y)[128][256] . tapw^T, one v_mfma_f32_16x16x32_f16 tile of 16
+        //      pixels per wave (8 waves = the 128 rows of the tile), K = 256 channels in 8 steps; act(Y) is split into fp16 hi | lo in
+        //      registers (three MFMAs per step, like every GEMM of the split-precision path), the tap weights arrive pre-split and in fragment
+        //      order.  Lane l: A = 8 channels 32 ks + 8 (l / 16) .. of pixel row l % 16 (one 32-byte LDS read; the row stride is padded by 8
+        //      floats, so the 16 rows of a lane group fall on different banks); D[i] = pixel 4 (l / 16) + i, tap l % 16.
+        static_assert(BM == 128 && BN == 256 && NW == 8, "one 16-row MFMA tile per wave");
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int prow = wave * 16 + (lane & 15), kq = lane >> 4;
+        const half8* __restrict__ wfrag = reinterpret_cast<const half8*>(a.tap_w) + lane;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < BN / 32; ++ks) {
+            const half8 wh = wfrag[(ks * 2 + 0) * 64], wl = wfrag[(ks * 2 + 1) * 64];
+            const float4 y0 = *reinterpret_cast<const float4*>(Cs + prow * CSS + ks * 32 + kq * 8);
+            const float4 y1 = *reinterpret_cast<const float4*>(Cs + prow * CSS + ks * 32 + kq * 8 + 4);
+            float y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+            half8 yh, yl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = y[e];
+                if (o_relu) v = v < 0.f ? 0.f : v;              // NaN stays NaN (torch's ReLU)
+                yh[e] = (_Float16)v;
+                yl[e] = (_Float16)(v - (float)yh[e]);
+            }
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh, d, 0, 0, 0);     // small cross terms first, then hi * hi
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh, d, 0, 0, 0);
+        }
+        float* const tout = reinterpret_cast<float*>(o_out);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wave * 16 + kq * 4 + i;
+            if (m < a.M) tout[(size_t)m * 16 + (lane & 15)] = d[i] * a.tap_scale;        // (taps 9..15: zero weights -> zeros)
+        }
+        SMAP_TL_END(a)
+        return;
     }
 
     // ---- epilogue 2: 8 consecutive channels of one pixel per thread.  Software-pipelined over the
@@ -710,6 +756,15 @@ hipError_t launch_dual(const ConvArgs& a, hipStream_t st)
 
 int smap_conv_tile_has_dual(int tile) { return tile == 20 || tile == 50 || tile == 51; }
 
+// the tap-dot instance (smap_op.tap_n = 9; tile 54 only: one N tile of 256 channels)
+template <bool X3>
+hipError_t launch_tapdot(const ConvArgs& a, hipStream_t st)
+{
+    if (a.up || a.add1 || a.add2 || a.res || a.ksplit > 1 || a.Cin2 > 0 || a.n_tiles != 1 || a.tap_n != 9 || !a.tap_w) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_igemm_kernel<128, 256, 2, 4, 2, 32, false, X3, false, false, false, true>), dim3(a.m_tiles), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
 // halves per staged K tile (= the packing unit of the weight blob, include/smap_hip.h); mirrors the BK template arguments
 // of smap_launch_conv below and smap_amd/engine.py::tile_bk (tests/test_host_cpu.py compares the two)
 extern "C" int smap_conv_tile_bk(int tile, int precision)
@@ -772,6 +827,7 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
     if (tile >= 60 && tile < 80) return smap_launch_convp(a, tile, st);      // persistent wave-specialised kernel, both precisions
     if (tile >= 80 && tile < 90) return smap_launch_convf(a, tile, st);      // 3x3 + fused 1x1 tail, both precisions
     if (tile >= 90 && tile < 100) return smap_launch_convb(a, tile, st);     // whole identity Bottleneck, split precision
+    if (a.tap_n > 0) return tile == 54 ? (a.x3 ? launch_tapdot<true>(a, st) : launch_tapdot<false>(a, st)) : hipErrorInvalidValue;
     if (a.Cin2 > 0) {                                       // second input along K: its own instances of three tiles (smap_conv_tile_has_dual)
         switch (tile) {
             case 20: return a.x3 ? launch_dual<128, 128, 2, 2, 2, 32, true>(a, st) : launch_dual<128, 128, 2, 2, 2, 32, false>(a, st);

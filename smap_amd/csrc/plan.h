@@ -46,6 +46,11 @@ struct ConvArgs {
     // second input, concatenated along K (smap_op.in2_*, conv.hip template DUAL): K = Cin + Cin2, 1x1; x2 sampled with spatial stride stride2
     long long in2_off;       // byte offset from the launch's base (the first input's window)
     int H2, W2, Cin2, in2_stride_c, stride2, in2_lo;
+    // tap-dot epilogue (smap_op.tap_n, conv.hip template TAPDOT): instead of storing its [M][N] activation the launch stores, per pixel, the
+    // tap_n dot products of that activation with tap_n weight vectors -- the per-pixel half of a following 3x3 conv with ONE output channel
+    const _Float16* tap_w;   // [8 K steps][hi, lo][64 lanes][8 halves]: B fragments of v_mfma_f32_16x16x32_f16, or null
+    int tap_n;
+    float tap_scale;
     // N segments (smap_op.seg_*): rows >= seg_n1 / seg_n2 of the weight matrix belong to outputs 1 / 2 (INT_MAX = no such segment)
     int seg_n1, seg_n2;
     void* seg_out1; void* seg_out2;

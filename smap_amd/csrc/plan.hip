@@ -539,6 +539,31 @@ __global__ __launch_bounds__(256) void headsum_kernel(HeadSrc s, float* __restri
     }
 }
 
+// SMAP_OP_TAPSUM: out[b,0,y,x] = bias + sum_{kh,kw} t[b, y+kh-1, x+kw-1][3 kh + kw] (zero outside the map): the stencil half of a 3x3 conv with
+// one output channel whose per-pixel dot products came out of the producing conv launch (conv.hip TAPDOT).  Taps summed in the fixed order
+// 0..8.  One thread per output pixel; the nine reads of a wave are nine coalesced 64-byte-strided gathers of neighbouring pixels.
+__global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ t, const float* __restrict__ bias, float* __restrict__ out,
+                                                     int B, int H, int W, int ts, int* __restrict__ status)
+{
+    const long long total = (long long)B * H * W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((long long)W * H));
+    float v = bias[0];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int yy = y + kh - 1, xx = x + kw - 1;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v += t[(((size_t)b * H + yy) * W + xx) * ts + kh * 3 + kw];
+        }
+    out[i] = v;
+    if (status && !(fabsf(v) <= 3.4028234e38f)) {
+        atomicOr(reinterpret_cast<unsigned*>(status) + b / 31, 1u | (2u << (b % 31)));
+        if (b >= 31) atomicOr(reinterpret_cast<unsigned*>(status), 1u);
+    }
+}
+
 inline int grid_for(long long total, int block)
 {
     long long g = (total + block - 1) / block;
@@ -585,7 +610,7 @@ static int validate(const smap_op& o)
     if (o.B <= 0 || o.H <= 0 || o.W <= 0 || o.Ho <= 0 || o.Wo <= 0 || o.Cout <= 0) return SMAP_E_ARG;
     if (o.precision != 0 && o.precision != 1) return SMAP_E_ARG;
     if (o.precision == 1 && o.kind != SMAP_OP_CONV && o.kind != SMAP_OP_STEM && o.kind != SMAP_OP_MAXPOOL && o.kind != SMAP_OP_HEADSUM &&
-        o.kind != SMAP_OP_STEMPOOL)
+        o.kind != SMAP_OP_STEMPOOL && o.kind != SMAP_OP_TAPSUM)
         return SMAP_E_ARG;                               // UPADD has no split-precision instance
     switch (o.kind) {
         case SMAP_OP_CONV: {
@@ -634,7 +659,7 @@ static int validate(const smap_op& o)
             if (o.tile >= 60 && o.tile < 80 && (o.out_fp32 || o.aux_off[0] >= 0 || o.Cout % 8 || o.cout_pad > 2048))
                 return SMAP_E_ARG;                       // persistent kernel: register epilogue, fp16 outputs, no fused bilinear add, bias table of 2048 channels in LDS
             if (o.in_stride_c % 8 || o.in_c_off % 8 || o.out_stride_c % 8 || o.out_c_off % 8) return SMAP_E_ARG;
-            if (o.out_stride_c < ((o.Cout + 7) & ~7)) return SMAP_E_ARG;
+            if (o.out_stride_c < ((o.Cout + 7) & ~7) && o.tap_n == 0) return SMAP_E_ARG;      // (tap-dot: `out` is the [M][16] tap tensor)
             if ((o.res_off >= 0 || o.add1_off >= 0 || o.add2_off >= 0 || o.aux_off[0] >= 0) && o.Cout % 8) return SMAP_E_ARG;
             if (o.aux_off[0] >= 0 && (o.aux_h[0] <= 0 || o.aux_w[0] <= 0)) return SMAP_E_ARG;
             if (o.in_off < SMAP_ZERO_PAGE || o.out_off < SMAP_ZERO_PAGE || o.w_off < 0 || o.bias_off < 0) return SMAP_E_ARG;
@@ -659,6 +684,12 @@ static int validate(const smap_op& o)
                 const int64_t pbytes = tiles * o.ksplit * bm * bn * 4, cbytes = tiles * 4;
                 if (o.kpart_off < SMAP_ZERO_PAGE || o.kcount_off < SMAP_ZERO_PAGE || o.kpart_off % 16 || o.kcount_off % 4) return SMAP_E_ARG;
                 if (hits_zero_page(o.kpart_off, pbytes) || hits_zero_page(o.kcount_off, cbytes)) return SMAP_E_ARG;
+            }
+            if (o.tap_n != 0) {                          // tap-dot epilogue: tile 54, one N tile of 256 channels, t = fp32 [M][16]
+                if (o.tap_n != 9 || o.tile != 54 || o.cout_pad != 256 || o.Cout != 256 || o.ksize != 1 || o.stride != 1 || !o.out_fp32 || o.out_stride_c != 16 ||
+                    o.out_c_off != 0 || o.res_off >= 0 || o.add1_off >= 0 || o.add2_off >= 0 || o.aux_off[0] >= 0 || o.seg_n[0] != 0 || o.ksplit > 1 || o.in2_C != 0 ||
+                    o.tap_w_off < 0 || !(o.tap_scale > 0.f))
+                    return SMAP_E_ARG;
             }
             if (o.in2_C < 0) return SMAP_E_ARG;
             if (o.in2_C > 0) {                           // second input along K: conv.hip's tiles 20 / 50 / 51, 1x1 stride 1 on the first input, plain epilogue
@@ -716,6 +747,10 @@ static int validate(const smap_op& o)
             return 0;
         case SMAP_OP_UPADD:
             if (o.Cout % 8 || o.aux_off[0] < 0 || o.aux_h[0] <= 0 || o.aux_w[0] <= 0) return SMAP_E_ARG;
+            return 0;
+        case SMAP_OP_TAPSUM:
+            if (o.Cout != 1 || o.Cin < 9 || o.Cin % 4 || o.Ho != o.H || o.Wo != o.W || o.aux_off[0] < SMAP_ZERO_PAGE || o.ext_off < 0 || o.bias_off < 0) return SMAP_E_ARG;
+            if (o.status_off < 0 || o.status_off % 4 || hits_zero_page(o.aux_off[0], (int64_t)o.B * o.H * o.W * o.Cin * 4)) return SMAP_E_ARG;
             return 0;
         case SMAP_OP_HEADSUM:
             if (o.n_aux < 1 || o.n_aux > 3 || o.Cout > 48 || o.Cin < o.Cout || o.ext_off < 0) return SMAP_E_ARG;
@@ -888,7 +923,7 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
         t = u;
     }
     for (int i = first; i < first + count; ++i)          // the status word (one per schedule) starts every run at 0
-        if (plan->ops[i].kind == SMAP_OP_HEADSUM && plan->ops[i].status_off > 0 && out) {
+        if ((plan->ops[i].kind == SMAP_OP_HEADSUM || plan->ops[i].kind == SMAP_OP_TAPSUM) && plan->ops[i].status_off > 0 && out) {
             if (hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(out) + plan->ops[i].status_off, 0, 4 * (size_t)SMAP_STATUS_WORDS(plan->ops[i].B), st); e != hipSuccess) return hip_rc(e);
             break;
         }
@@ -969,6 +1004,9 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
                 a.acc_scale0 = o.head_acc_scale;
                 a.wd = o.head_cin > 0 && o.short_acc_scale > 0.f ? reinterpret_cast<const _Float16*>(wb + o.short_w_off) : nullptr;
                 a.acc_scale_d = o.short_acc_scale;
+                a.tap_n = o.tap_n;
+                a.tap_w = o.tap_n > 0 ? reinterpret_cast<const _Float16*>(wb + o.tap_w_off) : nullptr;
+                a.tap_scale = o.tap_scale;
                 a.ksplit = o.ksplit > 1 ? o.ksplit : 1;
                 a.kpart = o.ksplit > 1 ? reinterpret_cast<float*>(ar + o.kpart_off) : nullptr;
                 a.kcount = o.ksplit > 1 ? reinterpret_cast<unsigned*>(ar + o.kcount_off) : nullptr;
@@ -1045,6 +1083,16 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
                 e = hipGetLastError();
                 break;
             }
+            case SMAP_OP_TAPSUM: {
+                if (!out) return fail(SMAP_E_ARG);
+                const long long total = (long long)o.B * o.H * o.W;
+                int* status = o.status_off > 0 ? reinterpret_cast<int*>(reinterpret_cast<char*>(out) + o.status_off) : nullptr;
+                hipLaunchKernelGGL(tapsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float*>(ar + o.aux_off[0]),
+                                   reinterpret_cast<const float*>(wb + o.bias_off), reinterpret_cast<float*>(reinterpret_cast<char*>(out) + o.ext_off),
+                                   o.B, o.H, o.W, o.Cin, status);
+                e = hipGetLastError();
+                break;
+            }
             case SMAP_OP_HEADSUM: {
                 if (!out) return fail(SMAP_E_ARG);
                 HeadSrc s;
@@ -1110,6 +1158,11 @@ int smap_workspace_bytes(const smap_plan* plan, int64_t* arena_bytes, int64_t* o
             case SMAP_OP_UPADD:
                 up(ar, o.in_off, M * o.Cout * 2); up(ar, o.out_off, M * o.Cout * 2);
                 up(ar, o.aux_off[0], (int64_t)o.B * o.aux_h[0] * o.aux_w[0] * o.Cout * 2); break;
+            case SMAP_OP_TAPSUM:
+                up(ar, o.aux_off[0], M * o.Cin * 4);
+                up(ob, o.ext_off, M * 4);
+                if (o.status_off > 0) up(ob, o.status_off, 4 * (int64_t)SMAP_STATUS_WORDS(o.B));
+                break;
             case SMAP_OP_HEADSUM: {
                 const int64_t frames = o.flip_from > 0 ? 2 * (int64_t)o.B : o.B;        // the sources hold the mirrored half too
                 for (int k = 0; k < o.n_aux; ++k) up(ar, o.aux_off[k], frames * o.aux_h[k] * o.aux_w[k] * o.Cin * 4);
@@ -1158,7 +1211,10 @@ int smap_plan_create_from_blob(const void* blob, size_t blob_bytes, smap_plan** 
             ok = inside(o.w_off, (int64_t)64 * ST_K * 2 * pl, wb) && inside(o.bias_off, 64 * 4, wb);
         } else if (o.kind == SMAP_OP_HEADSUM && o.flip_from > 0) {
             ok = o.Cout > 0 && inside(o.w_off, (int64_t)o.Cout * 4, wb);
+        } else if (o.kind == SMAP_OP_TAPSUM) {
+            ok = inside(o.bias_off, 4, wb);
         }
+        if (o.kind == SMAP_OP_CONV && o.tap_n > 0) ok = ok && inside(o.tap_w_off, (int64_t)(o.cout_pad / 32) * 2 * 64 * 8 * 2, wb);
         if (!ok) return SMAP_E_ARG;
     }
     smap_plan* p = nullptr;

@@ -32,7 +32,7 @@ import torch
 
 from . import lib as _L
 
-OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM, OP_STEMPOOL = range(6)
+OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM, OP_STEMPOOL, OP_TAPSUM = range(7)
 import os
 
 # tile id -> (BM, BN); ids 5..9 are the same tiles with deeper LDS-DMA pipelines (csrc/conv.hip)
@@ -612,6 +612,54 @@ class Graph:
             w_ref=w if self.keep_ref else None, b_ref=b if self.keep_ref else None)))
         return out
 
+    def conv_tapdot(self, name, pre1, pre3, x, frames=None):
+        """A 1x1 conv + ReLU (prefix pre1, 256 -> 256) whose ONLY consumer is a 3x3 conv with one output channel (prefix pre3) -- smap.py:227-229,
+        res_rd_conv1 -> res_rd_conv2 -- with the per-pixel half of that 3x3 inside its epilogue (include/smap_hip.h smap_op.tap_n): the launch
+        stores t[m][k] = <w3[k], y[m]>, nine fp32 numbers per pixel, instead of the 256-channel activation; Graph.tapsum finishes the conv.
+        Returns (t tensor, bias of the 3x3)."""
+        w1, b1 = fold_conv_bn(self.sd, pre1)
+        w3, b3 = fold_conv_bn(self.sd, pre3)
+        cout, cin = w1.shape[0], w1.shape[1]
+        assert cout == 256 == w3.shape[1] and w3.shape[0] == 1 and w3.shape[2] == 3 and cin == x.C and w1.shape[2] == 1
+        tile = 54
+        nfr = self.B if frames is None else frames
+        M = nfr * x.H * x.W
+        acc_scale = 1.0
+        if self.x3:
+            hi, lo, acc_scale = split_f16(w1.reshape(cout, cin))
+            wk = torch.stack([hi, lo])
+        else:
+            wk = w1.reshape(1, cout, cin).to(torch.float16)
+        wk = pack_conv_weights(wk, tile, self.x3, 1, cin, pairs=self.w_pairs)
+        # the 3x3's weights as B fragments of v_mfma_f32_16x16x32_f16 (include/smap_hip.h smap_op.tap_n): [K step][hi, lo][lane][8 halves],
+        # lane l = tap l % 16 (9..15: zeros), channels 32 step + 8 (l / 16) .. +7; pre-scaled by a power of two like every split weight matrix
+        tw = torch.zeros((16, cout), dtype=torch.float64)
+        tw[:9] = w3[0].permute(1, 2, 0).reshape(9, cout)                                   # [kh*3+kw][channel]
+        thi, tlo, tap_scale = split_f16(tw)
+        lane = torch.arange(64)
+        kidx = (torch.arange(cout // 32)[:, None, None] * 32 + (lane // 16)[None, :, None] * 8 + torch.arange(8)[None, None, :])     # [step][lane][8]
+        tapw = torch.stack([thi[(lane % 16)[None, :, None], kidx], tlo[(lane % 16)[None, :, None], kidx]], 1).contiguous()              # [step][2][64][8]
+        t = Tensor(name, self.B, x.H, x.W, 16, 4, 1)
+        self.tensors.append(t)
+        fl = 2 * M * cout * cin + 2 * M * 9 * cout
+        by = nfr * x.H * x.W * cin * 2 * x.planes + nfr * x.H * x.W * 16 * 4 + wk.numel() * 2
+        self.flops += fl
+        self.alg_bytes += by
+        keep = self.keep_ref
+        self.ops.append(Op(OP_CONV, out=t, inp=x, p=dict(
+            flops=fl, alg_bytes=by, kinds="1x1",
+            Cin=cin, in_c_off=0, Cout=cout, ksize=1, stride=1, pad=0, relu=1, cout_pad=cout, tile=tile, out_fp32=1,
+            w_off=self._add_w(wk), bias_off=self._add_w(b1.to(torch.float32)), acc_scale=acc_scale, frames=nfr, w_pairs=self.w_pairs,
+            tap=dict(w_off=self._add_w(tapw), scale=tap_scale, w_ref=w3 if keep else None),
+            w_ref=w1 if keep else None, b_ref=b1 if keep else None)))
+        return t, b3
+
+    def tapsum(self, t, b3, ext_off):
+        """The stencil half of conv_tapdot's 3x3: out[b,0,y,x] = b3 + sum over taps of t[b, y+kh-1, x+kw-1][3 kh + kw] -> the fp32 NCHW map at
+        ext_off of the output buffer (SMAP_OP_TAPSUM; stands where the head sum of that map stood)."""
+        self.ops.append(Op(OP_TAPSUM, aux=[t], p=dict(Cout=1, ext_off=ext_off, bias_off=self._add_w(b3.to(torch.float32).reshape(1)),
+                                                       b_ref=b3 if self.keep_ref else None)))
+
     def conv_cat(self, name, pre1, x, pre2, x2, stride2, relu=True, tile=None):
         """The last 1x1 of a Bottleneck (prefix pre1, on x) TOGETHER with the block's 1x1 shortcut conv (prefix pre2, on x2 sampled with spatial
         stride `stride2`) as ONE launch: out = act(W1 x + W2 x2 + b1 + b2) -- smap.py:60-77 adds the shortcut's output before the ReLU, no
@@ -1001,15 +1049,22 @@ class Graph:
                         cross = got[u + ".cross_conv"]
                 if heads:
                     if ind == 3:
-                        m = self.conv(u + ".heads1x1", [u + ".res_conv1", u + ".res_d_conv1", u + ".res_rd_conv1"], out, relu=True)
+                        # The root-depth head (res_rd_conv1 -> res_rd_conv2, a 3x3 with ONE output channel) as a 1x1 launch whose epilogue
+                        # keeps nine dot products per pixel instead of the 256-channel activation, + a nine-term stencil (conv_tapdot / tapsum):
+                        # 0.87 GB per 16 frames and the N = 1 MFMA launch (8.9 TFLOP/s) gone.  SMAP_TAPHEAD=0: round 5's three-way 1x1 + 3x3.
+                        tap = self.chl == 256 and os.environ.get("SMAP_TAPHEAD", "1") != "0"
+                        m = self.conv(u + ".heads1x1", [u + ".res_conv1", u + ".res_d_conv1"] + ([] if tap else [u + ".res_rd_conv1"]), out, relu=True)
                         c = self.chl
                         head_t["res4"] = self.conv(u + ".res", [u + ".res_conv2"], m, 3, relu=False, in_c_off=0, cin=c, out_fp32=True)
                         with self.on_lane(1):     # the three 3x3 heads read disjoint channel slices of m: side by side
                             head_t["res_d"] = self.conv(u + ".res_d", [u + ".res_d_conv2"], m, 3, relu=False, in_c_off=c, cin=c, out_fp32=True,
                                                         frames=self.frames)
                         with self.on_lane(2):
-                            head_t["res_rd"] = self.conv(u + ".res_rd", [u + ".res_rd_conv2"], m, 3, relu=False, in_c_off=2 * c, cin=c,
-                                                         out_fp32=True, frames=self.frames)
+                            if tap:
+                                head_t["res_rd_tap"] = self.conv_tapdot(u + ".res_rd_t", u + ".res_rd_conv1", u + ".res_rd_conv2", out, frames=self.frames)
+                            else:
+                                head_t["res_rd"] = self.conv(u + ".res_rd", [u + ".res_rd_conv2"], m, 3, relu=False, in_c_off=2 * c, cin=c,
+                                                             out_fp32=True, frames=self.frames)
                     elif ind >= 1:
                         with self.on_lane(1):     # the 3x3 head of this unit runs beside the next unit's launches
                             head_t[f"res{ind + 1}"] = self.conv(u + ".res", [u + ".res_conv2"], got[u + ".res1"], 3, relu=False, out_fp32=True)
@@ -1065,7 +1120,10 @@ class Graph:
             with self.on_lane(1):
                 self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_d"]], p=dict(Cout=n_d, ext_off=self.out_layout["det_d"][0])))
             with self.on_lane(2):
-                self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_rd"]], p=dict(Cout=1, ext_off=self.out_layout["root_d"][0])))
+                if "res_rd_tap" in head_t:
+                    self.tapsum(*head_t["res_rd_tap"], self.out_layout["root_d"][0])
+                else:
+                    self.ops.append(Op(OP_HEADSUM, aux=[head_t["res_rd"]], p=dict(Cout=1, ext_off=self.out_layout["root_d"][0])))
         return cross, (s1 if gen_skip else None), (s2 if gen_skip else None)
 
     # -- arena: liveness-based first-fit allocation
@@ -1208,6 +1266,9 @@ class Graph:
                     t = op.aux[0]
                     assert t.C == y.C and t.esize == 2
                     o.aux_off[0], o.aux_h[0], o.aux_w[0] = t.off, t.H, t.W
+                if "tap" in p:
+                    o.tap_n, o.tap_w_off, o.tap_scale = 9, p["tap"]["w_off"], p["tap"]["scale"]
+                    o.out_stride_c = 16
                 if "cat" in p:
                     t = op.aux2
                     assert t.off // WINDOW == x.off // WINDOW, (y.name, "both inputs of a conv_cat launch must lie in one 4 GiB window")
@@ -1236,6 +1297,13 @@ class Graph:
                 o.relu = p["relu"]
                 o.in_off, o.out_off = x.off, y.off
                 o.aux_off[0], o.aux_h[0], o.aux_w[0] = t.off, t.H, t.W
+            elif op.kind == OP_TAPSUM:
+                t = op.aux[0]
+                o.H, o.W, o.Cin, o.Ho, o.Wo, o.Cout = t.H, t.W, t.C, self.out_h, self.out_w, 1
+                o.aux_off[0], o.aux_h[0], o.aux_w[0] = t.off, t.H, t.W
+                o.ext_off, o.bias_off = p["ext_off"], p["bias_off"]
+                o.B = self.frames
+                o.status_off = self.status_off
             elif op.kind == OP_HEADSUM:
                 s0 = op.aux[0]
                 assert all(t.C == s0.C and t.esize == 4 for t in op.aux)

@@ -1000,6 +1000,67 @@ def test_merged_1x1_launch_matches_torch(case, x3):
         assert torch.isfinite(got).all() and err < ((3e-6 * mx + 1e-6) if x3 else 2e-3 * mx), (j, err, mx)
 
 
+@pytest.mark.parametrize("x3", [True, False], ids=["x3", "f16"])
+@pytest.mark.parametrize("shape", [(2, 16, 24), (1, 13, 21), (3, 5, 7), (1, 32, 52)], ids=lambda c: "x".join(map(str, c)))
+def test_one_channel_3x3_head_as_tap_dots_and_a_stencil(shape, x3):
+    """Graph.conv_tapdot + Graph.tapsum (smap_op.tap_n, SMAP_OP_TAPSUM): conv3x3_{256->1}(relu(conv1x1_{256->256}(x))) -- the root-depth head,
+    smap.py:227-229 -- with the 256-channel activation never stored: the 1x1 launch keeps nine dot products per pixel, a stencil sums them.
+    Against the f64 evaluation of the two convs; ragged M tiles, maps smaller than a tile, zero padding at the border."""
+    import torch.nn.functional as F
+    from smap_amd import engine as E
+    from smap_amd import lib as L
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(B * 100 + H)
+    sd = {}
+    for pre, co, ci, k in (("c1", 256, 256, 1), ("c3", 1, 256, 3)):
+        sd[pre + ".conv.weight"] = torch.randn(co, ci, k, k, generator=gen) * (1.0 / (ci * k * k)) ** 0.5
+        sd[pre + ".conv.bias"] = torch.randn(co, generator=gen) * 0.1
+        sd[pre + ".bn.weight"] = torch.rand(co, generator=gen) + 0.5
+        sd[pre + ".bn.bias"] = torch.randn(co, generator=gen) * 0.1
+        sd[pre + ".bn.running_mean"] = torch.randn(co, generator=gen) * 0.1
+        sd[pre + ".bn.running_var"] = torch.rand(co, generator=gen) + 0.5
+    g = E.Graph(sd, B, 4 * H, 4 * W, keep_ref=True, precision="x3" if x3 else "f16", build=False)
+    g.w_pairs = int(B == 1)
+    g.out_h, g.out_w, g.status_off, g.status_words = H, W, B * H * W * 4, 1
+    xt = g.tensor("x", H, W, 256)
+    t, b3 = g.conv_tapdot("t", "c1", "c3", xt)
+    g.tapsum(t, b3, 0)
+    xt.first = 0
+    g.allocate(reuse=False)
+    ops = g.emit()
+    lib = L.load()
+    h = C.c_void_p()
+    L.check(lib.smap_plan_create(ops, 2, C.byref(h)), "smap_plan_create")
+    arena = torch.zeros(g.arena_bytes, dtype=torch.uint8, device=DEV)
+    v = torch.randn(B, 256, H, W, generator=gen).permute(0, 2, 3, 1).contiguous()
+    hi = v.to(torch.float16)
+    if xt.planes == 2:
+        lo = (v - hi.float()).to(torch.float16)
+        raw, val = torch.stack([hi, lo], 3).reshape(-1), hi.double() + lo.double()
+    else:
+        raw, val = hi.reshape(-1), hi.double()
+    arena[xt.off:xt.off + xt.nbytes].view(torch.float16).copy_(raw.to(DEV))
+    xv = val.permute(0, 3, 1, 2)
+    blob = g.weight_blob().to(DEV)
+    out = torch.full((B * H * W + 1,), 7.0, dtype=torch.float32, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()), C.c_void_p(out.data_ptr()), st), "run")
+    torch.cuda.synchronize()
+    lib.smap_plan_destroy(h)
+    p = g.ops[0].p
+    q = (lambda w: w.double()) if x3 else (lambda w: w.to(torch.float16).double())
+    y = F.relu(F.conv2d(xv, q(p["w_ref"]), p["b_ref"].double()))
+    want = F.conv2d(y, p["tap"]["w_ref"].double(), g.ops[1].p["b_ref"].double(), padding=1)
+    got = out[:B * H * W].view(B, 1, H, W).cpu().double()
+    err, mx = (got - want).abs().max().item(), want.abs().max().item()
+    assert int(out[-1:].view(torch.int32).item()) == 0 and err < ((3e-6 * mx + 1e-6) if x3 else 2e-3 * mx), (err, mx)
+    tt = arena[t.off:t.off + t.nbytes].view(torch.float32).view(B, H, W, 16).cpu()
+    assert not tt[..., 9:].any()                                                 # the padding lanes of a pixel's 16 floats
+    bad = (L.SmapOp * 2)(ops[0], ops[1])
+    bad[0].tile = 50                                                             # only the one-N-tile 128 x 256 instance has the epilogue
+    assert lib.smap_plan_create(bad, 2, C.byref(h)) == -1
+
+
 CAT_CASES = [   # B, H (out), W (out), planes (c3's K), in_planes (the shortcut's K), cout, spatial stride of the shortcut, tile
     (2, 8, 13, 128, 256, 512, 2, 50),          # layer2's first block in small: ragged M tile, stride 2 (odd input width 25 -> 13)
     (1, 16, 26, 256, 512, 1024, 2, 51),        # layer3's

@@ -80,7 +80,7 @@ def test_x3_graph_emits_split_strides_and_weights(small_sd, monkeypatch, blocks)
 
 
 def test_flip_graph_runs_two_B_frames_and_merges_in_the_head_sum(small_sd):
-    from smap_amd.engine import Graph, OP_CONV, OP_HEADSUM, OP_STEM
+    from smap_amd.engine import Graph, OP_CONV, OP_HEADSUM, OP_STEM, OP_TAPSUM
     pair = list(range(43))[::-1]
     g = Graph(small_sd, 3, 64, 96, flip_pair=pair)
     g.allocate()
@@ -89,14 +89,15 @@ def test_flip_graph_runs_two_B_frames_and_merges_in_the_head_sum(small_sd):
     kinds = [op.kind for op in g.ops]
     stem = ops[kinds.index(OP_STEM)]
     assert stem.B == 6 and stem.flip_from == 3
-    heads = [o for o in ops if o.kind == OP_HEADSUM]
+    heads = [o for o in ops if o.kind in (OP_HEADSUM, OP_TAPSUM)]      # hms, det_d: head sums; root_d: the stencil half of its 3x3 (Graph.tapsum)
+    assert [h.kind for h in heads] == [OP_HEADSUM, OP_HEADSUM, OP_TAPSUM]
     assert [h.B for h in heads] == [3, 3, 3] and [h.flip_from for h in heads] == [3, 0, 0]
     assert heads[0].in_c_off == 15 and heads[0].w_off >= 0
     blob = g.weight_blob()
     tab = blob[heads[0].w_off:heads[0].w_off + 43 * 4].view(torch.int32).tolist()
     assert tab == pair
     convs = {op.out.name: o for op, o in zip(g.ops, ops) if op.kind == OP_CONV}
-    depth = [n for n in convs if n.endswith(".res_d") or n.endswith(".res_rd")]
+    depth = [n for n in convs if n.endswith(".res_d") or n.endswith(".res_rd_t")]
     assert len(depth) == 2 and all(convs[n].B == 3 for n in depth)          # mirrored half of the depth heads: never read
     assert all(o.B == 6 for n, o in convs.items() if n not in depth)
     with pytest.raises(AssertionError):
@@ -141,8 +142,10 @@ def test_shipped_launcher_settings_are_plannable():
     h = C.c_void_p()
     assert L.load().smap_plan_create(g.emit(), len(g.ops), C.byref(h)) == 0
     L.load().smap_plan_destroy(h)
+    # (the widest tensor is the 512-channel head tensor since round 6 -- the root-depth head no longer stores its 256 channels --: 78 frames per window)
+    Graph(sd, 32, 512, 832, precision="x3", flip_pair=list(range(43))).allocate()
     with pytest.raises(ArenaTooLarge, match="smaller batch"):
-        Graph(sd, 32, 512, 832, precision="x3", flip_pair=list(range(43))).allocate()
+        Graph(sd, 40, 512, 832, precision="x3", flip_pair=list(range(43))).allocate()
     with pytest.raises(ValueError):
         Graph(sd, 1, 64, 96, flip_pair=[0] * 43)             # not a permutation
 

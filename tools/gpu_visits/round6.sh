@@ -170,4 +170,32 @@ cat $O/ab_cat.log
 layers $O d1_f16_cat 16 --depth 1 --steps 6 --warmup 2
 }
 
+v10() {
+# visit 10: ResNet_top as one kernel (SMAP_STEMPOOL=1) in situ, once more on this round's schedule
+O=gpurun_out/r6v10; mkdir -p $O
+for rep in 1 2; do
+  for v in "SMAP_X=0" "SMAP_STEMPOOL=1"; do
+    env $v SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep depth 2 [$v]" >> $O/ab.log
+  done
+done
+cat $O/ab.log
+}
+
+v11() {
+# visit 11: the root-depth head as tap dots + a stencil (Graph.conv_tapdot / tapsum): parity, in situ against round 5's three-way 1x1 + 3x3
+O=gpurun_out/r6v11; mkdir -p $O
+timeout 1500 python -m pytest tests/test_backbone_gpu.py tests/test_abi_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "tap_dots or small_schedule or full_size or smap_module or plan_blob or flip_tta or several_input" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -6 $O/pytest.log
+for rep in 1 2; do
+  for v in "SMAP_TAPHEAD=0" "SMAP_TAPHEAD=1"; do
+    env $v SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep depth 2 [$v]" >> $O/ab_tap.log
+  done
+done
+for v in "SMAP_TAPHEAD=0" "SMAP_TAPHEAD=1"; do
+  env $v SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 2>>$O/ab.err | line "depth 1 [$v]" >> $O/ab_tap.log
+done
+cat $O/ab_tap.log
+layers $O d1_f16_tap 16 --depth 1 --steps 6 --warmup 2
+}
+
 "v$1"

@@ -16,7 +16,7 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     import torch
     from types import SimpleNamespace as NS
-    from smap_amd.engine import Graph, OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM, OP_STEMPOOL, TILES
+    from smap_amd.engine import Graph, OP_CONV, OP_STEM, OP_MAXPOOL, OP_UPADD, OP_HEADSUM, OP_STEMPOOL, OP_TAPSUM, TILES
     from smap_amd.model.smap import SMAP
     cfg = NS(MODEL=NS(STAGE_NUM=3, UPSAMPLE_CHANNEL_NUM=256), DATASET=NS(KEYPOINT=NS(NUM=15), PAF=NS(NUM=14)),
              OUTPUT_SHAPE=(128, 208), LOSS=NS(OHKM=True, TOPK=8, COARSE_TO_FINE=True))
@@ -24,7 +24,7 @@ def main():
     g = Graph(SMAP(cfg).state_dict(), B, 512, 832, precision=os.environ.get("SMAP_PRECISION", "f16"))
     # kernel-name fragments per op kind (conv ops run conv.hip, conv2.hip, conv3.hip or conv1.hip kernels, by tile id)
     names = {OP_CONV: ("conv_igemm", "conv3x3_halo", "conv1x1_ws", "convp_kernel", "conv3_tail_kernel", "bottleneck_kernel", "bottleneck_first_kernel", "bottleneck128_kernel"), OP_STEM: ("stem_kernel",), OP_STEMPOOL: ("stem_pool_kernel",), OP_MAXPOOL: ("maxpool",),
-             OP_UPADD: ("upadd",), OP_HEADSUM: ("headsum",)}       # set SMAP_NO_UPADD_FUSION=1 for pre-fusion traces
+             OP_UPADD: ("upadd",), OP_HEADSUM: ("headsum",), OP_TAPSUM: ("tapsum",)}       # set SMAP_NO_UPADD_FUSION=1 for pre-fusion traces
     con = sqlite3.connect(db)
     rows = con.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
     mine = [r for r in rows if any(k in r[0] for ks in names.values() for k in ks)]
@@ -59,7 +59,7 @@ def main():
             key = (shape, tile)
             a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += d; a[2] += fl; a[3] += by
-        name = op.out.name if op.out is not None else "headsum"
+        name = op.out.name if op.out is not None else ("tapsum" if op.kind == OP_TAPSUM else "headsum")
         print(f"{i:4d} {name[-44:]:44} {shape:34} {tile:8} {d:8.1f} {fl / d / 1e6 if d else 0:7.1f} {by / d / 1e3 if d else 0:7.0f}")
     print("total us per forward", tot, "runs", runs)
     print("\n== by shape")

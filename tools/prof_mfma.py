@@ -23,7 +23,7 @@ ids = sorted(by)
 stems = [i for i in ids if "stem_kernel" in by[i]["name"]]
 for last in reversed(stems):
     seg = [i for i in ids if i >= last]
-    heads = [i for i in seg if "headsum" in by[i]["name"]][:3]
+    heads = [i for i in seg if "headsum" in by[i]["name"] or "tapsum" in by[i]["name"]][:3]
     if len(heads) == 3:
         break
 seg = [i for i in seg if i <= heads[-1]]

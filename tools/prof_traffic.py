@@ -20,7 +20,7 @@ def total(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     stems = [i for i, r in enumerate(rows) if "stem_kernel" in r["Kernel_Name"] or "stem_pool_kernel" in r["Kernel_Name"]]
-    heads = [i for i, r in enumerate(rows) if "headsum" in r["Kernel_Name"]]
+    heads = [i for i, r in enumerate(rows) if "headsum" in r["Kernel_Name"] or "tapsum" in r["Kernel_Name"]]      # the three maps' final launches
     # the last forward that is complete: from its stem launch to its third headsum launch
     for s in reversed(stems):
         hs = [h for h in heads if h > s][:3]
