@@ -272,6 +272,16 @@ typedef struct smap_op {
        (one 64-bit base per launch, include/smap_hip.h "windows").  Not with split K, N segments, the fused bilinear add or a 3x3. */
     int64_t in2_off;
     int32_t in2_H, in2_W, in2_C, in2_stride_c, in2_stride;
+    /* in2_mode = 1 (needs in2_C > 0, in2_stride = 1): NOT one sum over the concatenated K but the sum of two ACTIVATED convs,
+           out = relu(W1 x + b1) + relu(W2 x2 + b2),
+       in one launch: the K loop walks x's tiles, the accumulators are turned into relu(acc * acc_scale + bias) and parked in registers, then
+       it walks x2's tiles from zero.  The inter-stage skips of an Upsample_unit, skip1(x) + skip2(out) (smap.py:218-241, 142-153: both are only
+       ever ADDED to the next stage's feature map), as ONE tensor: one write and one read of an in_planes-wide tensor less per level.  The
+       packed weight matrix is [W1 2^s1 | W2 2^s2] along K; bias_off / acc_scale belong to W1, in2_bias_off / in2_acc_scale to W2; the op's
+       relu field is ignored.  in2_mode = 0: the K-concatenated sum described above. */
+    int32_t in2_mode;
+    float in2_acc_scale;
+    int64_t in2_bias_off;
     /* TAP-DOT EPILOGUE (round 6; csrc/conv.hip tile 54 = 128 x 256, cout_pad = 256 = ONE N tile, ksize 1): tap_n = 9 -- the launch's
        activation y = act(W x + b) is NOT stored; its only consumer is a 3x3 conv with one output channel (smap.py:227-229, res_rd_conv2 on
        res_rd_conv1), whose per-pixel half the epilogue computes instead, on the matrix cores: t[m][k] = < tapw[k], y[m] >, k = 0..8.

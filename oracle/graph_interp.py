@@ -59,7 +59,11 @@ def run_graph(g, imgs, quantize, keep=False):
                 w, b = p["w_ref"].to(dt), p["b_ref"].to(dt)
                 w2, b2 = (p["cat"]["w_ref"].to(dt), p["cat"]["b_ref"].to(dt)) if cin2 else (None, None)
             y = F.conv2d(x, w.to(dev), b.to(dev), stride=p["stride"], padding=p["pad"])
-            if cin2:
+            if cin2 and p["cat"].get("relusum"):         # relu(conv1(x)) + relu(conv2(x2)): two activated convs, one tensor (Graph.conv_relusum)
+                if quantize:
+                    b2 = blob[p["cat"]["bias_off"]:p["cat"]["bias_off"] + p["cout_pad"] * 4].view(torch.float32)[:cout].clone()
+                y = F.relu(y) + F.relu(F.conv2d(T[op.aux2.name][:, :cin2], w2.to(dev), b2.to(dev)))
+            elif cin2:
                 st2 = p["cat"]["stride"]
                 y = y + F.conv2d(T[op.aux2.name][:, :cin2, ::st2, ::st2], w2.to(dev), b2.to(dev) if b2 is not None else None)
             if "tail" in p:                              # fused Bottleneck tail (csrc/convf.hip): relu(3x3) -> 1x1; the 3x3's

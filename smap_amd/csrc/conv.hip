@@ -72,10 +72,15 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 //     conv3x3(y)[p] = sum over taps of  < w[tap], y[p + offset(tap)] >
 // so the epilogue stores t[p][tap] = < w[tap], y[p] > -- nine fp32 numbers per pixel instead of 256 hi | lo pairs -- and a nine-term stencil
 // over t (plan.hip::tapsum_kernel) finishes the conv.  Dot products in fp32 on the fp32 accumulators (nothing is rounded to fp16 in between).
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3, bool SPLITK = false, bool REGEPI = false, bool DUAL = false, bool TAPDOT = false>
+// RELUSUM = true (with DUAL; smap_op.in2_mode = 1): out = relu(W1 x + b1) + relu(W2 x2 + b2).  When the K loop reaches the second input's first
+// tile the accumulators become relu(acc * s1 + b1) and are parked in registers (as many again as the accumulators: 32 per lane on the
+// eight-wave 128 x 128 tiles), the accumulators restart at zero; the LDS epilogue tile receives relu(acc * s2 + b2) + parked.
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FULL, bool X3, bool SPLITK = false, bool REGEPI = false, bool DUAL = false, bool TAPDOT = false,
+          bool RELUSUM = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a)
 {
     static_assert(!TAPDOT || (!FULL && !SPLITK && !REGEPI && !DUAL), "tap-dot epilogue: plain instance only");
+    static_assert(!RELUSUM || DUAL, "relu-sum: a second input");
     static_assert(!REGEPI || (X3 && !FULL && !SPLITK), "register epilogue: split precision, plain epilogue, no split K");
     static_assert(!DUAL || (!FULL && !SPLITK && !REGEPI), "second input: plain epilogue, no split K");
     constexpr int NPL = X3 ? 2 : 1;                    // fp16 planes per operand
@@ -341,6 +346,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     const int rswz = BK == 64 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
     const int a_row0 = wm * (BM / WM) + l31;     // + mi*32
     const int b_row0 = wn * (BN / WN) + l31;     // + ni*32
+    f32x16 park[RELUSUM ? MI : 1][RELUSUM ? NI : 1];          // relu(W1 x + b1) of this lane's accumulator elements
+    float bias1[RELUSUM ? NI : 1];                            // (loaded HERE: a plain load inside the LDS-DMA pipeline would drain vmcnt)
+    if (RELUSUM) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bias1[ni] = a.bias[n0 + wn * (BN / WN) + ni * 32 + l31];
+    }
 
     // ---- STAGES-deep LDS-DMA pipeline.  Iteration `it` needs K tile `it`; tiles it+1 .. it+STAGES-2
     //      stay in flight across the barrier (counted vmcnt + raw s_barrier: a __syncthreads() here
@@ -365,6 +376,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         if (it == 0) tr_t[2] = __builtin_amdgcn_s_memtime();
 #endif
         if (it + STAGES - 1 < n_iter && !(SMAP_ABLATE & 1)) stage(nbuf);
+        if (RELUSUM && it == cchunks) {        // the first conv is complete: activate, park, restart
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = X3 ? acc[mi][ni][r] * o_scale + bias1[ni] : acc[mi][ni][r] + bias1[ni];
+                        park[mi][ni][r] = v < 0.f ? 0.f : v;          // NaN stays NaN (torch's ReLU)
+                        acc[mi][ni][r] = 0.f;
+                    }
+        }
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + NPL * BM * ROWB;
 #pragma unroll
@@ -485,12 +508,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int col = wn * (BN / WN) + ni * 32 + l31;
-        const float bias = a.bias[n0 + col];
+        const float bias = RELUSUM ? a.bias_b[n0 + col] : a.bias[n0 + col];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * (BM / WM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (RELUSUM) {
+                    const float v = X3 ? acc[mi][ni][r] * a.acc_scale_b + bias : acc[mi][ni][r] + bias;
+                    Cs[row * CSS + col] = (v < 0.f ? 0.f : v) + park[mi][ni][r];
+                    continue;
+                }
                 Cs[row * CSS + col] = S > 1 ? acc[mi][ni][r] : (X3 ? acc[mi][ni][r] * o_scale + bias : acc[mi][ni][r] + bias);
             }
     }
@@ -754,7 +782,16 @@ hipError_t launch_dual(const ConvArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool X3>
+hipError_t launch_relusum(const ConvArgs& a, hipStream_t st)
+{
+    if (a.up || a.add1 || a.add2 || a.res || a.ksplit > 1 || a.ksize != 1 || a.relu || !a.bias_b) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, BK, false, X3, false, false, true, false, true>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+    return hipGetLastError();
+}
+
 int smap_conv_tile_has_dual(int tile) { return tile == 20 || tile == 50 || tile == 51; }
+int smap_conv_tile_has_relusum(int tile) { return tile == 50 || tile == 51; }
 
 // the tap-dot instance (smap_op.tap_n = 9; tile 54 only: one N tile of 256 channels)
 template <bool X3>
@@ -828,6 +865,13 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
     if (tile >= 80 && tile < 90) return smap_launch_convf(a, tile, st);      // 3x3 + fused 1x1 tail, both precisions
     if (tile >= 90 && tile < 100) return smap_launch_convb(a, tile, st);     // whole identity Bottleneck, split precision
     if (a.tap_n > 0) return tile == 54 ? (a.x3 ? launch_tapdot<true>(a, st) : launch_tapdot<false>(a, st)) : hipErrorInvalidValue;
+    if (a.Cin2 > 0 && a.bias_b) {                           // ... as the sum of two ACTIVATED convs (smap_op.in2_mode = 1): the eight-wave tiles only
+        switch (tile) {                                     // (the four-wave 128 x 128 instance needs 288 registers: one wave per SIMD)
+            case 50: return a.x3 ? launch_relusum<128, 128, 2, 4, 2, 32, true>(a, st) : launch_relusum<128, 128, 2, 4, 2, 32, false>(a, st);
+            case 51: return a.x3 ? launch_relusum<128, 128, 4, 2, 2, 32, true>(a, st) : launch_relusum<128, 128, 4, 2, 2, 32, false>(a, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     if (a.Cin2 > 0) {                                       // second input along K: its own instances of three tiles (smap_conv_tile_has_dual)
         switch (tile) {
             case 20: return a.x3 ? launch_dual<128, 128, 2, 2, 2, 32, true>(a, st) : launch_dual<128, 128, 2, 2, 2, 32, false>(a, st);

@@ -46,6 +46,9 @@ struct ConvArgs {
     // second input, concatenated along K (smap_op.in2_*, conv.hip template DUAL): K = Cin + Cin2, 1x1; x2 sampled with spatial stride stride2
     long long in2_off;       // byte offset from the launch's base (the first input's window)
     int H2, W2, Cin2, in2_stride_c, stride2, in2_lo;
+    // in2_mode 1 (conv.hip template RELUSUM): relu(W1 x + b1) + relu(W2 x2 + b2); bias / acc_scale are W1's, these W2's
+    const float* bias_b;
+    float acc_scale_b;
     // tap-dot epilogue (smap_op.tap_n, conv.hip template TAPDOT): instead of storing its [M][N] activation the launch stores, per pixel, the
     // tap_n dot products of that activation with tap_n weight vectors -- the per-pixel half of a following 3x3 conv with ONE output channel
     const _Float16* tap_w;   // [8 K steps][hi, lo][64 lanes][8 halves]: B fragments of v_mfma_f32_16x16x32_f16, or null
@@ -85,6 +88,7 @@ __device__ __forceinline__ Lerp lerp_index(int dst, int in_size, int out_size)
 }
 
 int smap_conv_tile_has_splitk(int tile);                                    // conv.hip: tile ids with a split-K instance
+int smap_conv_tile_has_relusum(int tile);                                   // ... with a relu(conv) + relu(conv) instance (smap_op.in2_mode = 1)
 int smap_conv_tile_has_dual(int tile);                                      // conv.hip: tile ids with a second-input (K-concatenated) instance
 int smap_conv_tile_has_x3(int tile);                                        // conv.hip: tile ids with a split-precision instance
 hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st);

@@ -704,7 +704,10 @@ static int validate(const smap_op& o)
                 if (window_of(o.in2_off) != window_of(o.in_off) || o.in2_off - window_of(o.in_off) + b2 > ((int64_t)1 << 32) || hits_zero_page(o.in2_off, b2))
                     return SMAP_E_ARG;
                 if ((int64_t)o.cout_pad * (o.Cin + o.in2_C) * 2 * (1 + o.precision) > ((int64_t)1 << 32)) return SMAP_E_ARG;
-            }
+                if (o.in2_mode != 0 && o.in2_mode != 1) return SMAP_E_ARG;
+                if (o.in2_mode == 1 && (!smap_conv_tile_has_relusum(o.tile) || o.in2_stride != 1 || o.res_off >= 0 || o.relu != 0 || o.in2_bias_off < 0 || (o.precision == 1 && !(o.in2_acc_scale > 0.f))))
+                    return SMAP_E_ARG;               // relu(W1 x + b1) + relu(W2 x2 + b2): its own activations, no residual
+            } else if (o.in2_mode != 0) return SMAP_E_ARG;
             if (o.seg_n[0] == 0 && o.seg_n[1] != 0) return SMAP_E_ARG;
             if (o.seg_n[0] != 0) {                       // N segments: conv.hip's tiles, 1x1, fp16 outputs; every segment starts on an N tile
                 const bool igemm = (o.tile >= 0 && o.tile < 30) || (o.tile >= 50 && o.tile < 60);
@@ -987,6 +990,8 @@ static int run_ops(const smap_plan* plan, int first, int count, const float* con
                 a.Cin2 = o.in2_C > 0 ? o.in2_C : 0;
                 a.in2_off = o.in2_C > 0 ? o.in2_off - window_of(o.in_off) : 0;       // same base as the first input (validate: same window)
                 a.H2 = o.in2_H; a.W2 = o.in2_W; a.in2_stride_c = o.in2_stride_c; a.stride2 = o.in2_stride; a.in2_lo = o.in2_stride_c / 2;
+                a.bias_b = (o.in2_C > 0 && o.in2_mode == 1) ? reinterpret_cast<const float*>(wb + o.in2_bias_off) : nullptr;
+                a.acc_scale_b = o.in2_acc_scale;
                 a.x3 = o.precision;
                 a.in_lo = o.in_stride_c / 2;
                 a.out_lo = o.out_stride_c / 2;
@@ -1214,6 +1219,7 @@ int smap_plan_create_from_blob(const void* blob, size_t blob_bytes, smap_plan** 
         } else if (o.kind == SMAP_OP_TAPSUM) {
             ok = inside(o.bias_off, 4, wb);
         }
+        if (o.kind == SMAP_OP_CONV && o.in2_C > 0 && o.in2_mode == 1) ok = ok && inside(o.in2_bias_off, (int64_t)o.cout_pad * 4, wb);
         if (o.kind == SMAP_OP_CONV && o.tap_n > 0) ok = ok && inside(o.tap_w_off, (int64_t)(o.cout_pad / 32) * 2 * 64 * 8 * 2, wb);
         if (!ok) return SMAP_E_ARG;
     }

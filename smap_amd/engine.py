@@ -122,6 +122,7 @@ def _table_entry(v):
 
 REGEPI_TILES = (56,)               # csrc/conv.hip tiles with the register epilogue
 DUAL_TILES = (20, 50, 51)          # csrc/conv.hip tiles with a second-input (K-concatenated) instance (smap_conv_tile_has_dual)
+RELUSUM_TILES = (50, 51)           # ... with a relu(conv) + relu(conv) instance (smap_conv_tile_has_relusum)
 
 
 def tile_legal(tile, *, cout, cout_pad=None, plain3=True, up=False, out_fp32=False, adds=False, x3=True):
@@ -612,6 +613,50 @@ class Graph:
             w_ref=w if self.keep_ref else None, b_ref=b if self.keep_ref else None)))
         return out
 
+    def conv_relusum(self, name, pre1, x, pre2, x2, tile=None):
+        """relu(conv1(x)) + relu(conv2(x2)) as ONE launch and ONE tensor (include/smap_hip.h smap_op.in2_mode = 1): the two inter-stage skips of an
+        Upsample_unit, skip1 on the unit's input and skip2 on its output (smap.py:218-241), which the next stage only ever ADDS to its feature map
+        (smap.py:142-153).  One write and one read of an in_planes-wide tensor less per level; each conv keeps its own power-of-two scale."""
+        (w1, b1), (w2, b2) = fold_conv_bn(self.sd, pre1), fold_conv_bn(self.sd, pre2)
+        cout, c1, c2 = w1.shape[0], w1.shape[1], w2.shape[1]
+        assert w2.shape[0] == cout and w1.shape[2] == 1 == w2.shape[2] and c1 == x.C and c2 == x2.C and cout % 8 == 0 and (x.H, x.W) == (x2.H, x2.W)
+        M, K = self.B * x.H * x.W, c1 + c2
+        if tile is None:
+            key = f"{self.B},{x.H},{x.W},{c1}+{c2}relusum,{cout},1,1"
+            cands = (pick_tile_x3(M, cout, key) if self.x3 else []) + [50, 51]
+            forced = os.environ.get("SMAP_RELUSUM_TILE", "")                     # A/B hook
+            tile = int(forced) if forced else next(t for t in cands if t in RELUSUM_TILES)
+        assert tile in RELUSUM_TILES, tile
+        bn = TILES[tile][1]
+        cout_pad = _rup(cout, bn)
+        sc1 = sc2 = 1.0
+        if self.x3:
+            h1, l1, sc1 = split_f16(w1.reshape(cout, c1))
+            h2, l2, sc2 = split_f16(w2.reshape(cout, c2))
+            wk = torch.zeros((2, cout_pad, K), dtype=torch.float16)
+            wk[0, :cout], wk[1, :cout] = torch.cat([h1, h2], 1), torch.cat([l1, l2], 1)
+        else:
+            wk = torch.zeros((1, cout_pad, K), dtype=torch.float16)
+            wk[0, :cout] = torch.cat([w1.reshape(cout, c1), w2.reshape(cout, c2)], 1).to(torch.float16)
+            if not torch.isfinite(wk).all():
+                raise ValueError(f"{name}: folded weights exceed the fp16 range")
+        wk = pack_conv_weights(wk, tile, self.x3, 1, K, pairs=self.w_pairs)
+        bk1, bk2 = torch.zeros((cout_pad,), dtype=torch.float32), torch.zeros((cout_pad,), dtype=torch.float32)
+        bk1[:cout], bk2[:cout] = b1.to(torch.float32), b2.to(torch.float32)
+        out = self.tensor(name, x.H, x.W, cout)
+        fl = 2 * M * cout * K
+        by = x.nbytes + x2.nbytes + out.nbytes + wk.numel() * 2
+        self.flops += fl
+        self.alg_bytes += by
+        keep = self.keep_ref
+        self.ops.append(Op(OP_CONV, out=out, inp=x, aux2=x2, p=dict(
+            flops=fl, alg_bytes=by, kinds="1x1",
+            Cin=c1, in_c_off=0, Cout=cout, ksize=1, stride=1, pad=0, relu=0, cout_pad=cout_pad, tile=tile, out_fp32=0,
+            w_off=self._add_w(wk), bias_off=self._add_w(bk1), acc_scale=sc1, frames=self.B, w_pairs=self.w_pairs,
+            cat=dict(cin=c2, stride=1, relusum=True, acc_scale=sc2, bias_off=self._add_w(bk2), w_ref=w2 if keep else None, b_ref=b2 if keep else None),
+            w_ref=w1 if keep else None, b_ref=b1 if keep else None)))
+        return out
+
     def conv_tapdot(self, name, pre1, pre3, x, frames=None):
         """A 1x1 conv + ReLU (prefix pre1, 256 -> 256) whose ONLY consumer is a 3x3 conv with one output channel (prefix pre3) -- smap.py:227-229,
         res_rd_conv1 -> res_rd_conv2 -- with the per-pixel half of that 3x3 inside its epilogue (include/smap_hip.h smap_op.tap_n): the launch
@@ -1019,18 +1064,24 @@ class Graph:
         for ind, xin in enumerate((x4, x3, x2, x1)):
             u = f"{pre}upsample.up{ind + 1}"
             un = f"{pre}upsample.up{ind + 2}"                     # the next unit: its up_conv reads this unit's `out` (commuted with the upsample)
+            # The inter-stage skips as ONE tensor per level: skip1(x) + skip2(out) in one launch (conv_relusum); the next stage adds that one tensor.
+            # SMAP_SKIPSUM=0: round 5's two tensors (skip1 beside u_skip, skip2 as a segment of the launch on `out`).  Not beyond one 4 GiB window.
+            skipsum = gen_skip and merge and os.environ.get("SMAP_SKIPSUM", "1") != "0" and self.B * self.H * self.W <= 20 * 512 * 832
             if merge:
                 # launch 1, on x:   out = relu(u_skip(x) [+ bilinear(up_conv@low)])  |  skip1 = relu(skip1(x))
-                if gen_skip and (tl is None or merge_mode == "2"):
+                if gen_skip and not skipsum and (tl is None or merge_mode == "2"):
                     out, s1[3 - ind] = self.conv_seg([(u + ".out", u + ".u_skip", True), (u + ".skip1", u + ".skip1", True)], xin, up=tl)
                 else:
                     out = self.conv(u + ".out", [u + ".u_skip"], xin, relu=True, up=tl)
-                    if gen_skip:
+                    if gen_skip and not skipsum:
                         s1[3 - ind] = self.conv(u + ".skip1", [u + ".skip1"], xin, relu=True)
+                if skipsum:
+                    s1[3 - ind] = self.conv_relusum(u + ".skipsum", u + ".skip1", xin, u + ".skip2", out)
                 # launch 2, on out: skip2 | cross_conv (stages with skips), res_conv1 (last stage), the next unit's up_conv@low
                 sg = []
                 if gen_skip:
-                    sg.append((u + ".skip2", u + ".skip2", True))
+                    if not skipsum:
+                        sg.append((u + ".skip2", u + ".skip2", True))
                     if ind == 3:
                         sg.append((u + ".cross_conv", u + ".cross_conv", True))
                 if heads and 1 <= ind < 3:
@@ -1044,7 +1095,7 @@ class Graph:
                     got = {sg[0][0]: self.conv(sg[0][0], [sg[0][1]], out, relu=sg[0][2])}
                 tl = got.get(un + ".up_conv@low")
                 if gen_skip:
-                    s2[3 - ind] = got[u + ".skip2"]
+                    s2[3 - ind] = None if skipsum else got[u + ".skip2"]
                     if ind == 3:
                         cross = got[u + ".cross_conv"]
                 if heads:
@@ -1273,6 +1324,8 @@ class Graph:
                     t = op.aux2
                     assert t.off // WINDOW == x.off // WINDOW, (y.name, "both inputs of a conv_cat launch must lie in one 4 GiB window")
                     o.in2_off, o.in2_H, o.in2_W, o.in2_C, o.in2_stride_c, o.in2_stride = t.off, t.H, t.W, p["cat"]["cin"], t.C * t.planes, p["cat"]["stride"]
+                    if p["cat"].get("relusum"):
+                        o.in2_mode, o.in2_acc_scale, o.in2_bias_off = 1, p["cat"]["acc_scale"], p["cat"]["bias_off"]
                 if p.get("ksplit", 1) > 1:
                     o.ksplit, o.kpart_off, o.kcount_off = p["ksplit"], op.scratch[0].off, self.kcount.off + 4 * p["kcount_first"]
                 for j, (sg, t) in enumerate(zip(p.get("segs", []), op.outs)):

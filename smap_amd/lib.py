@@ -50,7 +50,7 @@ class SmapOp(C.Structure):
         ("ksplit", C.c_int32), ("reserved1", C.c_int32), ("kpart_off", C.c_int64), ("kcount_off", C.c_int64),
         ("lane", C.c_int32), ("n_wait", C.c_int32), ("wait_op", C.c_int32 * 4),
         ("in2_off", C.c_int64), ("in2_H", C.c_int32), ("in2_W", C.c_int32), ("in2_C", C.c_int32), ("in2_stride_c", C.c_int32),
-        ("in2_stride", C.c_int32), ("tap_n", C.c_int32), ("tap_scale", C.c_float), ("tap_w_off", C.c_int64),
+        ("in2_stride", C.c_int32), ("in2_mode", C.c_int32), ("in2_acc_scale", C.c_float), ("in2_bias_off", C.c_int64), ("tap_n", C.c_int32), ("tap_scale", C.c_float), ("tap_w_off", C.c_int64),
     ]
 
 

@@ -760,6 +760,7 @@ def test_small_schedule_merged_shared_input_launches(golden_dir, small, monkeypa
     from oracle.graph_interp import run_graph
     _, sd = small
     monkeypatch.setenv("SMAP_MERGE_1X1", merge)
+    monkeypatch.setenv("SMAP_SKIPSUM", "0")              # (the skip convs as segments of these launches; the default -- skip1 + skip2 as one launch -- is below)
     z = np.load(f"{golden_dir}/backbone_small.npz")
     x = torch.from_numpy(z["x"])
     eng = BackboneEngine(sd, 2, 64, 96, DEV, reuse=False, precision=precision)
@@ -1135,6 +1136,71 @@ def test_last_1x1_with_the_shortcut_conv_as_one_gemm(case, x3):
     assert lib.smap_plan_create(bad, 1, C.byref(h)) == -1
     bad = (L.SmapOp * 1)(ops[0])
     bad[0].in2_stride = 3
+    assert lib.smap_plan_create(bad, 1, C.byref(h)) == -1
+
+
+@pytest.mark.parametrize("x3", [True, False], ids=["x3", "f16"])
+@pytest.mark.parametrize("case", [(2, 8, 13, 512, 256, 512, 50), (1, 16, 26, 1024, 256, 1024, 51), (3, 5, 7, 2048, 256, 2048, 50), (2, 16, 24, 256, 256, 256, 51),
+                                  (1, 9, 11, 128, 192, 320, 50)], ids=lambda c: "x".join(map(str, c)))
+def test_two_activated_skip_convs_as_one_launch_and_one_tensor(case, x3):
+    """Graph.conv_relusum / smap_op.in2_mode = 1: relu(skip1(x)) + relu(skip2(out)) (smap.py:218-241; only their sum is ever used, :142-153) as ONE
+    launch writing ONE tensor -- the first conv's accumulators are activated and parked in registers while the second conv runs -- against the
+    f64 evaluation of the two convs on the same operands; each conv with its own power-of-two weight scale (x 40 apart here)."""
+    import torch.nn.functional as F
+    from smap_amd import engine as E
+    from smap_amd import lib as L
+    B, H, W, c1, c2, cout, tile = case
+    gen = torch.Generator().manual_seed(sum(case))
+    sd = {}
+    for pre, c, sc in (("s1", c1, 0.004), ("s2", c2, 0.16)):
+        sd[pre + ".conv.weight"] = torch.randn(cout, c, 1, 1, generator=gen) * sc
+        sd[pre + ".conv.bias"] = torch.randn(cout, generator=gen) * 0.1
+        sd[pre + ".bn.weight"] = torch.rand(cout, generator=gen) + 0.5
+        sd[pre + ".bn.bias"] = torch.randn(cout, generator=gen) * 0.1
+        sd[pre + ".bn.running_mean"] = torch.randn(cout, generator=gen) * 0.1
+        sd[pre + ".bn.running_var"] = torch.rand(cout, generator=gen) + 0.5
+    g = E.Graph(sd, B, 4 * H, 4 * W, keep_ref=True, precision="x3" if x3 else "f16", build=False)
+    g.w_pairs = int(B == 1)
+    xt, ot = g.tensor("x", H, W, c1), g.tensor("o", H, W, c2)
+    out = g.conv_relusum("s", "s1", xt, "s2", ot, tile=tile)
+    xt.first = ot.first = 0
+    g.allocate(reuse=False)
+    ops = g.emit()
+    lib = L.load()
+    h = C.c_void_p()
+    L.check(lib.smap_plan_create(ops, 1, C.byref(h)), "smap_plan_create")
+    arena = torch.zeros(g.arena_bytes, dtype=torch.uint8, device=DEV)
+
+    def put(t, v):
+        v = v.permute(0, 2, 3, 1).contiguous()
+        hi = v.to(torch.float16)
+        if t.planes == 2:
+            lo = (v - hi.float()).to(torch.float16)
+            raw, val = torch.stack([hi, lo], 3).reshape(-1), hi.double() + lo.double()
+        else:
+            raw, val = hi.reshape(-1), hi.double()
+        arena[t.off:t.off + t.nbytes].view(torch.float16).copy_(raw.to(DEV))
+        return val.permute(0, 3, 1, 2)
+    xv, ov = put(xt, torch.randn(B, c1, H, W, generator=gen) * 3), put(ot, torch.randn(B, c2, H, W, generator=gen))
+    blob = g.weight_blob().to(DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.smap_plan_run(h, None, C.c_void_p(arena.data_ptr()), C.c_void_p(blob.data_ptr()), None, st), "run")
+    torch.cuda.synchronize()
+    lib.smap_plan_destroy(h)
+    p = g.ops[0].p
+    q = (lambda w: w.double()) if x3 else (lambda w: w.to(torch.float16).double())
+    a, b = F.conv2d(xv, q(p["w_ref"]), p["b_ref"].double()), F.conv2d(ov, q(p["cat"]["w_ref"]), p["cat"]["b_ref"].double())
+    want = F.relu(a) + F.relu(b)
+    assert (a < 0).any() and (b < 0).any() and (a > 0).any() and (b > 0).any()          # both activations matter
+    raw = arena[out.off:out.off + out.nbytes].view(torch.float16).cpu()
+    got = (raw.view(B, H, W, 2, out.C).double().sum(3) if out.planes == 2 else raw.view(B, H, W, out.C).double()).permute(0, 3, 1, 2)
+    err, mx = (got - want).abs().max().item(), want.abs().max().item()
+    assert torch.isfinite(got).all() and err < ((3e-6 * mx + 1e-6) if x3 else 2e-3 * mx), (err, mx)
+    bad = (L.SmapOp * 1)(ops[0])
+    bad[0].tile = 20                                                                   # K-concatenation yes, relu-sum no (288 registers)
+    assert lib.smap_plan_create(bad, 1, C.byref(h)) == -1
+    bad = (L.SmapOp * 1)(ops[0])
+    bad[0].relu = 1
     assert lib.smap_plan_create(bad, 1, C.byref(h)) == -1
 
 

@@ -55,7 +55,10 @@ def test_x3_graph_emits_split_strides_and_weights(small_sd, monkeypatch, blocks)
     assert n_blk == (18 if blocks else 0)                 # 3 stages x (first block + two identity blocks of layer1 + three identity blocks of layer2)
     # (a first block is 3 launches layer by layer since round 6 -- c1, c2, c3 with the shortcut conv inside, Graph.conv_cat -- and 1 as a whole block)
     assert len(g.ops) == len(g16.ops) - (3 * 2 + 2 * 6 + 2 * 9 if blocks else 0) and g.flops == g16.flops
-    assert sum(1 for op in g.ops if "cat" in op.p) == (9 if blocks else 12) and sum(1 for op in g16.ops if "cat" in op.p) == 12
+    ncat = lambda gr: sum(1 for op in gr.ops if "cat" in op.p and not op.p["cat"].get("relusum"))
+    assert ncat(g) == (9 if blocks else 12) and ncat(g16) == 12
+    # ... and the eight skip pairs of stages 0 / 1 (skip1 on the unit's input + skip2 on its output) are one launch, one tensor each (Graph.conv_relusum)
+    assert sum(1 for op in g.ops if "cat" in op.p and op.p["cat"].get("relusum")) == 8 and not any(t.name.endswith((".skip1", ".skip2")) for t in g.tensors)
     assert not any(op.out is not None and op.out.name.endswith(".downsample") for op in g.ops)
     assert g.weight_blob().numel() > 1.9 * g16.weight_blob().numel()
     for op, o in zip(g.ops, ops):
@@ -491,6 +494,7 @@ def test_merged_launch_descriptors_and_validation(small_sd, monkeypatch):
     import ctypes as C
     from smap_amd import lib as L
     from smap_amd.engine import Graph, OP_CONV, TILES
+    monkeypatch.setenv("SMAP_SKIPSUM", "0")              # (the skip convs as segments: with the default skip1 + skip2 launches only stage 2's two merged launches remain)
     for merge, n in (("2", 18), ("1", 12), ("0", 0)):
         monkeypatch.setenv("SMAP_MERGE_1X1", merge)
         g = Graph(small_sd, 2, 64, 96, precision="x3")

@@ -191,6 +191,27 @@ def test_backbone_ref_matches_reference_at_full_size(golden_dir):
     print("full-size oracle vs imported reference (sampled, channel sums):", worst)
 
 
+def test_default_schedule_wiring_matches_reference_golden(golden_dir, small_model):
+    """The DEFAULT schedule of round 6 -- shortcut convs inside their blocks' last 1x1 (conv_cat), skip1 + skip2 as one launch and one tensor
+    (conv_relusum), the root-depth head as tap dots + stencil (conv_tapdot / tapsum) -- interpreted on CPU, against the golden outputs of the
+    imported reference model."""
+    from smap_amd.engine import Graph, OP_TAPSUM
+    from oracle.graph_interp import run_graph
+    z = np.load(f"{golden_dir}/backbone_small.npz")
+    _, sd = small_model
+    g = Graph(sd, 2, 64, 96, keep_ref=True)
+    g.allocate()
+    assert sum(1 for op in g.ops if "cat" in op.p and op.p["cat"].get("relusum")) == 8 and sum(1 for op in g.ops if op.kind == OP_TAPSUM) == 1
+    assert sum(1 for op in g.ops if "cat" in op.p and not op.p["cat"].get("relusum")) == 12 and sum(1 for op in g.ops if "tap" in op.p) == 1
+    with torch.no_grad():
+        outs = run_graph(g, torch.from_numpy(z["x"]), quantize=False)
+        outs_q = run_graph(g, torch.from_numpy(z["x"]), quantize=True)
+    for a, q, k in zip(outs, outs_q, ("hms", "det_d", "root_d")):
+        ref = z[k]
+        assert np.abs(a.numpy() - ref).max() <= 2e-5 * np.abs(ref).max(), k
+        assert np.abs(q.numpy() - ref).max() <= 2e-2 * np.abs(ref).max(), k
+
+
 @pytest.mark.parametrize("merge", ["1", "2", "0"])
 def test_schedule_wiring_matches_reference_golden(golden_dir, small_model, monkeypatch, merge):
     """The engine's op list, interpreted in fp32 on CPU, reproduces the reference outputs:
@@ -201,6 +222,7 @@ def test_schedule_wiring_matches_reference_golden(golden_dir, small_model, monke
     z = np.load(f"{golden_dir}/backbone_small.npz")
     _, sd = small_model
     monkeypatch.setenv("SMAP_MERGE_1X1", merge)
+    monkeypatch.setenv("SMAP_SKIPSUM", "0")              # (the default -- skip1 + skip2 as one launch -- has its own test below)
     g = Graph(sd, 2, 64, 96, keep_ref=True)
     g.allocate()
     # 203 convs + stem + maxpool + 3 head sums; "2" (every shared-input pair): 2 launches fewer per Upsample_unit of stages 0 / 1, 1 fewer

@@ -198,4 +198,40 @@ cat $O/ab_tap.log
 layers $O d1_f16_tap 16 --depth 1 --steps 6 --warmup 2
 }
 
+v12() {
+# visit 12: tile of the two-way head 1x1 (N = 512 since the root-depth head left it), in situ
+O=gpurun_out/r6v12; mkdir -p $O
+for t in 20 50 51 54 56; do
+  python - <<PY
+import json
+t = json.load(open("smap_amd/tile_table_x3.json"))
+t["16,128,208,256,512,1,1"] = $t
+json.dump(t, open("$O/table_$t.json", "w"), indent=0, sort_keys=True)
+PY
+done
+for rep in 1 2; do
+  for t in 20 50 51 54 56; do
+    SMAP_TILE_TABLE_X3=$R/$O/table_$t.json SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep heads1x1 tile $t" >> $O/ab.log
+  done
+done
+cat $O/ab.log
+}
+
+v13() {
+# visit 13: skip1(x) + skip2(out) as one launch and one tensor (Graph.conv_relusum, smap_op.in2_mode = 1): parity, then in situ
+O=gpurun_out/r6v13; mkdir -p $O
+timeout 1500 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "two_activated_skip or small_schedule or full_size or smap_module or flip_tta" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -6 $O/pytest.log
+for rep in 1 2; do
+  for v in "SMAP_SKIPSUM=0" "SMAP_RELUSUM_TILE=50" "SMAP_RELUSUM_TILE=51"; do
+    env $v SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep depth 2 [$v]" >> $O/ab_skipsum.log
+  done
+done
+for v in "SMAP_SKIPSUM=0" "SMAP_RELUSUM_TILE=50" "SMAP_RELUSUM_TILE=51"; do
+  env $v SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 2>>$O/ab.err | line "depth 1 [$v]" >> $O/ab_skipsum.log
+done
+cat $O/ab_skipsum.log
+layers $O d1_f16_skipsum 16 --depth 1 --steps 6 --warmup 2
+}
+
 "v$1"
