@@ -261,7 +261,7 @@ typedef struct smap_op {
        guarantees that buffers touched by an op on a side lane are not reused before the end of the schedule. */
     int32_t lane, n_wait;
     int32_t wait_op[4];
-    /* SECOND INPUT, concatenated along K (round 6; csrc/conv.hip tiles 20, 50, 51; ksize 1): the op computes
+    /* SECOND INPUT, concatenated along K (round 6; csrc/conv.hip tiles 20, 50, 51, 53, 54; ksize 1): the op computes
            out = act( W [x | x2_sampled] + bias (+ res) )
        -- ONE accumulator over K = Cin + in2_C, the weight matrix [cout_pad][Cin + in2_C] being the two convs' matrices side by side.  This is
        the last 1x1 of a stride-2 / widening Bottleneck TOGETHER with its 1x1 shortcut conv (model/smap.py:60-77, 124-129:

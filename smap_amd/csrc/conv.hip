@@ -790,8 +790,8 @@ hipError_t launch_relusum(const ConvArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-int smap_conv_tile_has_dual(int tile) { return tile == 20 || tile == 50 || tile == 51; }
-int smap_conv_tile_has_relusum(int tile) { return tile == 50 || tile == 51; }
+int smap_conv_tile_has_dual(int tile) { return tile == 20 || tile == 50 || tile == 51 || tile == 53 || tile == 54; }
+int smap_conv_tile_has_relusum(int tile) { return tile == 50 || tile == 51 || tile == 53 || tile == 54; }
 
 // the tap-dot instance (smap_op.tap_n = 9; tile 54 only: one N tile of 256 channels)
 template <bool X3>
@@ -869,6 +869,8 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
         switch (tile) {                                     // (the four-wave 128 x 128 instance needs 288 registers: one wave per SIMD)
             case 50: return a.x3 ? launch_relusum<128, 128, 2, 4, 2, 32, true>(a, st) : launch_relusum<128, 128, 2, 4, 2, 32, false>(a, st);
             case 51: return a.x3 ? launch_relusum<128, 128, 4, 2, 2, 32, true>(a, st) : launch_relusum<128, 128, 4, 2, 2, 32, false>(a, st);
+            case 53: return a.x3 ? launch_relusum<256, 128, 4, 2, 2, 32, true>(a, st) : launch_relusum<256, 128, 4, 2, 2, 32, false>(a, st);     // 249 / 251 registers:
+            case 54: return a.x3 ? launch_relusum<128, 256, 2, 4, 2, 32, true>(a, st) : launch_relusum<128, 256, 2, 4, 2, 32, false>(a, st);     // two waves per SIMD still
             default: return hipErrorInvalidValue;
         }
     }
@@ -877,6 +879,8 @@ hipError_t smap_launch_conv(const ConvArgs& a, int tile, hipStream_t st)
             case 20: return a.x3 ? launch_dual<128, 128, 2, 2, 2, 32, true>(a, st) : launch_dual<128, 128, 2, 2, 2, 32, false>(a, st);
             case 50: return a.x3 ? launch_dual<128, 128, 2, 4, 2, 32, true>(a, st) : launch_dual<128, 128, 2, 4, 2, 32, false>(a, st);
             case 51: return a.x3 ? launch_dual<128, 128, 4, 2, 2, 32, true>(a, st) : launch_dual<128, 128, 4, 2, 2, 32, false>(a, st);
+            case 53: return a.x3 ? launch_dual<256, 128, 4, 2, 2, 32, true>(a, st) : launch_dual<256, 128, 4, 2, 2, 32, false>(a, st);
+            case 54: return a.x3 ? launch_dual<128, 256, 2, 4, 2, 32, true>(a, st) : launch_dual<128, 256, 2, 4, 2, 32, false>(a, st);
             default: return hipErrorInvalidValue;
         }
     }

@@ -121,8 +121,8 @@ def _table_entry(v):
 
 
 REGEPI_TILES = (56,)               # csrc/conv.hip tiles with the register epilogue
-DUAL_TILES = (20, 50, 51)          # csrc/conv.hip tiles with a second-input (K-concatenated) instance (smap_conv_tile_has_dual)
-RELUSUM_TILES = (50, 51)           # ... with a relu(conv) + relu(conv) instance (smap_conv_tile_has_relusum)
+DUAL_TILES = (20, 50, 51, 53, 54)  # csrc/conv.hip tiles with a second-input (K-concatenated) instance (smap_conv_tile_has_dual)
+RELUSUM_TILES = (50, 51, 53, 54)   # ... with a relu(conv) + relu(conv) instance (smap_conv_tile_has_relusum)
 
 
 def tile_legal(tile, *, cout, cout_pad=None, plain3=True, up=False, out_fp32=False, adds=False, x3=True):
@@ -623,7 +623,9 @@ class Graph:
         M, K = self.B * x.H * x.W, c1 + c2
         if tile is None:
             key = f"{self.B},{x.H},{x.W},{c1}+{c2}relusum,{cout},1,1"
-            cands = (pick_tile_x3(M, cout, key) if self.x3 else []) + [50, 51]
+            # measured in situ (profiles/r6_v14_ab_two_input_tiles.log): the 128 x 256 tile (both inputs' rows staged once per launch instead of once
+            # per 128-channel N tile) 860-864 frames/s against 847 with the 128 x 128 tiles; the K-concatenated launches (conv_cat) do not care
+            cands = (pick_tile_x3(M, cout, key) if self.x3 else []) + [54, 53, 50, 51]
             forced = os.environ.get("SMAP_RELUSUM_TILE", "")                     # A/B hook
             tile = int(forced) if forced else next(t for t in cands if t in RELUSUM_TILES)
         assert tile in RELUSUM_TILES, tile

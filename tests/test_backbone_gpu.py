@@ -1068,6 +1068,8 @@ CAT_CASES = [   # B, H (out), W (out), planes (c3's K), in_planes (the shortcut'
     (3, 5, 7, 512, 1024, 2048, 2, 20),         # layer4's: M < one tile
     (2, 16, 24, 64, 64, 256, 1, 50),           # layer1's first block (stride 1: the shortcut reads the block's own input)
     (1, 9, 11, 128, 192, 320, 1, 20),          # Cout not a tile multiple
+    (2, 8, 13, 128, 256, 512, 2, 54),          # 128 x 256 and 256 x 128 instances
+    (1, 16, 26, 256, 512, 1024, 2, 53),
 ]
 
 
@@ -1141,7 +1143,7 @@ def test_last_1x1_with_the_shortcut_conv_as_one_gemm(case, x3):
 
 @pytest.mark.parametrize("x3", [True, False], ids=["x3", "f16"])
 @pytest.mark.parametrize("case", [(2, 8, 13, 512, 256, 512, 50), (1, 16, 26, 1024, 256, 1024, 51), (3, 5, 7, 2048, 256, 2048, 50), (2, 16, 24, 256, 256, 256, 51),
-                                  (1, 9, 11, 128, 192, 320, 50)], ids=lambda c: "x".join(map(str, c)))
+                                  (1, 9, 11, 128, 192, 320, 50), (2, 8, 13, 512, 256, 512, 54), (1, 16, 26, 1024, 256, 1024, 53)], ids=lambda c: "x".join(map(str, c)))
 def test_two_activated_skip_convs_as_one_launch_and_one_tensor(case, x3):
     """Graph.conv_relusum / smap_op.in2_mode = 1: relu(skip1(x)) + relu(skip2(out)) (smap.py:218-241; only their sum is ever used, :142-153) as ONE
     launch writing ONE tensor -- the first conv's accumulators are activated and parked in registers while the second conv runs -- against the

@@ -234,4 +234,41 @@ cat $O/ab_skipsum.log
 layers $O d1_f16_skipsum 16 --depth 1 --steps 6 --warmup 2
 }
 
+v14() {
+# visit 14: wider tiles for the two-input launches (128 x 256 / 256 x 128 instances of conv_cat and conv_relusum), in situ
+O=gpurun_out/r6v14; mkdir -p $O
+timeout 600 python -m pytest tests/test_backbone_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "two_activated_skip or shortcut_conv_as_one_gemm" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -4 $O/pytest.log
+for rep in 1 2; do
+  for v in "SMAP_RELUSUM_TILE=50" "SMAP_RELUSUM_TILE=54" "SMAP_RELUSUM_TILE=53" "SMAP_CAT_TILE=54" "SMAP_CAT_TILE=53" "SMAP_RELUSUM_TILE=54 SMAP_CAT_TILE=54"; do
+    env $v SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep depth 2 [$v]" >> $O/ab.log
+  done
+done
+for v in "SMAP_RELUSUM_TILE=50" "SMAP_RELUSUM_TILE=54" "SMAP_RELUSUM_TILE=53" "SMAP_CAT_TILE=54"; do
+  env $v SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 40 --depth 1 2>>$O/ab.err | line "depth 1 [$v]" >> $O/ab.log
+done
+cat $O/ab.log
+}
+
+v15() {
+# visit 15: in situ, the 128 x 256 tile for the N >= 512 1x1 launches the cold isolated autotune gave 128 x 128 tiles
+O=gpurun_out/r6v15; mkdir -p $O
+python - <<PY
+import json
+base = json.load(open("smap_amd/tile_table_x3.json"))
+var = {"l3c3": {"16,32,52,256,1024,1,1": 54}, "l4c3": {"16,16,26,512,2048,1,1": 54}, "l2c3cat_up3": {"16,64,104,256,512,1,1": 54},
+       "l3l4": {"16,32,52,256,1024,1,1": 54, "16,16,26,512,2048,1,1": 54}, "l3c3_53": {"16,32,52,256,1024,1,1": 53}}
+for k, v in var.items():
+    t = dict(base); t.update(v)
+    json.dump(t, open("$O/table_%s.json" % k, "w"), indent=0, sort_keys=True)
+PY
+for rep in 1 2; do
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep shipped table" >> $O/ab.log
+  for k in l3c3 l4c3 l2c3cat_up3 l3l4 l3c3_53; do
+    SMAP_TILE_TABLE_X3=$R/$O/table_$k.json SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "rep $rep $k" >> $O/ab.log
+  done
+done
+cat $O/ab.log
+}
+
 "v$1"
