@@ -1030,4 +1030,4 @@ extern "C" int smap_preprocess(const unsigned char* src, int h, int w, int nh, i
     return hip_rc(hipGetLastError());
 }
 
-extern "C" const char* smap_version(void) { return "smap_hip gfx950 r5 (assoc + backbone f16|x3 + flip-TTA + persistent conv + whole-Bottleneck launches + plan blob + windowed arena + N segments + split K + lanes)"; }
+extern "C" const char* smap_version(void) { return "smap_hip gfx950 r6 (assoc + backbone f16|x3 + flip-TTA + persistent conv + whole-Bottleneck launches + plan blob v2 + windowed arena + N segments + split K + lanes + two-input launches + tap-dot head + scaled head sum + two-launch peak search)"; }

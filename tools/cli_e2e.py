@@ -87,13 +87,16 @@ def main():
             os.symlink(os.path.realpath(os.path.join(enc, n)), os.path.join(enc + "_few", n))
     for name, folder, extra, env_extra in cases:
         timing = os.path.join(tmp, "timing.json")
-        env = dict(os.environ, PROJECT_HOME=tmp, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), SMAP_CLI_TIMING=timing, **env_extra)
+        # the plan cache of this run lives in the temporary folder: the FIRST case builds the schedules (first_submit_s = seconds of weight
+        # packing), every later case is a "second start" that loads them through smap_plan_create_from_blob
+        env = dict(os.environ, PROJECT_HOME=tmp, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), SMAP_CLI_TIMING=timing,
+                   SMAP_PLAN_CACHE=os.path.join(tmp, "plan_cache"), **env_extra)
         t0 = time.perf_counter()
         r = subprocess.run([sys.executable, os.path.join(ROOT, "exps", "stage3_root2", "test.py"), "-p", os.path.join(tmp, "SMAP.pth"),
                             "-t", "run_inference", "-d", "test", "--batch_size", str(args.batch), "--dataset_path", folder, "--json_name", "e2e"] + extra,
                            capture_output=True, text=True, env=env, cwd=tmp, timeout=1500)
         wall = time.perf_counter() - t0
-        rec = {"case": name, "returncode": r.returncode, "process_wall_s": wall}
+        rec = {"case": name, "returncode": r.returncode, "process_wall_s": wall, "plan_cache": "cold (schedules built and stored)" if not runs else "warm (second start)"}
         if r.returncode == 0 and os.path.exists(timing):
             rec.update(json.load(open(timing)))
             out = os.path.join(tmp, "model_logs", "stage3_root2", "result", "stage3_root2_run_inference_test_e2e.json")

@@ -7,7 +7,7 @@ R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"
 TAG=${1:-final}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+timeout 2700 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
 tail -8 $O/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 timeout 400 python bench.py > $O/bench_x3.json 2> $O/bench_x3.err; echo "rc $?" >> $O/bench_x3.err
@@ -17,9 +17,10 @@ timeout 400 python bench.py --refine --steps 60 > $O/bench_x3_refine.json 2> $O/
 timeout 300 python bench.py --forward-only --batch 1 --graph --steps 300 --warmup 30 > $O/bench_x3_forward_b1.json 2>> $O/bench_x3.err
 timeout 300 python bench.py --forward-only --batch 1 --steps 300 --warmup 30 > $O/bench_x3_forward_b1_kernel_by_kernel.json 2>> $O/bench_x3.err
 timeout 300 python bench.py --precision f16 --steps 60 > $O/bench_f16.json 2>> $O/bench_x3.err
+timeout 300 python bench.py --no-cpu-baseline --batch 1 --depth 1 --launch-frames 0 --steps 200 --warmup 20 > $O/bench_x3_batch1_full_path.json 2>> $O/bench_x3.err
 TAG=$TAG python - <<'PY'
 import json, os
-for f in ("bench_x3", "bench_x3_driver_form", "bench_x3_flip", "bench_x3_refine", "bench_x3_forward_b1", "bench_x3_forward_b1_kernel_by_kernel", "bench_f16"):
+for f in ("bench_x3", "bench_x3_driver_form", "bench_x3_flip", "bench_x3_refine", "bench_x3_forward_b1", "bench_x3_forward_b1_kernel_by_kernel", "bench_f16", "bench_x3_batch1_full_path"):
     try:
         d = json.load(open("gpurun_out/%s/%s.json" % (os.environ["TAG"], f))); c = d["config"]; m = c.get("e2e_parity") or {}
         print(f, round(d["value"], 1), "lf0", c.get("value_launch_frames_0"), "mfma frac", round(d["roofline"]["frac"], 4), "pipe", round(d["roofline"].get("pipe_frac", 0), 4),
@@ -34,6 +35,9 @@ db=$(find $O/prof_default -name "*.db" | head -1); python $R/tools/prof_export.p
 # per-layer, depth 1, one launch per step
 SMAP_PRECISION=x3 SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $O/prof_d1 -o smap -- python $R/bench.py --depth 1 --launch-frames 0 --steps 4 --warmup 2 --no-cpu-baseline > $O/rocprof_d1.log 2>&1
 db=$(find $O/prof_d1 -name "*.db" | head -1); (cd $R; SMAP_PRECISION=x3 python tools/prof_layers.py $db 8 > $O/layers_d1.txt 2>&1); python $R/tools/prof_export.py $db $O/kernel_stats_d1.csv; rm -rf $O/prof_d1
+# per-layer, depth 1, 16 frames per launch (what the default pipeline launches)
+SMAP_PRECISION=x3 SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $O/prof_d1_16 -o smap -- python $R/bench.py --depth 1 --steps 6 --warmup 2 --no-cpu-baseline > $O/rocprof_d1_16.log 2>&1
+db=$(find $O/prof_d1_16 -name "*.db" | head -1); (cd $R; SMAP_PRECISION=x3 python tools/prof_layers.py $db 16 > $O/layers_d1_16_frames.txt 2>&1); rm -rf $O/prof_d1_16
 # HBM traffic: two separate PMC passes
 SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o pmc -- python $R/bench.py --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
 SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o pmc -- python $R/bench.py --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
