@@ -1013,8 +1013,11 @@ class Graph:
         # A block with a shortcut conv (the first of layer2 / 3 / 4; layer1's runs as a whole-block launch above): its last 1x1 and the shortcut
         # as ONE GEMM over K = (planes | in_planes) -- the shortcut tensor is never stored (conv_cat).  SMAP_CAT=0: two launches, as round 5 ran.
         # (Not for arenas beyond one 4 GiB window: both inputs are addressed from one base.)
-        cat = (has_ds and add1 is None and add2 is None and os.environ.get("SMAP_CAT", "1") != "0" and self.tail_tile(planes, stride) is None
-               and self.B * self.H * self.W <= 20 * 512 * 832)
+        # (Not in small schedules -- <= 2 frames of 512x832 --: their launches live on split K and the deep-pipeline 64 x 64 tile, which the
+        #  two-input instances do not have: batch 1 measured 3.4 ms per frame with them against 2.9 without, profiles/r6_final_*.)
+        cat_env = os.environ.get("SMAP_CAT", "")
+        cat = (has_ds and add1 is None and add2 is None and cat_env != "0" and self.tail_tile(planes, stride) is None
+               and self.B * self.H * self.W <= 20 * 512 * 832 and (cat_env == "1" or self.B * self.H * self.W > 2 * 512 * 832))
         idn = x if (not has_ds or cat) else self.conv(pre + ".downsample", [pre + ".downsample"], x, 1, stride, relu=False)
         y = self.conv(pre + ".c1", [pre + ".conv_bn_relu1"], x, 1, 1, relu=True)
         if cat:
@@ -1068,7 +1071,9 @@ class Graph:
             un = f"{pre}upsample.up{ind + 2}"                     # the next unit: its up_conv reads this unit's `out` (commuted with the upsample)
             # The inter-stage skips as ONE tensor per level: skip1(x) + skip2(out) in one launch (conv_relusum); the next stage adds that one tensor.
             # SMAP_SKIPSUM=0: round 5's two tensors (skip1 beside u_skip, skip2 as a segment of the launch on `out`).  Not beyond one 4 GiB window.
-            skipsum = gen_skip and merge and os.environ.get("SMAP_SKIPSUM", "1") != "0" and self.B * self.H * self.W <= 20 * 512 * 832
+            ss_env = os.environ.get("SMAP_SKIPSUM", "")
+            skipsum = (gen_skip and merge and ss_env != "0" and self.B * self.H * self.W <= 20 * 512 * 832
+                       and (ss_env == "1" or self.B * self.H * self.W > 2 * 512 * 832))          # (small schedules: as conv_cat, see _bottleneck)
             if merge:
                 # launch 1, on x:   out = relu(u_skip(x) [+ bilinear(up_conv@low)])  |  skip1 = relu(skip1(x))
                 if gen_skip and not skipsum and (tl is None or merge_mode == "2"):
@@ -1105,7 +1110,8 @@ class Graph:
                         # The root-depth head (res_rd_conv1 -> res_rd_conv2, a 3x3 with ONE output channel) as a 1x1 launch whose epilogue
                         # keeps nine dot products per pixel instead of the 256-channel activation, + a nine-term stencil (conv_tapdot / tapsum):
                         # 0.87 GB per 16 frames and the N = 1 MFMA launch (8.9 TFLOP/s) gone.  SMAP_TAPHEAD=0: round 5's three-way 1x1 + 3x3.
-                        tap = self.chl == 256 and os.environ.get("SMAP_TAPHEAD", "1") != "0"
+                        tap_env = os.environ.get("SMAP_TAPHEAD", "")
+                        tap = self.chl == 256 and tap_env != "0" and (tap_env == "1" or self.B * self.H * self.W > 2 * 512 * 832)
                         m = self.conv(u + ".heads1x1", [u + ".res_conv1", u + ".res_d_conv1"] + ([] if tap else [u + ".res_rd_conv1"]), out, relu=True)
                         c = self.chl
                         head_t["res4"] = self.conv(u + ".res", [u + ".res_conv2"], m, 3, relu=False, in_c_off=0, cin=c, out_fp32=True)

@@ -37,3 +37,13 @@ def golden_dir():
 def smap_cfg():
     from helpers import make_cfg
     return make_cfg
+
+
+@pytest.fixture(autouse=True)
+def two_input_launches_in_test_schedules(monkeypatch):
+    """The schedule builder keeps round 6's launches (conv_cat, conv_relusum, the tap-dot head) out of SMALL schedules (<= 2 frames of 512x832:
+    batch 1 lives on split K and the deep-pipeline tile, smap_amd/engine.py).  The test schedules are small by construction (2 frames of
+    64x96) and exist to exercise exactly those launches: forced on here; the tests of the batch-1 rules remove the switches again."""
+    for k in ("SMAP_CAT", "SMAP_SKIPSUM", "SMAP_TAPHEAD"):
+        if k not in os.environ:
+            monkeypatch.setenv(k, "1")

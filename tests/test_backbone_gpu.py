@@ -889,11 +889,13 @@ def test_split_k_batch_1_full_size_many_runs_bit_for_bit(monkeypatch):
     visible, or a ticket left non-zero, shows here), and agree with the same schedule without split K to the summation-order level."""
     from smap_amd.engine import BackboneEngine
     from smap_amd.model.smap import SMAP
+    for k in ("SMAP_CAT", "SMAP_SKIPSUM", "SMAP_TAPHEAD"):          # (conftest forces round 6's launches on for the small TEST schedules; this is the real batch-1 schedule)
+        monkeypatch.delenv(k, raising=False)
     torch.manual_seed(0)
     sd = recipe_state_dict(SMAP(make_cfg((128, 208))).state_dict())
     x = torch.randn(1, 3, 512, 832, generator=torch.Generator().manual_seed(7)).to(DEV)
     eng = BackboneEngine(sd, 1, 512, 832, DEV, precision="x3")
-    assert sum(1 for op in eng.graph.ops if op.p.get("ksplit", 1) > 1) >= 30
+    assert sum(1 for op in eng.graph.ops if op.p.get("ksplit", 1) > 1) >= 30 and not any("cat" in op.p or "tap" in op.p for op in eng.graph.ops)
     sib = eng.sibling()
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     outs = [eng.new_output(), sib.new_output()]

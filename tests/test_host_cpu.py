@@ -436,6 +436,8 @@ def test_batch_1_schedule_rules_and_arena(monkeypatch):
     from smap_amd import lib as L
     from smap_amd.engine import Graph, OP_CONV, TILES, tile_bk
     sd = _full_size_sd()
+    for k in ("SMAP_CAT", "SMAP_SKIPSUM", "SMAP_TAPHEAD"):          # (conftest forces round 6's launches on for the small TEST schedules; this is the real batch-1 rule)
+        monkeypatch.delenv(k, raising=False)
     for lanes in ("0", "1"):
         monkeypatch.setenv("SMAP_LANES", lanes)
         g = Graph(sd, 1, 512, 832, precision="x3")

@@ -271,4 +271,23 @@ done
 cat $O/ab.log
 }
 
+v16() {
+# visit 16: batch 1 (configs[1]) with and without round 6's launches: the small-schedule rule
+O=gpurun_out/r6v16; mkdir -p $O
+b1() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$1', round(d['value'],1),'fps', round(d['ms_per_step'],3),'ms/frame', d['config']['launch'], 'conv launches', d['config'].get('conv_launches_per_forward'))
+"; }
+B1="--forward-only --batch 1 --steps 300 --warmup 30"
+for rep in 1 2; do
+  for v in "SMAP_X=0" "SMAP_TAPHEAD=1" "SMAP_CAT=1" "SMAP_SKIPSUM=1" "SMAP_CAT=1 SMAP_SKIPSUM=1 SMAP_TAPHEAD=1"; do
+    env $v timeout 300 python bench.py $B1 2>>$O/ab.err | b1 "rep $rep b1 [$v]" >> $O/ab_b1.log
+  done
+done
+env timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "b1 rule, one HIP graph per forward" >> $O/ab_b1.log
+cat $O/ab_b1.log
+}
+
 "v$1"
