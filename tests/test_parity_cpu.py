@@ -67,6 +67,64 @@ def test_a_wrong_coordinate_is_not_a_tie():
         assert m["joints_over_0.1cm_unexplained"] >= 1
 
 
+def _scene_paths(seed, eps, tamper=None):
+    """One frame through both paths; `tamper(bodys, peaks)` edits the HIP side's skeletons / peak table before lifting."""
+    rng = np.random.default_rng(seed)
+    cam = np.asarray(PEOPLE_CAM, np.float64)
+    hms, rdepth, _, _ = synth_scene(8, seed=seed)
+    yy, xx = np.mgrid[0:128, 0:208].astype(np.float32)
+    det_d = np.stack([10.0 * np.sin(xx / (5.0 + k) + k) * np.cos(yy / (7.0 + k)) for k in range(14)]).astype(np.float32)
+    root_d = (rdepth * 2.0).astype(np.float32)
+
+    def path(h, edit=None):
+        bodys, peaks, _ = O.connect(h, root_d, 2, True)
+        if edit is not None:
+            bodys, peaks = bodys.copy(), peaks.copy()
+            edit(bodys, peaks)
+        p2, p3, rz = O.lift(bodys, det_d, root_d, cam)
+        return dict(peaks=peaks, bodys=bodys, p2=p2, p3=p3, rz=rz, hms=h, det_d=det_d, root_d=root_d)
+    noisy = (hms + rng.uniform(-eps, eps, hms.shape).astype(np.float32) * (np.abs(hms) > 0)).astype(np.float32)
+    return path(noisy, tamper), path(hms)
+
+
+def test_a_small_wrong_coordinate_that_moves_a_depth_sample_is_never_called_a_tie():
+    """ADVERSARIAL for the tie classifier: a joint coordinate wrong by 2e-3 .. 5e-2 heat-map px -- 10 to 500 times the centroid
+    noise the measured map difference allows, still far too small to see in the 2D output -- on skeletons whose limbs then sample the depth
+    maps at another pixel.  Looks exactly like a lifter tie (an index step, a joint off by millimetres to centimetres) except for the size of
+    the coordinate difference: every such joint beyond 0.1 cm must come out UNEXPLAINED, whatever joint / person / shift."""
+    flagged = moved = 0
+    for seed in (610, 611, 612, 613):
+        for shift in (2e-3, 1e-2, 5e-2):
+            for joint in (1, 4, 7, 10, 13):
+                def tamper(bodys, peaks, joint=joint, shift=shift):
+                    for p in range(len(bodys)):
+                        if bodys[p, joint, 3] > 0:                      # a joint that exists: x and y off by `shift`
+                            bodys[p, joint, 0] += shift
+                            bodys[p, joint, 1] -= shift
+                hip, ref = _scene_paths(seed, 3e-6, tamper)
+                m = parity.compare([hip], [ref])
+                if m["max_joint_err_cm"] > 0.1:
+                    moved += 1
+                    assert m["joints_over_0.1cm_unexplained"] >= 1 and m["lifter_ties"] < m["joints_over_0.1cm"] + m["lifter_ties"], (seed, shift, joint, m)
+                    flagged += 1
+                else:
+                    assert m["lifter_ties_over_cap"] == 0
+    assert moved >= 3 and flagged == moved, (moved, flagged)                # the sweep does reach the interesting case
+
+
+def test_a_wrong_peak_coordinate_breaks_the_derived_centroid_bound():
+    """The same for the peak table: a centroid off by 2e-3 px (the map noise allows ~1e-4) must show as measured / bound > 1 -- the check
+    that validates the derivation on every matched peak is the one that has to see it."""
+    def tamper(bodys, peaks):
+        ch = int(np.argmax(peaks[:, 0, 0]))                             # a channel with peaks: move its first centroid
+        peaks[ch, 1, 0] += 2e-3
+    hip, ref = _scene_paths(700, 3e-6, tamper)
+    m = parity.compare([hip], [ref])
+    assert m["centroid_noise_max_over_bound"] > 1.0, m
+    clean_hip, clean_ref = _scene_paths(700, 3e-6)
+    assert parity.compare([clean_hip], [clean_ref])["centroid_noise_max_over_bound"] <= 1.0
+
+
 def test_counter_files_are_quoted_only_for_the_build_they_were_measured_on(tmp_path):
     """bench.py's roofline.traffic / pipe_frac_counters come from committed PMC passes; benchkit/buildhash.py ties them to a hash of the
     kernel sources, the header, the tile tables and the schedule builder: one flipped byte in a .hip file and the figures are withheld."""
