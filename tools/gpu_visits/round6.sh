@@ -290,4 +290,16 @@ env timeout 300 python bench.py $B1 --graph 2>>$O/ab.err | b1 "b1 rule, one HIP 
 cat $O/ab_b1.log
 }
 
+v17() {
+# visit 17: are the two backbones in flight better off half a schedule apart?  (after a flush both are submitted back to back and run in step)
+O=gpurun_out/r6v17; mkdir -p $O
+for rep in 1 2; do
+  for v in "SMAP_STAGGER_MS=0" "SMAP_STAGGER_MS=5" "SMAP_STAGGER_MS=9" "SMAP_STAGGER_MS=14"; do
+    env $v SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 2>>$O/ab.err | line "rep $rep 100 steps [$v]" >> $O/ab.log
+    env $v SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 2>>$O/ab.err | line "rep $rep 20 steps [$v]" >> $O/ab.log
+  done
+done
+cat $O/ab.log
+}
+
 "v$1"
