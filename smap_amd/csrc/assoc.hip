@@ -152,31 +152,44 @@ __global__ __launch_bounds__(NMS_NT) void nms_kernel(const float* __restrict__ h
         if (tid == 0) { out[0] = (float)count; out[1] = 0.f; out[2] = 0.f; }
         else if (tid > count) { out[3 * tid] = 0.f; out[3 * tid + 1] = 0.f; out[3 * tid + 2] = 0.f; }
     }
+    // Pass 3 (round 6): first the pixel of every kept peak by RANK (a thread still owns pixel i * NT + tid of chunk i), then ONE lane per peak:
+    // its window values are requested a row of seven at a time and accumulated in the reference's raster order (nmsBase.cu:96-117: same fp32 additions, same
+    // order, bit for bit).  Round 5 computed a centroid inside the chunk loop, in the thread that owned the pixel: a wave that met peaks in three
+    // of its 26 chunks walked three 49-load dependency chains one after the other -- 77 us per launch for ~24 peaks per channel.
+    __shared__ int s_pos[MAXP];
     for (int i = 0; i < nchunk; ++i) {
         const unsigned long long m = s_ballot[i * NMS_NW + wave];
         if (!((m >> lane) & 1ull)) continue;
         const int rank = s_off[i * NMS_NW + wave] + __popcll(m & ((1ull << lane) - 1ull));
-        if (rank >= MAXP) continue;
-        const int p = i * NMS_NT + tid;
+        if (rank < MAXP) s_pos[rank] = i * NMS_NT + tid;
+    }
+    __syncthreads();
+    if (tid < count) {
+        const int p = s_pos[tid];
         const int px = p % W, py = p / W;
         float xAcc = 0.f, yAcc = 0.f, sAcc = 0.f;
-        for (int dy = -3; dy <= 3; ++dy) {
-            const int y = py + dy;
-            if (0 <= y && y < H) {
-                for (int dx = -3; dx <= 3; ++dx) {
-                    const int x = px + dx;
-                    if (0 <= x && x < W) {
-                        const float sc = s[y * W + x];
-                        if (sc > 0) {
-                            xAcc += (float)x * sc;
-                            yAcc += (float)y * sc;
-                            sAcc += sc;
-                        }
-                    }
+#pragma unroll 1
+        for (int dy = -3; dy <= 3; ++dy) {      // a window ROW at a time: seven loads in flight (all 49 at once cost 110 registers -- a 1024-thread
+            const int y = py + dy;              // workgroup of those does not find a CU next to two running backbones: 191 us in situ)
+            if (!(0 <= y && y < H)) continue;
+            float win[7];
+#pragma unroll
+            for (int dx = -3; dx <= 3; ++dx) {
+                const int x = px + dx;
+                win[dx + 3] = (0 <= x && x < W) ? s[y * W + x] : 0.f;          // (outside the map: skipped below like a non-positive value)
+            }
+#pragma unroll
+            for (int dx = -3; dx <= 3; ++dx) {
+                const int x = px + dx;
+                const float sc = win[dx + 3];
+                if (0 <= x && x < W && sc > 0) {
+                    xAcc += (float)x * sc;
+                    yAcc += (float)y * sc;
+                    sAcc += sc;
                 }
             }
         }
-        const int oi = (rank + 1) * 3;
+        const int oi = (tid + 1) * 3;
         out[oi] = xAcc / sAcc + 0.5f;
         out[oi + 1] = yAcc / sAcc + 0.5f;
         out[oi + 2] = s[p];

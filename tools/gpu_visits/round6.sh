@@ -302,4 +302,28 @@ done
 cat $O/ab.log
 }
 
+v18() {
+# visit 18: peak search pass 3 with one lane per peak (49 loads in flight, the reference's accumulation order): bitwise vs the reference build, timing
+O=gpurun_out/r6v18; mkdir -p $O
+timeout 900 python -m pytest tests/test_assoc_gpu.py tests/test_ref_gpu.py -m gpu -q --tb=short -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -4 $O/pytest.log
+(cd /tmp; SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $R/$O/prof -o smap -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/rocprof.log 2>&1)
+db=$(find $R/$O/prof -name "*.db" | head -1); python tools/prof_export.py $db $R/$O/kernel_stats.csv; rm -rf $R/$O/prof
+grep -i "nms\|group\|paf\|lift\|copyBuffer" $O/kernel_stats.csv | cut -c1-160
+SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 60 2>>$O/ab.err | line "60 steps" >> $O/bench.log
+timeout 300 python bench.py --no-cpu-baseline --batch 1 --depth 1 --launch-frames 0 --steps 200 --warmup 20 2>>$O/ab.err | line "batch 1 full path" >> $O/bench.log
+cat $O/bench.log
+}
+
+v19() {
+# visit 19: where do the ~225 copyBuffer launches per step come from?  counts at 5 and 45 timed steps, and with the bench's synthetic extras off
+O=gpurun_out/r6v19; mkdir -p $O
+for cfg in "--steps 5 --warmup 5" "--steps 45 --warmup 5"; do
+  (cd /tmp; SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $R/$O/prof -o smap -- python $R/bench.py $cfg --no-cpu-baseline > $R/$O/rocprof.log 2>&1)
+  db=$(find $R/$O/prof -name "*.db" | head -1); python tools/prof_export.py $db $R/$O/ks.csv > /dev/null; rm -rf $R/$O/prof
+  echo "== $cfg" >> $O/copies.log; grep -i "copyBuffer\|fillBuffer\|nms_mask\|lift_kernel\|stem_kernel" $O/ks.csv | cut -d, -f1-4 | cut -c1-90 >> $O/copies.log
+done
+cat $O/copies.log
+}
+
 "v$1"
