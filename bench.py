@@ -481,6 +481,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    from benchkit.clocks import ClockSampler
+    sampler = ClockSampler(local)             # shader clock + package power the box holds during the timed region (sysfs reads, 50 Hz)
+    sampler.__enter__()
     cpu0 = time.process_time()
     thr0 = thread_cpu_seconds()
     wait0 = pipe.wait_s
@@ -501,6 +504,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    sampler.__exit__()
+    clocks = sampler.summary(t0, t0 + dt)
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
     thr1 = thread_cpu_seconds()
     busiest = sorted(((n, (c - thr0.get(t, (n, 0.0))[1]) / args.steps * 1e3) for t, (n, c) in thr1.items()), key=lambda x: -x[1])[:4]
@@ -577,6 +582,11 @@ def main():
         t, mfma_info = counters_for_build(os.path.join(ROOT, "profiles", "mfma_utilisation_x3.json" if x3 else "mfma_utilisation.json"))
         if t is not None and B == 8:
             mfma_ctr, mfma_src = t["pipe_utilisation"], t["source"]
+        mfma_ctr16, mfma16_info = None, None                    # the same pass over the 16-frame launches the default pipeline issues
+        if x3:
+            t, mfma16_info = counters_for_build(os.path.join(ROOT, "profiles", "mfma_utilisation_x3_16_frames.json"))
+            if t is not None and B == 8 and fpl == t.get("frames_per_launch"):
+                mfma_ctr16 = t["pipe_utilisation"]
 
         def hbm_view(nbytes):                                   # bytes per step -> GB/s over the timed region and its share of the HBM peak
             g = nbytes / step_s / 1e9
@@ -653,11 +663,17 @@ def main():
                          "frac": achieved / PEAK_F16_TFLOPS,
                          "flops_executed_per_algorithmic_flop": 3 if x3 else 1,
                          "pipe_frac": (3 if x3 else 1) * achieved / PEAK_F16_TFLOPS,
+                         # the chip clocks to its power budget: what the box held in the timed region, and pipe_frac against the MFMA
+                         # peak AT that clock (2.5 PFLOP/s is the peak at 2.4 GHz)
+                         "clocks": clocks,
+                         "pipe_frac_at_measured_clock": ((3 if x3 else 1) * achieved / PEAK_F16_TFLOPS / clocks["clock_share_of_max"]) if clocks else None,
                          "pipe_frac_counters": mfma_ctr, "pipe_frac_counters_source": mfma_src,
+                         # busy cycles / available cycles at whatever clock the pass ran at; `pipe_frac` prices time against 2.5 PFLOP/s
+                         "pipe_frac_counters_this_launch_size": mfma_ctr16,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_commit": traffic_info.get("measured_on_commit"),
                          "counters_match_build": bool(traffic_info["counters_match_build"] and mfma_info["counters_match_build"]),
-                         "counters": {"traffic": traffic_info, "pipe_frac_counters": mfma_info},
+                         "counters": {"traffic": traffic_info, "pipe_frac_counters": mfma_info, "pipe_frac_counters_this_launch_size": mfma16_info},
                          "kernel": "conv_igemm_kernel / conv3x3_halo_kernel / convp_kernel / bottleneck_kernel / bottleneck128_kernel (all backbone launches; HIP "
                                    "events: per-schedule span below, rate = algorithmic work of the timed region / its duration when depth > 1)",
                          "hbm": {"peak": PEAK_HBM_GBPS, "unit": "GB/s",

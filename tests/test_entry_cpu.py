@@ -397,3 +397,24 @@ def test_coalesced_pipeline_protocol_without_a_gpu(monkeypatch):
     assert P.make_pipeline(None, None, 4, 8, 8, "cpu", launch_frames=16, do_flip=True).group == 2
     for kw in (dict(launch_frames=0), dict(launch_frames=16, do_flip=True), dict(launch_frames=16, record_mode="generate_result")):
         assert isinstance(P.make_pipeline(None, None, 8, 8, 8, "cpu", **kw), Recorder), kw
+
+
+def test_clock_sampler_reads_hwmon_files_and_survives_their_absence(tmp_path, monkeypatch):
+    """benchkit/clocks.py: the bench line's `roofline.clocks` (shader clock and package power held in the timed region).  With hwmon files:
+    means over the samples inside [t0, t1]; without: None, and the bench goes on."""
+    import time
+    from benchkit import clocks
+    (tmp_path / "freq1_input").write_text("1990000000\n")
+    (tmp_path / "power1_average").write_text("1380000000\n")
+    monkeypatch.setattr(clocks, "_hwmon_dir", lambda i=0: str(tmp_path))
+    t0 = time.perf_counter()
+    with clocks.ClockSampler(0, period_s=0.005) as s:
+        time.sleep(0.06)
+    got = s.summary(t0, time.perf_counter())
+    assert got["samples"] >= 3 and abs(got["sclk_mhz"] - 1990.0) < 1e-6 and abs(got["power_w"] - 1380.0) < 1e-6
+    assert abs(got["clock_share_of_max"] - 1990.0 / 2400.0) < 1e-9
+    assert s.summary(t0 - 10, t0 - 5) is None
+    monkeypatch.setattr(clocks, "_hwmon_dir", lambda i=0: None)
+    with clocks.ClockSampler(0) as s2:
+        pass
+    assert s2.summary() is None

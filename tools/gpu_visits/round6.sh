@@ -326,4 +326,46 @@ done
 cat $O/copies.log
 }
 
+v20() {
+# visit 20: MFMA pipe utilisation by counters over the launches the DEFAULT pipeline issues (16 frames per launch, depth 1 so that kernels
+# do not overlap), next to the 8-frame figure of validate_all.sh; and the driver's command three times (box-internal spread)
+O=gpurun_out/r6v20; mkdir -p $O
+(cd /tmp; SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/pmc_mfma -o pmc -- python $R/bench.py --depth 1 --steps 2 --warmup 2 --no-cpu-baseline > $R/$O/pmc_mfma.log 2>&1)
+python tools/prof_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) $O/mfma_utilisation_x3_16_frames.json 16 > $O/mfma_16.log 2>&1; cat $O/mfma_16.log
+rm -rf $O/pmc_mfma
+for i in 1 2 3; do
+  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/driver_form_$i.json 2>> $O/bench.err
+  python -c "import json; d = json.load(open('$O/driver_form_$i.json')); print('driver form run $i', round(d['value'], 1), d['ms_per_step'], d['config'].get('host_timeline_ms'))"
+done
+}
+
+v21() {
+# visit 21: what clock and power does the box hold under the bench?  (GRBM cycles of the PMC passes x 1/2.4 GHz are 4-14 % below the traced
+# kernel durations: the shader clock under load is not the 2.4 GHz the peak is quoted at)
+O=gpurun_out/r6v21; mkdir -p $O
+rocm-smi --showclocks --showpower --showtemp > $O/idle.txt 2>&1
+timeout 300 python bench.py --steps 1500 --warmup 10 --no-cpu-baseline > $O/bench_400.json 2> $O/bench.err &
+BP=$!
+i=0
+while kill -0 $BP 2>/dev/null; do
+  i=$((i+1)); echo "== sample $i $(date +%s.%N)" >> $O/load.txt
+  rocm-smi --showclocks --showpower --showtemp 2>&1 | grep -i "sclk\\|mclk\\|fclk\\|power\\|junction\\|edge" >> $O/load.txt
+  sleep 0.3
+done
+wait $BP
+python -c "import json; d = json.load(open('$O/bench_400.json')); print('bench 400 steps', round(d['value'], 1))"
+grep -i "sclk\|power" $O/idle.txt | head -4
+grep -i "sclk\|Power (W)" $O/load.txt | sort | uniq -c | sort -k1,1nr | head -40
+}
+
+v22() {
+# visit 22: the bench line with the clock / power the box held in the timed region (benchkit/clocks.py)
+O=gpurun_out/r6v22; mkdir -p $O
+ls /sys/class/drm/card*/device/hwmon/hwmon*/ > $O/hwmon_files.txt 2>&1
+for cfg in "--steps 20 --warmup 5" "" "--depth 1 --launch-frames 0 --steps 60" "--precision f16 --steps 60"; do
+  n=$(echo "$cfg" | tr -d ' -'); timeout 400 python bench.py $cfg --no-cpu-baseline > $O/bench_$n.json 2>> $O/bench.err
+  python -c "import json; d = json.load(open('$O/bench_$n.json')); r = d['roofline']; print('[$cfg]', round(d['value'], 1), 'fps; clocks', r.get('clocks'), 'pipe', round(r['pipe_frac'], 4), 'at clock', r.get('pipe_frac_at_measured_clock'), 'counters', r.get('pipe_frac_counters'), r.get('pipe_frac_counters_this_launch_size'))"
+done
+}
+
 "v$1"

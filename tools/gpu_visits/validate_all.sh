@@ -47,6 +47,10 @@ rm -rf $O/pmc_fetch $O/pmc_write
 SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o pmc -- python $R/bench.py --depth 1 --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_mfma.log 2>&1
 python $R/tools/prof_mfma.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) $O/mfma_utilisation_x3.json > $O/mfma_utilisation_pmc.log 2>&1; cat $O/mfma_utilisation_pmc.log
 rm -rf $O/pmc_mfma
+# the same pass over the 16-frame launches the default pipeline issues
+SMAP_BENCH_NO_LF0=1 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma16 -o pmc -- python $R/bench.py --depth 1 --steps 2 --warmup 2 --no-cpu-baseline > $O/pmc_mfma16.log 2>&1
+python $R/tools/prof_mfma.py $(find $O/pmc_mfma16 -name "*counter_collection.csv" | head -1) $O/mfma_utilisation_x3_16_frames.json 16 > $O/mfma_utilisation_pmc_16_frames.log 2>&1; cat $O/mfma_utilisation_pmc_16_frames.log
+rm -rf $O/pmc_mfma16
 cd $R
 bash tools/host_budget.sh 24 > $O/host_budget.log 2>&1; cat $O/host_budget.log
 timeout 1500 python tools/cli_e2e.py --images 1024 --out $O/cli_e2e.json > $O/cli_e2e.log 2>&1; tail -7 $O/cli_e2e.log | cut -c1-400

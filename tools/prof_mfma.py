@@ -2,7 +2,8 @@
 """MFMA pipe utilisation of one forward from a rocprofv3 PMC pass (its own run, with --kernel-trace only):
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d DIR -o pmc -- \
         python bench.py --depth 1 --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline
-    python tools/prof_mfma.py DIR/.../pmc_counter_collection.csv [profiles/mfma_utilisation_x3.json]
+    python tools/prof_mfma.py DIR/.../pmc_counter_collection.csv [profiles/mfma_utilisation_x3.json [FRAMES_PER_LAUNCH]]
+(FRAMES_PER_LAUNCH = 16 for a pass over `bench.py --depth 1 --steps 2 --warmup 2`, the launches the default pipeline issues.)
 Over the conv launches of the LAST complete forward: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8
 XCDs x 1024 SIMDs).  depth 1 so that kernels do not overlap."""
 import collections
@@ -40,8 +41,10 @@ if blk:
     print(f"   whole-Bottleneck launches alone ({len(blk)}): {mfb / (gab / 8 * 1024):.3f}")
 if len(sys.argv) > 2:          # the figure bench.py quotes next to its arithmetic pipe_frac (roofline.pipe_frac_counters)
     import json
+    fpl = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    cmd = "--depth 1 --launch-frames 0 --steps 2 --warmup 1" if fpl == 8 else "--depth 1 --steps 2 --warmup 2"
     json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE (own pass, --kernel-trace only) over `python bench.py "
-                         "--depth 1 --launch-frames 0 --steps 2 --warmup 1 --no-cpu-baseline`: MFMA busy cycles / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) over the "
-                         f"{len(conv)} conv launches of one 8-frame forward (tools/prof_mfma.py)",
-               "pipe_utilisation": mf / (ga / 8 * 1024), "conv_launches": len(conv), "serial_conv_ms_at_2.4GHz": ga / 8 / 2.4e6,
+                         f"{cmd} --no-cpu-baseline`: MFMA busy cycles / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) over the "
+                         f"{len(conv)} conv launches of one {fpl}-frame forward (tools/prof_mfma.py)",
+               "pipe_utilisation": mf / (ga / 8 * 1024), "conv_launches": len(conv), "frames_per_launch": fpl, "serial_conv_ms_at_2.4GHz": ga / 8 / 2.4e6,
                "whole_block_launches_pipe_utilisation": (mfb / (gab / 8 * 1024)) if blk else None, **stamp()}, open(sys.argv[2], "w"), indent=1)
