@@ -526,24 +526,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     if (SPLITK && S == 1 && o_res) load_res();
     if (SPLITK && S > 1) {
         // raw partial tile -> scratch [tile][k part][BM * BN]; ticket.  Everyone but the last arriver is done.
-        // Coherence WITHOUT fences: the parts of a tile may run on different XCDs, whose L2s are not coherent with each other; an
-        // agent-scope release fence (__threadfence) writes back the WHOLE L2 of the XCD -- measured: a batch-1 forward 3.7 -> 10+ ms
-        // with two parts per tile (profiles/r5_v2_ab_b1.log).  Instead the partials are written and read with agent-scope relaxed
-        // atomic accesses (sc1: written through / read around the non-coherent caches), the writers wait for their stores to be
-        // acknowledged (vmcnt counts stores on gfx9) before the barrier that precedes the ticket, and the ticket is an agent-scope
-        // atomic: when the last arriver sees S - 1, every part is in memory.
-        // This hand-off is OUTSIDE the HIP / LLVM memory model (relaxed accesses, no release / acquire): it rests on gfx942 / gfx950 facts --
-        // an agent-scope atomic store is an sc1 write-THROUGH to memory, an agent-scope atomic load an sc1 read that misses the XCD's L2,
-        // vmcnt counts a store until memory has acknowledged it -- and on hipcc lowering relaxed agent-scope atomics to exactly those
-        // accesses.  So: only for the architectures it was verified on (the #error below), with the stress test of tests/test_backbone_gpu.py
-        // (::test_split_k_batch_1_full_size_many_runs_bit_for_bit: two streams, 40 runs, bit for bit) in the default GPU suite, and with
-        // -DSMAP_SPLITK_ACQREL=1 as the model-conforming form (release on the ticket of every writer, acquire on the last arriver's: an
-        // agent-scope release writes the XCD's L2 back; measured in EXPERIMENTS R6.5).
-#if !defined(__gfx942__) && !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
-#error "split K: the fence-free partial-tile hand-off is verified for gfx942 / gfx950 only; build with -DSMAP_SPLITK_ACQREL=1 elsewhere"
-#endif
+        // Coherence: the parts of a tile may run on different XCDs, whose L2s are not coherent with each other.  The partials are written
+        // and read with agent-scope relaxed atomic accesses (sc1: written through / read around the non-coherent caches), the writers wait
+        // for their stores to be acknowledged (vmcnt counts stores on gfx9) before the barrier that precedes the ticket, and the ticket is
+        // an agent-scope atomic: when the last arriver sees S - 1, every part is in memory.
+        // SHIPPED FORM (SMAP_SPLITK_ACQREL=1, the default): the ticket is a RELEASE read-modify-write of every writer and the last
+        // arriver passes an agent-scope ACQUIRE fence before it reads the parts -- the hand-off the HIP / LLVM memory model asks for
+        // (release sequence over the ticket's RMWs; the workgroup barriers on either side carry it to the other threads).  It costs a
+        // write-back of the XCD's L2 per workgroup: a batch-1 forward 2.89 -> 2.98 ms (EXPERIMENTS R6.5; batch-8 schedules have no split K).
+        // A full __threadfence() per thread was 3.7 -> 10+ ms (profiles/r5_v2_ab_b1.log).
+        // -DSMAP_SPLITK_ACQREL=0 is the fence-free form rounds 5 shipped: OUTSIDE the memory model (relaxed accesses only), resting on
+        // gfx942 / gfx950 facts -- an agent-scope atomic store is an sc1 write-THROUGH to memory, an agent-scope atomic load an sc1 read
+        // that misses the XCD's L2, vmcnt counts a store until memory has acknowledged it -- and on hipcc lowering relaxed agent-scope
+        // atomics to exactly those accesses; it compiles for those two architectures only.  Either form is covered by
+        // tests/test_backbone_gpu.py::test_split_k_batch_1_full_size_many_runs_bit_for_bit (two streams, 40 runs, bit for bit).
 #ifndef SMAP_SPLITK_ACQREL
-#define SMAP_SPLITK_ACQREL 0
+#define SMAP_SPLITK_ACQREL 1
+#endif
+#if !SMAP_SPLITK_ACQREL && !defined(__gfx942__) && !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "split K: the fence-free partial-tile hand-off is verified for gfx942 / gfx950 only; build with -DSMAP_SPLITK_ACQREL=1 elsewhere"
 #endif
         float* part = a.kpart + (size_t)tile_id * S * (BM * BN);
         for (int i = tid; i < BM * BN; i += NT) __hip_atomic_store(part + (size_t)ks * (BM * BN) + i, Cs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -552,7 +553,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         volatile int* s_last = reinterpret_cast<volatile int*>(smem + LDS_BYTES - 16);     // behind the epilogue tile
         if (tid == 0) {
 #if SMAP_SPLITK_ACQREL
-            const unsigned t = __hip_atomic_fetch_add(a.kcount + tile_id, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned t = __hip_atomic_fetch_add(a.kcount + tile_id, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == (unsigned)(S - 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #else
             const unsigned t = atomicAdd(a.kcount + tile_id, 1u);
 #endif

@@ -515,7 +515,7 @@ class Graph:
             # Measured at batch 1 (profiles/r5_v3_*): a part costs ~9 us (partial tile to memory and back, ticket, late epilogue), so
             # only long K loops gain: K = 4608 with 4 parts 57.6 -> 33.0 us, K = 2304 with 2 parts 30.2 -> 25.1, K = 2048 with 4
             # parts 27.9 -> 25.8; K = 1024 with 2 parts LOSES (17.0 -> 19.0), and aiming at 384 / 512 workgroups instead of 256 loses too
-            if K < 2048:
+            if K < int(os.environ.get("SMAP_SPLITK_MINK", "2048")):      # (A/B hook; re-measured with the release / acquire ticket: R6.5)
                 return 1
             s = min(4, 256 // tiles, n_k // 8)
         return s if s >= 2 else 1

@@ -368,4 +368,16 @@ for cfg in "--steps 20 --warmup 5" "" "--depth 1 --launch-frames 0 --steps 60" "
 done
 }
 
+v23() {
+# visit 23: split K with the release / acquire ticket as the shipped default: which K still gains at batch 1?  (and the split-K tests on it)
+O=gpurun_out/r6v23; mkdir -p $O
+timeout 900 python -m pytest tests/test_backbone_gpu.py -q -x -k "split_k" -p no:cacheprovider > $O/pytest_split_k.log 2>&1; tail -3 $O/pytest_split_k.log
+for rep in 1 2; do
+  for cfg in "SMAP_SPLITK_MINK=2048" "SMAP_SPLITK_MINK=2305" "SMAP_SPLITK_MINK=4608" "SMAP_SPLITK=0"; do
+    env $cfg timeout 300 python bench.py --forward-only --batch 1 --graph --steps 300 --warmup 30 > $O/b1.json 2>> $O/bench.err
+    python -c "import json; d = json.load(open('$O/b1.json')); print('rep $rep [$cfg] batch-1 forward graph', round(d['value'], 1), 'fps', round(d['ms_per_step'], 4), 'ms')" | tee -a $O/ab.log
+  done
+done
+}
+
 "v$1"
