@@ -380,4 +380,15 @@ for rep in 1 2; do
 done
 }
 
+v24() {
+# visit 24: the two headline lines again, now that the committed counter files carry this tree's build hash (validate_all.sh measures the
+# counters AFTER its bench lines, which therefore print `traffic: null` whenever a hashed source changed since the previous passes)
+O=gpurun_out/r6v24; mkdir -p $O
+timeout 400 python bench.py > $O/bench_x3.json 2> $O/bench.err
+timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_x3_driver_form.json 2>> $O/bench.err
+for f in bench_x3 bench_x3_driver_form; do
+  python -c "import json; d = json.load(open('$O/$f.json')); r = d['roofline']; print('$f', round(d['value'], 1), 'frac', round(r['frac'], 4), 'traffic', r['traffic'], 'match', r['counters_match_build'], 'ctr', r['pipe_frac_counters'], r['pipe_frac_counters_this_launch_size'], 'clocks', r['clocks'] and (round(r['clocks']['sclk_mhz']), round(r['clocks']['power_w'] or 0)), 'at clock', r['pipe_frac_at_measured_clock'], 'cpu', d['cpu_baseline']['value'])"
+done
+}
+
 "v$1"
