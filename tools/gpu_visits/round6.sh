@@ -391,4 +391,24 @@ for f in bench_x3 bench_x3_driver_form; do
 done
 }
 
+v25() {
+# visit 25: the fused bilinear add with its index arithmetic once per tile row (LDS records) instead of once per thread and pass:
+# bit-for-bit digests of a seeded forward against the previous form (-DSMAP_EPI_ROWREC=0), the Upsample_unit tests, in situ A/B, per-op trace
+O=gpurun_out/r6v25; mkdir -p $O
+OLD=$R/smap_amd/csrc/obj/libsmap_hip_conv_epi_rowrec0.so
+for cfg in "--batch 8 --precision x3" "--batch 1 --precision x3" "--batch 8 --precision f16"; do
+  echo "== $cfg" >> $O/digest.log
+  timeout 300 python tools/forward_digest.py $cfg 2>>$O/err.log | sed 's/^/new /' >> $O/digest.log
+  SMAP_HIP_LIB=$OLD timeout 300 python tools/forward_digest.py $cfg 2>>$O/err.log | sed 's/^/old /' >> $O/digest.log
+done
+cat $O/digest.log
+timeout 900 python -m pytest tests/test_backbone_gpu.py -q -x -k "upsample or bilinear or unit or small_schedule or merged" -p no:cacheprovider > $O/pytest_units.log 2>&1; tail -3 $O/pytest_units.log
+for rep in 1 2; do
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 2>>$O/ab.err | line "rep $rep records per row (new)" | tee -a $O/ab.log
+  SMAP_HIP_LIB=$OLD SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 2>>$O/ab.err | line "rep $rep per thread and pass (old)" | tee -a $O/ab.log
+done
+layers $O d1_f8_new 8 --depth 1 --launch-frames 0 --steps 4 --warmup 2 > /dev/null
+grep "\.out \|total us" $O/layers_d1_f8_new.txt | cut -c1-150
+}
+
 "v$1"
