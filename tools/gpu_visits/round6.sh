@@ -411,4 +411,18 @@ layers $O d1_f8_new 8 --depth 1 --launch-frames 0 --steps 4 --warmup 2 > /dev/nu
 grep "\.out \|total us" $O/layers_d1_f8_new.txt | cut -c1-150
 }
 
+v26() {
+# visit 26: tile 57 (64 x 256, four waves of 64 x 64, 80 KiB of LDS: two workgroups per CU) under the fused bilinear add, where tile 54's
+# 128 KiB epilogue tile leaves one workgroup per CU: the launch alone (cold operands), then in situ through alternative tile tables
+O=gpurun_out/r6v26; mkdir -p $O
+for t in 54 57 53; do
+  timeout 200 python tools/bench_conv.py --x3 --rotate 3 --only L20,L21,L3 --tile-override L20:$t,L21:$t,L3:$t 2>>$O/err.log | tee -a $O/alone.log
+done
+for rep in 1 2; do
+  for tb in "" tools/tables/x3_tile57_up4.json tools/tables/x3_tile57_up4_up3.json; do
+    SMAP_TILE_TABLE_X3=$tb SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 2>>$O/ab.err | line "rep $rep table [$tb]" | tee -a $O/ab.log
+  done
+done
+}
+
 "v$1"
