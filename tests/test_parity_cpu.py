@@ -154,3 +154,61 @@ def test_counter_files_are_quoted_only_for_the_build_they_were_measured_on(tmp_p
     # a counter file from before the stamp existed (no build_hash) is never quoted
     json.dump({"hbm_read_bytes_per_batch": 1.0, "hbm_write_bytes_per_batch": 2.0, "source": "old"}, open(cj, "w"))
     assert H.counters_for_build(str(cj))[0] is None
+
+
+def _one_peak_maps(delta_rel=0.0, bump=None):
+    """Reference and "HIP" frames over one hand-made key-point map: a plateau of two neighbouring pixels whose values differ by
+    `delta_rel` of the map scale (the reference prefers the left one), the HIP side with the order flipped; `bump` = (value) adds a
+    genuinely different local maximum to the HIP side only."""
+    cam = np.asarray(PEOPLE_CAM, np.float64)
+    hms, rdepth, _, _ = synth_scene(4, seed=900)
+    root_d = (rdepth * 2.0).astype(np.float32)
+    yy, xx = np.mgrid[0:128, 0:208].astype(np.float32)
+    det_d = np.stack([10.0 * np.sin(xx / (5.0 + k) + k) * np.cos(yy / (7.0 + k)) for k in range(14)]).astype(np.float32)
+    scale = float(np.abs(hms[:15]).max())
+    ref_h, hip_h = hms.copy(), hms.copy()
+    c, y, x = 3, 100, 180                                              # an empty corner of channel 3
+    assert float(np.abs(hms[c, y - 3:y + 4, x - 3:x + 5]).max()) < 0.2 * scale     # (background only)
+    top = np.float32(0.5 * scale)
+    ref_h[c, y, x], ref_h[c, y, x + 1] = top, np.float32(top - delta_rel * scale)
+    hip_h[c, y, x], hip_h[c, y, x + 1] = np.float32(top - delta_rel * scale), top
+    if bump is not None:
+        hip_h[5, 20, 190] = np.float32(bump * scale)                   # channel 5, nothing near it in the reference
+
+    def path(h):
+        bodys, peaks, _ = O.connect(h, root_d, 2, True)
+        p2, p3, rz = O.lift(bodys, det_d, root_d, cam)
+        return dict(peaks=peaks, bodys=bodys, p2=p2, p3=p3, rz=rz, hms=h, det_d=det_d, root_d=root_d)
+    return path(hip_h), path(ref_h)
+
+
+def test_a_flipped_plateau_is_a_tie_only_below_the_margin_and_a_new_maximum_never_is():
+    """ADVERSARIAL for the PEAK classifier: (a) two neighbouring pixels 2.5e-7 of the map scale apart (four fp32 steps), winner flipped in one path -- the
+    situation the split-precision backbone produces a few times per 10 000 candidates -- counts as differing peaks, none of them clear;
+    (b) the same flip with the pixels 1e-4 apart (no rounding of the backbone explains that) must be a CLEAR mismatch; (c) a local
+    maximum that exists in one path only, 30 % of the map scale high, must be a clear mismatch whatever else agrees."""
+    hip, ref = _one_peak_maps(2.5e-7)
+    m = parity.compare([hip], [ref])
+    assert m["peaks_differing"] == 2 and m["peaks_clear_mismatch"] == 0 and m["peaks_differing_max_margin"] < parity.NEAR_TIE, m
+    hip, ref = _one_peak_maps(1e-4)
+    m = parity.compare([hip], [ref])
+    assert m["peaks_differing"] == 2 and m["peaks_clear_mismatch"] == 2, m
+    hip, ref = _one_peak_maps(0.0, bump=0.3)                            # (exact plateau: neither path keeps either pixel -- strict >)
+    m = parity.compare([hip], [ref])
+    assert m["peaks_clear_mismatch"] >= 1 and m["peaks_differing_max_margin"] > 0.1, m
+
+
+def test_a_peak_table_that_lost_a_peak_of_its_own_maps_is_a_mismatch_not_a_tie():
+    """ADVERSARIAL: identical maps in both paths (so no decision can be called close), but the HIP side's peak TABLE lacks one peak its
+    maps contain -- what a broken scan / rank step of the NMS kernel would produce.  peak_match must drop below 1 and the missing
+    peak must be counted unmatched; nothing in the tie accounting may absorb it."""
+    def tamper(bodys, peaks):
+        ch = int(np.argmax(peaks[:, 0, 0]))
+        n = int(peaks[ch, 0, 0])
+        peaks[ch, 1:n] = peaks[ch, 2:n + 1]                             # drop the first centroid of the fullest channel
+        peaks[ch, n] = 0
+        peaks[ch, 0, 0] = n - 1
+    hip, ref = _scene_paths(820, 0.0, tamper)
+    m = parity.compare([hip], [ref])
+    assert m["peaks_differing"] == 0 and m["peaks_clear_mismatch"] == 0             # the maps agree everywhere
+    assert m["peak_match"] < 1.0 and m["peaks_unmatched"] >= 1, m
