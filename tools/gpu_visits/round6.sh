@@ -425,4 +425,17 @@ for rep in 1 2; do
 done
 }
 
+v27() {
+# visit 27: the whole library under other instruction-scheduling switches of the compiler (tools/build_flags.py): same bits? faster?
+O=gpurun_out/r6v27; mkdir -p $O
+timeout 300 python tools/forward_digest.py 2>>$O/err.log | sed 's/^/shipped /' | tee -a $O/digest.log
+SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 2>>$O/ab.err | line "shipped (first)" | tee -a $O/ab.log
+for tag in maxilp maxmem nopostsched bias0 trackers; do
+  LIB=$R/smap_amd/csrc/obj/libsmap_hip_flags_$tag.so
+  SMAP_HIP_LIB=$LIB timeout 300 python tools/forward_digest.py 2>>$O/err.log | sed "s/^/$tag /" | tee -a $O/digest.log
+  SMAP_HIP_LIB=$LIB SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 2>>$O/ab.err | line "$tag" | tee -a $O/ab.log
+  SMAP_BENCH_NO_LF0=1 timeout 300 python bench.py --no-cpu-baseline --steps 100 2>>$O/ab.err | line "shipped (after $tag)" | tee -a $O/ab.log
+done
+}
+
 "v$1"
