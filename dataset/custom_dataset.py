@@ -35,11 +35,8 @@ class CustomDataset(Dataset):
 
     @staticmethod
     def _read_bgr(path):
-        if path.endswith(".npy"):
-            return np.load(path)
-        from PIL import Image, ImageOps
-        # cv2.imread(IMREAD_COLOR) (custom_dataset.py:33 upstream) applies the EXIF orientation; PIL does not by itself
-        return np.asarray(ImageOps.exif_transpose(Image.open(path)).convert("RGB"))[:, :, ::-1].copy()
+        from dataset.decode import read_bgr          # (numpy + PIL only: the decode workers of the CLI import it without torch)
+        return read_bgr(path)
 
     def __getitem__(self, index):
         image_path = self.image_list[index].rstrip()

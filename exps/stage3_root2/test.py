@@ -55,7 +55,11 @@ class DevicePreprocLoader:
     normalise in one HIP kernel per image (smap_amd/preprocess.py).  The decodes run AHEAD of the consumer on a small thread pool
     (PIL's decoders and numpy's file reads release the GIL): at ~800 frames/s of engine, one thread decoding a 1080p JPEG in ~10 ms
     would be the whole run (profiles/r5_cli_e2e.json: 62 frames/s with one thread, 333 with 8, 461 with 32).  SMAP_DECODE_THREADS
-    (default: up to 16 of the allowed CPUs; 1 = decode in the consumer's thread, the round-4 behaviour)."""
+    (default: up to 16 of the allowed CPUs; 1 = decode in the consumer's thread, the round-4 behaviour).
+    SMAP_DECODE_PROCS=<n>: the decoders as n WORKER PROCESSES (python -m dataset.decode: numpy + PIL only) writing into one shared-memory
+    block, one slot per worker; the pool threads of this process then only talk to their worker and copy its slot into page-locked memory.
+    What threads cannot scale past is the part of a decode that holds the interpreter lock (PIL's packers, file objects): ~600 frames/s on
+    the bench's image mix, below the engine (EXPERIMENTS R6.11).  SMAP_DECODE_SLOT_MB (default 16): a larger frame is decoded in-thread."""
 
     def __init__(self, dataset, indices, batch_size, cfg, device):
         self.ds, self.idx, self.bs, self.cfg, self.device = dataset, list(indices), batch_size, cfg, device
@@ -64,6 +68,10 @@ class DevicePreprocLoader:
         except AttributeError:
             allowed = os.cpu_count() or 1
         self.threads = int(os.environ.get("SMAP_DECODE_THREADS", "0")) or max(1, min(16, allowed))
+        self.procs = int(os.environ.get("SMAP_DECODE_PROCS", "0"))
+        if self.procs > 0:
+            self.threads = self.procs                        # one pool thread per worker process
+        self.slot_bytes = int(os.environ.get("SMAP_DECODE_SLOT_MB", "16")) << 20
 
     def __len__(self):
         return (len(self.idx) + self.bs - 1) // self.bs
@@ -77,14 +85,24 @@ class DevicePreprocLoader:
                 yield imgs, list(names), scales
             return
         import collections
+        import contextlib
         from concurrent.futures import ThreadPoolExecutor
         ahead = max(2 * self.threads, 3 * self.bs)           # images being decoded or waiting: bounds the host memory (~6 MB per 1080p frame)
-        def decode(i):
-            # ... and leave the frame in PAGE-LOCKED memory (torch's caching host allocator recycles the blocks): the consumer's
+
+        def pinned(img):
+            # ... leave the frame in PAGE-LOCKED memory (torch's caching host allocator recycles the blocks): the consumer's
             # upload is then an asynchronous DMA instead of a blocking pageable copy (~1 ms per 1080p frame of the consumer's time)
+            buf = torch.empty(img.shape, dtype=torch.uint8, pin_memory=True)
+            np.copyto(buf.numpy(), img)                      # (one copy, GIL released; `img` may be a read-only view of the decoder's bytes)
+            return buf
+
+        def decode(i):
             img, name = self.ds.raw(i)
-            return torch.from_numpy(np.ascontiguousarray(img)).pin_memory(), name
-        with ThreadPoolExecutor(self.threads) as ex:
+            return pinned(img), name
+        workers = contextlib.ExitStack()
+        if self.procs > 0:
+            decode = self._process_decoders(workers, pinned)
+        with workers, ThreadPoolExecutor(self.threads) as ex:
             todo, futs = iter(self.idx), collections.deque()
 
             def fill():
@@ -101,6 +119,64 @@ class DevicePreprocLoader:
                 raws, names = zip(*got)
                 imgs, scales = preprocess_batch(raws, self.cfg.INPUT.MEANS, self.cfg.INPUT.STDS, self.device)
                 yield imgs, list(names), scales
+
+
+    def _process_decoders(self, stack, pinned):
+        """Start SMAP_DECODE_PROCS workers (dataset/decode.py) over one shared-memory block; -> decode(i) for the pool threads.  A pool
+        thread takes a free worker and its slot per frame: it writes "<slot>\\t<path>", blocks on the answer (no interpreter lock held), copies the
+        slot into page-locked memory.  `stack` closes the workers' pipes, waits for them and unlinks the block when the iteration ends."""
+        import queue
+        import subprocess
+        import sys
+        from multiprocessing import shared_memory
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        shm = shared_memory.SharedMemory(create=True, size=self.procs * self.slot_bytes)
+        view = np.frombuffer(shm.buf, np.uint8)
+        procs = [subprocess.Popen([sys.executable, "-m", "dataset.decode", shm.name, str(self.slot_bytes)], cwd=root, text=True, bufsize=1,
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=dict(os.environ, OMP_NUM_THREADS="1"))
+                 for _ in range(self.procs)]
+        free = queue.Queue()
+        for k in range(self.procs):
+            free.put(k)
+
+        def close():
+            nonlocal view
+            for p in procs:
+                try:
+                    p.stdin.close()
+                except Exception:
+                    pass
+            for p in procs:
+                try:
+                    p.wait(timeout=5)
+                except Exception:
+                    p.kill()
+            view = None
+            shm.close()
+            shm.unlink()
+        stack.callback(close)
+
+        def decode(i):
+            k = free.get()                                   # a worker and its slot, for this frame (as many pool threads as workers: no wait)
+            try:
+                p = procs[k]
+                path = self.ds.image_list[i].rstrip()
+                name = path.replace(self.ds.dataset_path, "").lstrip("/")
+                p.stdin.write(f"{k}\t{path}\n")
+                p.stdin.flush()
+                ans = p.stdout.readline().split(None, 3)
+                if len(ans) < 3:
+                    raise RuntimeError(f"decode worker {k} died on {path}")
+                h, w = int(ans[1]), int(ans[2])
+                if h == -1:                                  # larger than a slot: here, in this thread
+                    return pinned(self.ds.raw(i)[0]), name
+                if h < 0:
+                    raise RuntimeError(f"decode worker: {path}: {ans[3] if len(ans) > 3 else 'failed'}")
+                n = h * w * 3
+                return pinned(view[k * self.slot_bytes:k * self.slot_bytes + n].reshape(h, w, 3)), name
+            finally:
+                free.put(k)
+        return decode
 
 
 class _DryRunPipeline:

@@ -6,6 +6,8 @@ kernel (`smap_preprocess`) writes the letter-boxed, normalised fp32 frame straig
 resized size and the padding offsets."""
 import ctypes as C
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -84,7 +86,12 @@ def preprocess_batch(images, means, stds, device, net_w=832, net_h=512):
     keep = []
     with torch.cuda.device(device):
         for i, im in enumerate(images):
-            t = torch.as_tensor(np.ascontiguousarray(im) if not isinstance(im, torch.Tensor) else im.contiguous())
+            if isinstance(im, torch.Tensor):
+                t = im.contiguous()
+            else:
+                with warnings.catch_warnings():          # the decoder's frames are read-only views of its bytes: they are only read here
+                    warnings.simplefilter("ignore", UserWarning)
+                    t = torch.as_tensor(np.ascontiguousarray(im))
             if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
                 raise ValueError("images must be uint8 HxWx3 (BGR)")
             h0, w0 = int(t.shape[0]), int(t.shape[1])

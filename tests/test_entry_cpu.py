@@ -418,3 +418,55 @@ def test_clock_sampler_reads_hwmon_files_and_survives_their_absence(tmp_path, mo
     with clocks.ClockSampler(0) as s2:
         pass
     assert s2.summary() is None
+
+
+def test_process_decoders_hand_over_the_frames_the_in_thread_decoder_reads(tmp_path):
+    """exps/stage3_root2/test.py::DevicePreprocLoader with SMAP_DECODE_PROCS: worker processes (dataset/decode.py: numpy + PIL only) decode into
+    one shared-memory block, the loader's pool threads copy their slot out.  Same bytes as the in-thread decoder for PNG, JPEG (EXIF
+    orientation applied) and .npy files; a frame larger than a slot is decoded in-thread; a broken file raises in the consumer; the block
+    is unlinked when the iteration ends."""
+    import contextlib
+    import importlib.util
+    import types
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from dataset.decode import read_bgr
+    spec = importlib.util.spec_from_file_location("smap_cli_test", os.path.join(ROOT, "exps", "stage3_root2", "test.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    rng = np.random.default_rng(5)
+    paths = []
+    for i, (h, w, ext) in enumerate([(40, 60, "png"), (64, 48, "jpg"), (30, 30, "npy"), (200, 300, "png"), (50, 70, "jpg")]):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        p = str(tmp_path / f"f{i}.{ext}")
+        if ext == "npy":
+            np.save(p, a)
+        elif i == 4:
+            ex = Image.Exif()
+            ex[0x0112] = 6                                   # "rotated 90 degrees": cv2.imread applies it
+            Image.fromarray(a).save(p, quality=95, exif=ex)
+        else:
+            Image.fromarray(a).save(p)
+        paths.append(p)
+    ds = types.SimpleNamespace(image_list=paths, dataset_path=str(tmp_path), raw=lambda i: (read_bgr(paths[i]), os.path.basename(paths[i])))
+    ld = cli.DevicePreprocLoader.__new__(cli.DevicePreprocLoader)
+    ld.ds, ld.procs, ld.slot_bytes = ds, 2, 64 * 1024        # 64 KiB slots: the 200x300 frame (180 kB) does not fit
+    shm_dir = "/dev/shm"
+    before = set(os.listdir(shm_dir)) if os.path.isdir(shm_dir) else set()
+    with contextlib.ExitStack() as stack:
+        decode = ld._process_decoders(stack, lambda img: np.array(img))
+        during = (set(os.listdir(shm_dir)) if os.path.isdir(shm_dir) else set()) - before
+        with ThreadPoolExecutor(2) as ex:
+            got = list(ex.map(decode, range(len(paths))))
+        for i, (img, name) in enumerate(got):
+            assert name == os.path.basename(paths[i])
+            assert np.array_equal(img, read_bgr(paths[i])), i
+        assert got[4][0].shape == (70, 50, 3)                 # the EXIF rotation happened in the worker too
+        bad = str(tmp_path / "broken.png")
+        with open(bad, "wb") as f:
+            f.write(b"not a png")
+        paths.append(bad)
+        with pytest.raises(RuntimeError):
+            decode(len(paths) - 1)
+    if os.path.isdir(shm_dir):
+        assert during and not (during & set(os.listdir(shm_dir)))       # the block existed while the loader ran and is gone now

@@ -397,8 +397,8 @@ def test_device_preprocess_equals_host_dataset(tmp_path):
 
 
 def test_cli_device_preprocess_loader_equals_host_loader(tmp_path):
-    """`test.py --device_preprocess 1` (decode-ahead thread pool, page-locked staging, resize / pad / normalise on the GPU) writes the same
-    result file as the reference's loader path (DataLoader + host resize), record for record, bit for bit -- the pre-processing kernel
+    """`test.py --device_preprocess 1` (decode-ahead thread pool or worker processes, page-locked staging, resize / pad / normalise on the GPU)
+    writes the same result file as the reference's loader path (DataLoader + host resize), record for record, bit for bit -- the pre-processing kernel
     is bit-exact and the loader keeps the frame order; five images of four sizes, batch 2 (a ragged last batch)."""
     from model.smap import SMAP
     imgdir = tmp_path / "imgs"
@@ -414,7 +414,8 @@ def test_cli_device_preprocess_loader_equals_host_loader(tmp_path):
             sd[k] = sd[k] + 40.0
     torch.save({"model": sd}, tmp_path / "SMAP.pth")
     res = {}
-    for tag, extra, env_extra in (("host", [], {}), ("device", ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "3"})):
+    for tag, extra, env_extra in (("host", [], {}), ("device", ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "3"}),
+                                  ("procs", ["--device_preprocess", "1"], {"SMAP_DECODE_PROCS": "2", "SMAP_DECODE_SLOT_MB": "4"})):   # (1080p does not fit 4 MB)
         env = dict(os.environ, PROJECT_HOME=str(tmp_path), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **env_extra)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "exps", "stage3_root2", "test.py"), "-p", str(tmp_path / "SMAP.pth"),
                             "-t", "run_inference", "-d", "test", "--batch_size", "2", "--dataset_path", str(imgdir), "--json_name", tag],
@@ -423,6 +424,7 @@ def test_cli_device_preprocess_loader_equals_host_loader(tmp_path):
         res[tag] = json.loads((tmp_path / "model_logs" / "stage3_root2" / "result" / f"stage3_root2_run_inference_test_{tag}.json").read_text())
     assert len(res["host"]["3d_pairs"]) >= 3, "the set-up must produce frames with persons"
     assert res["device"] == res["host"]
+    assert res["procs"] == res["host"]                # decoders as worker processes over shared memory (SMAP_DECODE_PROCS): the same file
 
 
 def _annotated_set(tmp_path, net, dev, sizes, seed):

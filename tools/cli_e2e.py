@@ -78,6 +78,8 @@ def main():
     cases = [("encoded jpg/png, GPU pre-processing, 16 decode threads (default)", enc, ["--device_preprocess", "1"], {}),
              ("encoded jpg/png, GPU pre-processing, 8 decode threads", enc, ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "8"}),
              ("encoded jpg/png, GPU pre-processing, 32 decode threads", enc, ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "32"}),
+             ("encoded jpg/png, GPU pre-processing, 16 decode PROCESSES (SMAP_DECODE_PROCS)", enc, ["--device_preprocess", "1"], {"SMAP_DECODE_PROCS": "16"}),
+             ("encoded jpg/png, GPU pre-processing, 32 decode PROCESSES", enc, ["--device_preprocess", "1"], {"SMAP_DECODE_PROCS": "32"}),
              ("encoded jpg/png, GPU pre-processing, ONE decode thread (round-4 loader)", enc, ["--device_preprocess", "1"], {"SMAP_DECODE_THREADS": "1"}),
              (".npy frames (no decoder), GPU pre-processing", raw, ["--device_preprocess", "1"], {}),
              ("encoded jpg/png, host pre-processing (the reference's DataLoader path), first 128 images", enc + "_few", [], {})]

@@ -438,4 +438,28 @@ for tag in maxilp maxmem nopostsched bias0 trackers; do
 done
 }
 
+v28() {
+# visit 28: the image decoder hands over BGR bytes from PIL's own packer (no reversed-stride numpy copy) and copies once into page-locked
+# memory: loader tests, then the shipped CLI end to end on 1024 image files
+O=gpurun_out/r6v28; mkdir -p $O
+timeout 1200 python -m pytest tests/test_entry_gpu.py -q -x -p no:cacheprovider > $O/pytest_entry.log 2>&1; tail -3 $O/pytest_entry.log
+timeout 1500 python tools/cli_e2e.py --images 1024 --out $O/cli_e2e.json > $O/cli_e2e.log 2>&1
+python -c "
+import json
+d = json.load(open('$O/cli_e2e.json'))
+for r in d['runs']: print(r['case'], '|', round(r['frames_per_s'], 1), 'fps overall |', round(r['frames_per_s_after_engine_build'], 1), 'after engine build | loader', round(r['loader_s'], 2), 's submit', round(r['submit_s'], 2), 's')
+"
+}
+
+v29() {
+# visit 29: the CLI end to end again: process decoders, and the interpreter's switch interval
+O=gpurun_out/r6v29; mkdir -p $O
+timeout 1500 python tools/cli_e2e.py --images 1024 --out $O/cli_e2e.json > $O/cli_e2e.log 2>&1
+python -c "
+import json
+d = json.load(open('$O/cli_e2e.json'))
+for r in d['runs']: print(r['case'], '|', round(r['frames_per_s'], 1), 'fps overall |', round(r['frames_per_s_after_engine_build'], 1), 'after engine build | loader', round(r['loader_s'], 2), 's submit', round(r['submit_s'], 2), 's')
+"
+}
+
 "v$1"
